@@ -1,0 +1,308 @@
+"""
+Rolling-stock description for the MI355X train-control solver.
+
+`Train` mirrors the reference loader (`mseetc/train.py:9-219`): a plain, mutable
+attribute bag filled from a TTOBench json file, which callers are free to edit
+between solver constructions (figure5.py:88, figure10.py:17-22).  The solver
+reads the attributes at construction time.  `TrainModel` carries the specific
+Davis coefficients (train.py:175-187, 225-277); the ODE itself is integrated on
+the device (csrc/), `TrainIntegrator` exposes single-interval integration through
+the same C ABI.  Integrator option classes: train.py:457-534.
+"""
+
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+
+from .utils import Options, StaticLosses, checkTTOBenchVersion, convertUnit, splitLosses
+
+_DATA_DIR = Path(__file__).resolve().parent.parent / 'data'
+
+# (json key, attribute, sign, mandatory): sign -1 stores -abs(value) (train.py:81-91)
+_FIELDS = (
+    ('max traction force', 'forceMax', +1),
+    ('max reg braking force', 'forceMin', -1),
+    ('max pn braking force', 'forceMinPn', -1),
+    ('max traction power', 'powerMax', +1),
+    ('max reg braking power', 'powerMin', -1),
+    ('max acceleration', 'accMax', +1),
+    ('max deceleration', 'accMin', -1),
+)
+
+
+def _quantity(entry, sign=+1):
+    val = entry['value']
+    return convertUnit(-abs(val) if sign < 0 else val, entry['unit'])
+
+
+class Train():
+
+    def __init__(self, config, pathJSON=_DATA_DIR / 'trains') -> None:
+
+        self.g = 9.81  # acceleration of gravity [m/s^2]
+
+        if not isinstance(config, dict):
+            raise ValueError("Train configuration should be provided as a dictionary!")
+
+        if 'id' not in config:
+            raise ValueError("Train ID must be specified in configuration!")
+
+        with open(Path(pathJSON) / (config['id'] + '.json')) as file:
+            data = json.load(file)
+
+        checkTTOBenchVersion(data, ['1.1', '1.2', '1.3'])
+
+        # config overrides: None drops a limit, {'unit','value'} replaces it (train.py:36-66);
+        # the caller's dict is left untouched (the reference pops 'id' from it)
+        optional = {"max acceleration", "max deceleration"}
+        overrides = {k: v for k, v in config.items() if k != 'id'}
+        used = set()
+
+        for key, val in overrides.items():
+
+            if val is None and key in data:
+                del data[key]
+                used.add(key)
+                continue
+
+            if not isinstance(val, dict) or set(val.keys()) != {'unit', 'value'}:
+                raise ValueError("Configuration field '{}' should be specified as a dictionary with 'unit' and 'value' keys!".format(key))
+
+            if key in data or key in optional:
+                data[key] = val
+                used.add(key)
+
+        if set(overrides) != used:
+            raise ValueError("Redundant fields in train configuration: {}!".format(', '.join(set(overrides) - used)))
+
+        self.mass = _quantity(data['mass'])  # [kg]
+
+        self.rho = _quantity(data['rho'])  # rotating-mass factor [-]
+
+        if self.rho < 1:
+            self.rho += 1  # 6% -> 0.06 -> 1.06
+
+        self.velocityMax = _quantity(data['max speed'])  # [m/s]
+
+        for key, attr, sign in _FIELDS:
+            setattr(self, attr, _quantity(data[key], sign) if key in data else None)
+
+        self.r0 = _quantity(data['rolling resistance r0'])  # [N]
+        self.r1 = _quantity(data['rolling resistance r1'])  # [N/(m/s)]
+        self.r2 = _quantity(data['rolling resistance r2'])  # [N/(m/s)^2]
+
+        hasT, hasR = 'efficiency traction' in data, 'efficiency reg brake' in data
+
+        if hasT or hasR:
+
+            if not (hasT and hasR):
+                raise ValueError("Both efficiencies need to be specified in json file!")
+
+            self.etaTraction = _quantity(data['efficiency traction'])
+            self.etaRgBrake = _quantity(data['efficiency reg brake'])
+
+        self.checkFields()
+
+    def checkFields(self):
+
+        def bad(x):
+            return x is None or (isinstance(x, float) and math.isinf(x))
+
+        if self.mass is None or self.mass < 0 or np.isinf(self.mass):
+            raise ValueError("Train mass must be a positive number, not {}!".format(self.mass))
+
+        if self.g is None or not 9 <= self.g <= 10:
+            raise ValueError("Acceleration of gravity must be between 9 and 10 m/s^2, not {}!".format(self.g))
+
+        if self.rho is None or not 1 <= self.rho <= 1.5:
+            raise ValueError("Rotation mass factor must be between 1 and 1.5, not {}!".format(self.rho))
+
+        if self.velocityMax is None or self.velocityMax <= 0 or np.isinf(self.velocityMax):
+            raise ValueError("Maximum velocity must be a strictly positive number, not {}!".format(self.velocityMax))
+
+        if self.forceMax is not None and (self.forceMax <= 0 or np.isinf(self.forceMax)):
+            raise ValueError("Maximum traction force must be strictly positive or free (None), not {}!".format(self.forceMax))
+
+        if self.forceMinPn is not None and (self.forceMinPn > 0 or np.isinf(self.forceMinPn)):
+            raise ValueError("Maximum pneumatic braking force must be negative, zero or free (None), not {}!".format(self.forceMinPn))
+
+        if self.forceMin is not None and (self.forceMin > 0 or np.isinf(self.forceMin)):
+            raise ValueError("Maximum regenerative braking force must be negative, zero or free (None), not {}!".format(self.forceMin))
+
+        if self.forceMin == 0 and self.forceMinPn == 0:
+            raise ValueError("Both brakes cannot be deactivated simultaneously!")
+
+        if self.powerMax is not None and (self.powerMax <= 0 or np.isinf(self.powerMax)):
+            raise ValueError("Maximum traction power must be strictly positive or free (None), not {}!".format(self.powerMax))
+
+        if self.powerMin is not None and (self.powerMin >= 0 or np.isinf(self.powerMin)):
+            raise ValueError("Maximum regenerative brake power must be strictly negative or free (None), not {}!".format(self.powerMin))
+
+        if self.accMax is not None and (self.accMax <= 0 or np.isinf(self.accMax)):
+            raise ValueError("Maximum acceleration must be strictly positive or free (None), not {}!".format(self.accMax))
+
+        if self.accMin is not None and (self.accMin >= 0 or np.isinf(self.accMin)):
+            raise ValueError("Maximum deceleration must be strictly negative or free (None), not {}!".format(self.accMin))
+
+        for name in ('r0', 'r1', 'r2'):
+
+            coef = getattr(self, name)
+
+            if coef is None or coef < 0:
+                raise ValueError("Rolling resistance coefficient {} must be positive, not {}!".format(name, coef))
+
+    def exportModel(self):
+        "Specific (per kg of mass*rho) Davis coefficients + constants needed by the integrator."
+
+        totalMass = self.mass*self.rho
+
+        return TrainModel(self.r0/totalMass, self.r1/totalMass, self.r2/totalMass, self.rho, self.g, self.forceMinPn != 0)
+
+    def lossesCallable(self):
+        "The train's power-loss function L(F [N], v [m/s]) -> [W]: explicit attribute or the two efficiencies."
+
+        if hasattr(self, 'powerLosses'):
+            return self.powerLosses
+
+        if hasattr(self, 'etaTraction') and hasattr(self, 'etaRgBrake'):
+            return StaticLosses(self.etaTraction, self.etaRgBrake)
+
+        raise ValueError("Power losses function of train must by either explicitly or implicitly defined!")
+
+    def powerLossesFuns(self, split=True):
+        "Specific power losses [W/kg] as function(s) of specific force [N/kg] and speed (train.py:190-219)."
+
+        fun = self.lossesCallable()
+        totalMass = self.mass*self.rho
+
+        def specific(f, v):
+            return (1/totalMass)*fun(f*totalMass, v)
+
+        return splitLosses(specific) if split else specific
+
+
+class TrainModel():
+    "Data of the space-domain train ODE (train.py:225-277): dt/ds = 1/sqrt(b), db/ds = 2 a(b,u)."
+
+    def __init__(self, sr0, sr1, sr2, rho=1, g=9.81, withPnBrake=True) -> None:
+
+        self.sr0, self.sr1, self.sr2 = sr0, sr1, sr2
+        self.rho = rho
+        self.g = g
+        self.withPnBrake = withPnBrake
+
+    def resistance(self, gradient=0.0, curvature=0.0):
+        "Velocity-independent specific resistance g*grad/rho + cr/rho (train.py:252-254)."
+
+        c = abs(curvature)
+        cr = self.g*0.5*c/(1 - 30*c) if c <= 1/300 else self.g*0.65*c/(1 - 55*c)
+
+        return self.g*gradient/self.rho + cr/self.rho
+
+    def acceleration(self, velocitySquared, traction=0.0, pnBrake=0.0, gradient=0.0, curvature=0.0):
+        "Instantaneous acceleration [m/s^2] (train.py:251-254, accelerationFun :267)."
+
+        rr = self.sr0 + self.sr1*math.sqrt(velocitySquared) + self.sr2*velocitySquared
+
+        return traction + (pnBrake if self.withPnBrake else 0) - rr - self.resistance(gradient, curvature)
+
+
+class TrainIntegrator():
+    """
+    One shooting interval (reference: train.py:280-364).  Only the explicit RK4
+    branch exists on the device; 'IRK' and 'CVODES' are validated like the
+    reference but not implemented.
+    """
+
+    def __init__(self, model, solver, optsDict={}) -> None:
+
+        if solver not in {'RK', 'IRK', 'CVODES'}:
+            raise ValueError("Unknown integration method!")
+
+        if solver != 'RK':
+            raise NotImplementedError("Only the explicit Runge-Kutta integrator runs on the device.")
+
+        self.model = model
+        self.opts = OptionsRK(optsDict)
+
+    def solve(self, time, velocitySquared, ds, traction=0, pnBrake=0, gradient=0, curvature=0):
+
+        if not self.model.withPnBrake and pnBrake != 0:
+            raise ValueError("Cannot define value for pneumatic braking when this brake is deactivated!")
+
+        from . import _device
+
+        out = _device.stage_eval(self.model, self.opts, [time], [velocitySquared], [ds], [traction + pnBrake],
+                                 [gradient], [curvature])
+
+        return {'time': float(out['time'][0]), 'velSquared': float(out['velSquared'][0])}
+
+
+class OptionsRK(Options):
+
+    def __init__(self, paramsDict):
+
+        self.order = 4  # integration order
+
+        self.numSteps = 1  # number of integration steps inside shooting interval
+
+        self.numApproxSteps = 0  # trapezoidal time update on this many sub-intervals (0: integrate time with RK4)
+
+        super().__init__(paramsDict)
+
+    def checkValues(self):
+
+        if self.order != 4:
+            raise ValueError("Only explicit Runge-Kutta of order 4 is currently implemented in casadi!")
+
+        self.checkPositiveInteger(self.numSteps, 'Number of integration steps', allowZero=False)
+
+        self.checkPositiveInteger(self.numApproxSteps, 'Number of time approximation steps', allowZero=True)
+
+
+class OptionsIRK(Options):
+
+    def __init__(self, paramsDict):
+
+        self.order = 2
+        self.numSteps = 1
+        self.numApproxSteps = 0
+        self.collMethod = 'radau'
+        self.maxIter = 10
+        self.jit = False
+
+        super().__init__(paramsDict)
+
+    def checkValues(self):
+
+        if int(self.order) != self.order or not 1 <= self.order <= 9:
+            raise ValueError("Order of implicit Runge-Kutta should be a positive integer between 1 and 9!")
+
+        self.checkPositiveInteger(self.numSteps, 'Number of integration steps', allowZero=False)
+
+        self.checkPositiveInteger(self.numApproxSteps, 'Number of time approximation steps', allowZero=True)
+
+        if self.collMethod not in {'radau', 'legendre'}:
+            raise ValueError("Unknown collocation method: {}!".format(self.collMethod))
+
+        self.checkPositiveInteger(self.maxIter, 'Maximum number of iterations', allowZero=False)
+
+        if not isinstance(self.jit, bool):
+            raise ValueError("JIT option must be a boolean!")
+
+
+class OptionsCVODES(Options):
+
+    def __init__(self, paramsDict):
+
+        self.absTol = 1e-8
+        self.relTol = 1e-6
+
+        super().__init__(paramsDict)
+
+    def checkValues(self):
+
+        self.checkBounds(self.absTol, 'Absolute tolerance', 1e-20, 1e-1)
+        self.checkBounds(self.relTol, 'Relative tolerance', 1e-20, 1e-1)

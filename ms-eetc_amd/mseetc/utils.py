@@ -1,0 +1,302 @@
+"""
+Host-side helpers of the MI355X train-control solver: option containers, unit
+handling, TTOBench version check, loss-model descriptors and the energy
+accounting that is used as the parity metric.
+
+Mirrors the public surface of the reference's `mseetc/utils.py`
+(`Options` :45-107, `convertUnit` :367-438, `checkTTOBenchVersion` :339-364,
+`splitLosses` :197-220, `postProcessDataFrame` :223-336) without CasADi: loss
+models are plain Python callables on the host and small parameter records on
+the device.
+"""
+
+import math
+import re
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# units (reference: utils.py:367-438).  NOTE the reference quirk: 'km' DIVIDES
+# by 1e3 (utils.py:376-378); shipped data only uses 'm'.  Reproduced as is.
+# --------------------------------------------------------------------------
+
+_UNIT_FACTORS = {
+    'm': 1.0, 'm/s': 1.0, 'permil': 1.0, 'kg': 1.0, 'W': 1.0, 'N': 1.0, 'm/s^2': 1.0, '-': 1.0,
+    'N/(m/s)': 1.0, 'N/(m/s)^2': 1.0, 'kg/m': 1.0,
+    'km': 1.0/1e3,
+    't': 1e3, 'kW': 1e3, 'MW': 1e6, 'kN': 1e3, 'kN/(m/s)': 1e3, 'kN/(m/s)^2': 1e3, 't/m': 1e3,
+}
+
+_IDENTITY_UNITS = {'m', 'm/s', 'permil', 'kg', 'W', 'N', 'm/s^2', '-', 'N/(m/s)', 'N/(m/s)^2', 'kg/m'}
+
+
+def convertUnit(value, unit):
+    "Convert `value` given in `unit` to the internally used SI-style unit."
+
+    if unit in _IDENTITY_UNITS:
+        return value                      # untouched (keeps ints ints, like the reference)
+    if unit == 'km':
+        return value/1e3
+    if unit == 'km/h':
+        return value/3.6
+    if unit == '%':
+        return value/100
+    if unit == 'kN/(km/h)':
+        return value*1e3*3.6
+    if unit == 'N/(km/h)':
+        return value*3.6
+    if unit == 'kN/(km/h)^2':
+        return value*1e3*3.6**2
+    if unit == 'N/(km/h)^2':
+        return value*3.6**2
+    if unit in _UNIT_FACTORS:
+        return value*_UNIT_FACTORS[unit]
+
+    raise ValueError("Unknown unit: {}!".format(unit))
+
+
+def checkTTOBenchVersion(jsonDict, supportedVersions):
+    "Raise unless the json file advertises one of the supported TTOBench versions."
+
+    if not isinstance(supportedVersions, list) or not all(isinstance(x, str) for x in supportedVersions):
+        raise TypeError("'supportedVersions' must be specified a list of strings!")
+
+    meta = jsonDict.get('metadata') if isinstance(jsonDict, dict) else None
+
+    if not isinstance(meta, dict) or 'library version' not in meta:
+        raise ValueError("Library version not found in json file!")
+
+    found = re.search(r'v([\d.]+)', meta['library version'])
+
+    if not found:
+        raise ValueError("Unexpected format of 'library version' in json file!")
+
+    if found.group(1) not in supportedVersions:
+        raise ValueError("Import function works only for library versions {}!".format(','.join(supportedVersions)))
+
+
+# --------------------------------------------------------------------------
+# options (reference: utils.py:45-107)
+# --------------------------------------------------------------------------
+
+class Options():
+    """
+    Attribute-bag options: subclasses set their defaults as attributes and then
+    call `super().__init__(paramsDict)`; unknown keys raise ValueError, nested
+    Options are overwritten recursively, `checkValues` validates.
+    """
+
+    def __init__(self, paramsDict):
+
+        self.overwriteDefaults(paramsDict)
+        self.checkValues()
+
+    def checkValues(self):
+        pass
+
+    def checkPositiveInteger(self, num, fieldName, allowZero=True):
+
+        ok = (int(num) == num) and (num >= 0 if allowZero else num > 0)
+
+        if not ok:
+            raise ValueError("{} must be a {} positive integer!".format(fieldName, 'strictly' if not allowZero else ''))
+
+    def checkBounds(self, num, fieldName, lowerBound, upperBound):
+
+        if not lowerBound <= num <= upperBound:
+            raise ValueError("{} must be between {} and {}!".format(fieldName, lowerBound, upperBound))
+
+    def overwriteDefaults(self, paramsDict):
+
+        for key, val in paramsDict.items():
+
+            if not hasattr(self, key):
+                raise ValueError("Specified option ({}) does not exist!".format(key))
+
+            cur = getattr(self, key)
+
+            if isinstance(cur, Options):
+
+                if not isinstance(val, dict):
+                    raise ValueError("Nested options must be specified as a dictionary!")
+
+                cur.overwriteDefaults(val)
+
+            else:
+                setattr(self, key, val)
+
+    def toDict(self):
+
+        out = {}
+
+        for name, val in vars(self).items():
+
+            if name.startswith('__') or name == 'ignoreFields' or callable(val):
+                continue
+
+            out[name] = val.toDict() if isinstance(val, Options) else val
+
+        return out
+
+
+# --------------------------------------------------------------------------
+# loss models
+# --------------------------------------------------------------------------
+
+LOSS_NONE = 0     # perfect efficiency, L(f,v) = 0
+LOSS_STATIC = 1   # constant efficiencies: L = f v (1-eta_t)/eta_t (f>0), -(1-eta_r) f v (f<0)
+
+
+class StaticLosses():
+    """
+    Power losses [W] of a drive with constant traction / regenerative-brake
+    efficiencies (reference: train.py:199-212).  Callable like the reference's
+    lambda `powerLosses(F [N], v [m/s])`.
+    """
+
+    def __init__(self, etaTraction, etaRgBrake):
+        self.etaTraction = float(etaTraction)
+        self.etaRgBrake = float(etaRgBrake)
+
+    def __call__(self, f, v):
+        return f*v*(f > 0)*(1 - self.etaTraction)/self.etaTraction - (1 - self.etaRgBrake)*f*v*(f < 0)
+
+    def slopes(self):
+        "(ct, cr): slack rows s >= ct*f and s >= -cr*f of the static model (v cancels)."
+        return (1 - self.etaTraction)/self.etaTraction, (1 - self.etaRgBrake)
+
+
+def classifyLosses(fun):
+    """
+    Work out which device loss model a user-supplied callable `fun(F, v)`
+    corresponds to.  The reference accepts arbitrary CasADi-traceable lambdas
+    (`train.powerLosses = lambda f,v: ...`, e.g. figure5.py:92-93); the device
+    path has closed-form models only, so the callable is probed on a grid and
+    matched.  Returns (kind, ct, cr).
+    """
+
+    if isinstance(fun, StaticLosses):
+        ct, cr = fun.slopes()
+        return LOSS_STATIC, ct, cr
+
+    fs = np.array([-3e5, -1.1e5, -2.5e4, -1.0, 1.0, 3.3e4, 1.2e5, 2.9e5])
+    vs = np.array([0.7, 3.0, 11.0, 27.0, 44.0])
+
+    vals = np.array([[float(fun(float(f), float(v))) for v in vs] for f in fs])
+
+    if np.all(vals == 0):
+        return LOSS_NONE, 0.0, 0.0
+
+    # static-efficiency shape: L = ct f v for f > 0 and -cr f v for f < 0
+    pw = fs[:, None]*vs[None, :]
+    ct = vals[-1, -1]/pw[-1, -1]
+    cr = -vals[0, -1]/pw[0, -1]
+    model = np.where(pw > 0, ct*pw, -cr*pw)
+
+    if ct >= 0 and cr >= 0 and np.allclose(vals, model, rtol=1e-12, atol=1e-9):
+        return LOSS_STATIC, float(ct), float(cr)
+
+    raise NotImplementedError("The power-losses callable is neither zero, nor a constant-efficiency model: "
+                              "only closed-form loss models can run on the device.")
+
+
+def splitLosses(fun):
+    """
+    Split a loss function into a traction and a regenerative-brake part, each
+    extended linearly through f = 0 (reference: utils.py:197-220).  The slope is
+    taken by a central difference of width 1e-10 around +-1e-10 like the
+    reference's symbolic derivative evaluated there.
+    """
+
+    tol = 1e-10
+
+    def slope(f0, v):
+        h = 0.5e-10
+        return (fun(f0 + h, v) - fun(f0 - h, v))/(2*h)
+
+    def funTr(f, v):
+        return fun(f, v) if f >= 0 else slope(tol, v)*f + fun(0, v)
+
+    def funRgb(f, v):
+        return fun(f, v) if f < 0 else slope(-tol, v)*f + fun(0, v)
+
+    return funTr, funRgb
+
+
+# --------------------------------------------------------------------------
+# energy accounting (reference: utils.py:223-259, 291-294, 330)
+# --------------------------------------------------------------------------
+
+def curvatureResistance(curv, g, rho):
+    "Specific curvature resistance [m/s^2] (reference: train.py:252-253 as written, divided by rho as in :254)."
+
+    c = abs(curv)
+
+    return (g*0.5*c/(1 - 30*c) if c <= 1/300 else g*0.65*c/(1 - 55*c))/rho
+
+
+def postProcessDataFrame(dfIn, points, train, CVODES=False, integrateLosses=False, integrateRollingResistance=False):
+    """
+    Adds the force / power / energy columns the reference computes after a solve
+    (utils.py:230-259,291-294,330).  Differences, by scope:
+    the CVODES re-simulation columns and the `integrateLosses` /
+    `integrateRollingResistance` branches need an adaptive ODE integrator and are
+    not part of the hot path; requesting them raises NotImplementedError.
+    """
+
+    if integrateLosses or integrateRollingResistance:
+        raise NotImplementedError("Integrated losses / rolling resistance are outside the device hot path.")
+
+    if CVODES:
+        raise NotImplementedError("CVODES re-simulation is outside the device hot path.")
+
+    unitScaling = 1e-6/3.6  # Nm -> kWh
+    totalMass = train.mass*train.rho
+
+    df = dfIn.copy()
+
+    df['Speed limit [m/s]'] = points['Speed limit [m/s]'].values
+    df['Gradient [permil]'] = points['Gradient [permil]'].values
+    df['Curvature [1/m]'] = points['Curvature [1/m]'].values
+
+    fel = df['Force (el) [N]'].values.astype(float)
+    fpb = df['Force (pnb) [N]'].values.astype(float)
+    vel = df['Velocity [m/s]'].values.astype(float)
+    pos = df['Position [m]'].values.astype(float)
+
+    with np.errstate(invalid='ignore'):
+        facc = fel*(fel >= 0)
+        frgb = fel*(fel < 0)
+
+    df['Force (acc) [N]'] = facc
+    df['Force (rgb) [N]'] = frgb
+    df['Force [N]'] = facc + frgb + fpb
+
+    velNext = np.append(vel[1:], np.nan)
+    ds = np.append(np.diff(pos), np.nan)
+
+    df['Max. Power [kW]'] = np.maximum(facc*vel/1e3, facc*velNext/1e3)
+    df['Min. Power [kW]'] = np.minimum(frgb*vel/1e3, frgb*velNext/1e3)
+
+    losses = train.powerLossesFuns(split=False)   # specific: f [N/kg] -> [W/kg]
+    vm = 0.5*(vel + velNext)
+
+    lossE = np.full(len(df), np.nan)
+
+    for k in range(len(df) - 1):
+        lossE[k] = unitScaling*ds[k]*totalMass*losses(fel[k]/totalMass, vm[k])/vm[k]
+
+    df['Losses [kWh]'] = lossE
+    df['Energy [kWh]'] = unitScaling*ds*facc + unitScaling*ds*frgb + lossE
+    df['Energy (pnb) [kWh]'] = -unitScaling*ds*fpb
+    df['Energy (kin) [kWh]'] = unitScaling*0.5*train.mass*vel**2   # train.mass, not mass*rho (utils.py:294)
+
+    grad = df['Gradient [permil]'].values/1000
+    curv = df['Curvature [1/m]'].values
+
+    rr = (train.r0 + train.r1*vel + train.r2*vel**2)/totalMass
+    cr = np.array([curvatureResistance(c, train.g, train.rho) for c in curv])
+
+    df['Acceleration [m/s^2]'] = df['Force [N]'].values/totalMass - rr - train.g*grad/train.rho - cr
+
+    return df
