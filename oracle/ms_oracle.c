@@ -1,0 +1,1260 @@
+/*
+ * ms_oracle.c -- CPU ORACLE (test infrastructure, not product code; see ms_oracle.h).
+ *
+ * Serial, double precision, written for clarity: every interval is assembled as a dense
+ * 8x8 local system and the stage recursion uses plain dense 3x3 / 6x6 loops.  The HIP
+ * product (ms-eetc_amd/csrc) is a separate implementation with a different decomposition
+ * (one thread per stage, sparsity-exploiting Riccati); the two only share the mathematics.
+ *
+ * Reference citations are relative to the reference repository root.
+ */
+#include "ms_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * second-order forward-mode "jets" in two inputs (b, w): value, gradient, Hessian (00,01,11).
+ * The reference gets these derivatives from CasADi's AD of the same expressions.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double v, g0, g1, h00, h01, h11; } jet;
+
+static jet j_const(double c) { jet r = {c, 0, 0, 0, 0, 0}; return r; }
+static jet j_var(double v, int k) { jet r = {v, k == 0, k == 1, 0, 0, 0}; return r; }
+static jet j_add(jet a, jet b) { jet r = {a.v + b.v, a.g0 + b.g0, a.g1 + b.g1, a.h00 + b.h00, a.h01 + b.h01, a.h11 + b.h11}; return r; }
+static jet j_sub(jet a, jet b) { jet r = {a.v - b.v, a.g0 - b.g0, a.g1 - b.g1, a.h00 - b.h00, a.h01 - b.h01, a.h11 - b.h11}; return r; }
+static jet j_scale(jet a, double s) { jet r = {a.v*s, a.g0*s, a.g1*s, a.h00*s, a.h01*s, a.h11*s}; return r; }
+static jet j_axpy(double s, jet a, jet y) { return j_add(j_scale(a, s), y); }
+/* outer function F(a) with F' = f1, F'' = f2 */
+static jet j_chain(jet a, double F, double f1, double f2)
+{
+    jet r;
+    r.v = F;
+    r.g0 = f1*a.g0;
+    r.g1 = f1*a.g1;
+    r.h00 = f1*a.h00 + f2*a.g0*a.g0;
+    r.h01 = f1*a.h01 + f2*a.g0*a.g1;
+    r.h11 = f1*a.h11 + f2*a.g1*a.g1;
+    return r;
+}
+static jet j_sqrt(jet a) { double s = sqrt(a.v); return j_chain(a, s, 0.5/s, -0.25/(a.v*s)); }
+static jet j_recip(jet a) { double r = 1.0/a.v; return j_chain(a, r, -r*r, 2*r*r*r); }
+
+/* ------------------------------------------------------------------------------------------
+ * problem data
+ * ---------------------------------------------------------------------------------------- */
+enum { VT = 0, VB = 1, VF = 2, VP = 3, VS = 4, NV = 5 };          /* variables of a stage          */
+enum { RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5 }; /* inequality rows of an interval */
+/* local ordering of an interval: t_i b_i q_i f_i p_i s_i | t_{i+1} b_{i+1};  q_i := f_{i-1} */
+enum { LT = 0, LB = 1, LQ = 2, LF = 3, LP = 4, LS = 5, LT1 = 6, LB1 = 7, NL = 8 };
+static const int var2loc[NV] = {LT, LB, LF, LP, LS};
+
+typedef struct {
+    int N, withPn, hasPower, energyOpt, numSteps, numApprox, lossKind, maxIter;
+    const double *ds, *grad, *curv, *bmax;
+    double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
+    double t0, tEnd, v0sq, vNsq;
+} Prob;
+
+static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds, const double *grad, const double *curv, const double *bmax)
+{
+    P->N = ip[OR_IP_N]; P->withPn = ip[OR_IP_WITH_PN]; P->hasPower = ip[OR_IP_HAS_POWER]; P->energyOpt = ip[OR_IP_ENERGY_OPT];
+    P->numSteps = ip[OR_IP_NUM_STEPS]; P->numApprox = ip[OR_IP_NUM_APPROX]; P->lossKind = ip[OR_IP_LOSS_KIND]; P->maxIter = ip[OR_IP_MAX_ITER];
+    P->ds = ds; P->grad = grad; P->curv = curv; P->bmax = bmax;
+    P->sr0 = dp[OR_DP_SR0]; P->sr1 = dp[OR_DP_SR1]; P->sr2 = dp[OR_DP_SR2]; P->g = dp[OR_DP_G]; P->rho = dp[OR_DP_RHO];
+    P->fmax = dp[OR_DP_FMAX]; P->fmin = dp[OR_DP_FMIN]; P->fminPn = dp[OR_DP_FMIN_PN];
+    P->pwU = dp[OR_DP_PW_UPPER]; P->pwL = dp[OR_DP_PW_LOWER]; P->accMin = dp[OR_DP_ACC_MIN]; P->accMax = dp[OR_DP_ACC_MAX];
+    P->ct = dp[OR_DP_LOSS_CT]; P->cr = dp[OR_DP_LOSS_CR]; P->vminSq = dp[OR_DP_VMIN_SQ]; P->objDen = dp[OR_DP_OBJ_DEN]; P->tol = dp[OR_DP_TOL];
+    P->t0 = dp[OR_DP_T0]; P->tEnd = dp[OR_DP_TEND]; P->v0sq = dp[OR_DP_V0SQ]; P->vNsq = dp[OR_DP_VNSQ];
+}
+
+/* velocity-independent specific resistance of interval i: g*grad/rho + cr(curv)/rho (train.py:252-254) */
+static double track_resistance(const Prob *P, double grad, double curv)
+{
+    double c = fabs(curv);
+    double cr = (c <= 1.0/300.0) ? P->g*0.5*c/(1 - 30*c) : P->g*0.65*c/(1 - 55*c);
+    return P->g*grad*(1/P->rho) + cr*(1/P->rho);
+}
+
+/* d(b)/d(sigma) on the unit interval: 2*ds*(w - rr(b) - G)  (train.py:251,254,256,259) */
+static jet ode_b(const Prob *P, jet b, jet w, double G, double ds)
+{
+    jet rr = j_add(j_const(P->sr0), j_add(j_scale(j_sqrt(b), P->sr1), j_scale(b, P->sr2)));
+    jet acc = j_sub(j_sub(w, rr), j_const(G));
+    return j_scale(acc, 2*ds);
+}
+
+/* casadi.simpleRK(f, numSteps, 4) applied to the b-equation only, total step H (train.py:298-301) */
+static jet rk4_b(const Prob *P, jet b, jet w, double G, double ds, double H)
+{
+    double h = H/P->numSteps;
+    for (int s = 0; s < P->numSteps; s++) {
+        jet k1 = ode_b(P, b, w, G, ds);
+        jet k2 = ode_b(P, j_axpy(0.5*h, k1, b), w, G, ds);
+        jet k3 = ode_b(P, j_axpy(0.5*h, k2, b), w, G, ds);
+        jet k4 = ode_b(P, j_axpy(h, k3, b), w, G, ds);
+        jet sum = j_add(j_add(k1, j_scale(k2, 2)), j_add(j_scale(k3, 2), k4));
+        b = j_axpy(h/6, sum, b);
+    }
+    return b;
+}
+
+/*
+ * One shooting interval: tau = t+ - t and b+ as jets in (b, w), w = Fel + Fpb.
+ * numApprox == 0: RK4 on (t, b) jointly (train.py:296-301, dt/ds = ds/sqrt(b) :255,258).
+ * numApprox  > 0: RK4 on b, evaluated from b0 at h = j/ns, trapezoidal time (train.py:324-344).
+ */
+static void interval_map(const Prob *P, double b0, double w0, double G, double ds, jet *tau, jet *bplus)
+{
+    jet b = j_var(b0, 0), w = j_var(w0, 1);
+
+    if (P->numApprox == 0) {
+        double h = 1.0/P->numSteps;
+        jet t = j_const(0);
+        for (int s = 0; s < P->numSteps; s++) {
+            jet k1b = ode_b(P, b, w, G, ds);
+            jet k1t = j_scale(j_recip(j_sqrt(b)), ds);
+            jet b2 = j_axpy(0.5*h, k1b, b);
+            jet k2b = ode_b(P, b2, w, G, ds);
+            jet k2t = j_scale(j_recip(j_sqrt(b2)), ds);
+            jet b3 = j_axpy(0.5*h, k2b, b);
+            jet k3b = ode_b(P, b3, w, G, ds);
+            jet k3t = j_scale(j_recip(j_sqrt(b3)), ds);
+            jet b4 = j_axpy(h, k3b, b);
+            jet k4b = ode_b(P, b4, w, G, ds);
+            jet k4t = j_scale(j_recip(j_sqrt(b4)), ds);
+            b = j_axpy(h/6, j_add(j_add(k1b, j_scale(k2b, 2)), j_add(j_scale(k3b, 2), k4b)), b);
+            t = j_axpy(h/6, j_add(j_add(k1t, j_scale(k2t, 2)), j_add(j_scale(k3t, 2), k4t)), t);
+        }
+        *tau = t; *bplus = b;
+        return;
+    }
+
+    int ns = P->numApprox;
+    jet prev = b, acc = j_const(0);
+    for (int j = 1; j <= ns; j++) {
+        jet cur = rk4_b(P, b, w, G, ds, (double)j/ns);
+        /* 2*ds*(e_{j} - e_{j-1})/(v_{j-1} + v_j) */
+        jet den = j_add(j_sqrt(prev), j_sqrt(cur));
+        acc = j_add(acc, j_scale(j_recip(den), 2*ds*((double)j/ns - (double)(j - 1)/ns)));
+        prev = cur;
+    }
+    *tau = acc; *bplus = prev;
+}
+
+void oracle_stage_eval(const int *ip, const double *dp, double b, double w, double ds, double grad, double curv, double *out)
+{
+    Prob P; prob_init(&P, ip, dp, NULL, NULL, NULL, NULL);
+    jet tau, bp;
+    interval_map(&P, b, w, track_resistance(&P, grad, curv), ds, &tau, &bp);
+    out[0] = tau.v; out[1] = bp.v; out[2] = tau.g0; out[3] = tau.g1; out[4] = bp.g0; out[5] = bp.g1;
+    out[6] = tau.h00; out[7] = tau.h01; out[8] = tau.h11; out[9] = bp.h00; out[10] = bp.h01; out[11] = bp.h11;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NLP functions in the reference's layout (ocp.py:166-284)
+ * ---------------------------------------------------------------------------------------- */
+static int rows_per_interval(const Prob *P) { return (P->hasPower ? 2 : 0) + 1 + 2 + (P->energyOpt ? 2 : 0); }
+
+void oracle_nlp_eval(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                     const double *z, double *obj, double *gout)
+{
+    Prob P; prob_init(&P, ip, dp, ds, grad, curv, NULL);
+    int N = P.N, stp = 4 + P.withPn, rpi = rows_per_interval(&P);
+    double J = 0;
+
+    for (int i = 0; i < N; i++) {
+        const double *zi = z + stp*i;
+        double f = zi[0], p = P.withPn ? zi[1] : 0, s = zi[1 + P.withPn], t = zi[2 + P.withPn], b = zi[3 + P.withPn];
+        double t1 = (i + 1 < N) ? z[stp*(i + 1) + 2 + P.withPn] : z[stp*N];
+        double b1 = (i + 1 < N) ? z[stp*(i + 1) + 3 + P.withPn] : z[stp*N + 1];
+        double G = track_resistance(&P, grad[i], curv[i]);
+        jet tau, bp;
+        interval_map(&P, b, f + p, G, ds[i], &tau, &bp);
+        double *g = gout ? gout + rpi*i : NULL;
+        int r = 0;
+        if (g) {
+            if (P.hasPower) { g[r++] = f*sqrt(b); g[r++] = f*sqrt(b1); }
+            g[r++] = f + p - (P.sr0 + P.sr1*sqrt(b) + P.sr2*b) - G;
+            g[r++] = t1 - (t + tau.v);
+            g[r++] = b1 - bp.v;
+            if (P.energyOpt) { g[r++] = s - P.ct*f; g[r++] = s + P.cr*f; }
+        }
+        if (P.energyOpt) {
+            J += ds[i]*(f + s);
+            if (i > 0) { double fp = z[stp*(i - 1)]; J += 1e-3*(f - fp)*(f - fp); }
+        } else {
+            J += 1e-4*(f*f + p*p);
+        }
+    }
+    if (!P.energyOpt) J += z[stp*N];
+    *obj = J/P.objDen;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * interior-point workspace
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double x[NV];        /* t b f p s  (f p s unused at the terminal stage) */
+    double sig[NR];      /* slacks of the inequality rows of interval i */
+    double lam[2];       /* dynamics multipliers (t, b) of interval i */
+    double nu[NR];       /* multipliers of d(x) - sigma = 0 */
+    double zL[NV], zU[NV], zLs[NR], zUs[NR];
+} StageIt;
+
+typedef struct {
+    double lb[NV], ub[NV];
+    int on[NV], hasL[NV], hasU[NV];   /* on: free variable of the NLP (exists and not fixed) */
+} StageBd;
+
+typedef struct {
+    /* function values */
+    double tau, bplus, c[2], d[NR];
+    double tg[2], bg[2], th[3], bh[3];     /* derivatives of tau, bplus wrt (b, w) */
+    /* row derivatives in local ordering */
+    double gr[NR][NL], hr[NR][NL][NL];
+    double objg[NL], objh[NL][NL];
+} StageEv;
+
+typedef struct {
+    double H[6][6], h[6], E[6][3];         /* condensed stage system, cross term y_i^T E x_{i+1} */
+    double F[3][6], r[3];
+    double K[3][3], k[3], Pn[3][3], pn[3]; /* feedback, and the (P,p) of stage i+1 used at i */
+    double ef[6], e0;                       /* terminal elimination: df = ef . y~ + e0 (last interval only) */
+    double Ghat[6][6], ghat[6];             /* G, g before elimination (for multiplier recovery) */
+} StageKkt;
+
+typedef struct {
+    double dx[NV], dsig[NR], dlam[2], dnu[NR], dzL[NV], dzU[NV], dzLs[NR], dzUs[NR];
+} StageDir;
+
+typedef struct {
+    Prob P;
+    int N, rowOn[NR];
+    double dL[NR], dU[NR]; int rhasL[NR], rhasU[NR];
+    double rs[NR];          /* inequality row scaling (gradient based) */
+    double sf;              /* objective scaling */
+    double *sct, *scb;      /* dynamics row scaling (enters norms only) */
+    double *G;              /* track resistance per interval */
+    StageIt *it, *trial;
+    StageBd *bd;
+    StageEv *ev;
+    StageKkt *kk;
+    StageDir *dir, *soc;
+    double HN[3][3], hN[3]; /* terminal stage */
+    double mu, tau;
+    /* filter */
+    double filt_theta[512], filt_phi[512]; int nfilt;
+    double theta_max, theta_min;
+    /* inertia correction memory */
+    double delta_last;
+    /* stats */
+    int n_reg, n_soc, n_back;
+} Ws;
+
+/* IPOPT default option values (Waechter & Biegler 2006, section 3 + IPOPT 3.14 defaults) */
+static const double K_BOUND_RELAX = 1e-8;
+static const double K_PUSH = 1e-2, K_FRAC = 1e-2;          /* bound_push, bound_frac (kappa_1, kappa_2) */
+static const double K_MU_INIT = 0.1, K_EPS = 10.0;          /* mu_init, barrier_tol_factor (kappa_eps) */
+static const double K_MU_LIN = 0.2, K_MU_SUP = 1.5;         /* kappa_mu, theta_mu */
+static const double K_TAU_MIN = 0.99;
+static const double K_SMAX = 100.0;
+static const double K_SIGMA = 1e10;                         /* kappa_Sigma */
+static const double K_D = 1e-5;                             /* kappa_d */
+static const double G_THETA = 1e-5, G_PHI = 1e-8;           /* gamma_theta, gamma_phi */
+static const double K_DELTA = 1.0, S_THETA = 1.1, S_PHI = 2.3, ETA_PHI = 1e-8;
+static const double K_SOC = 0.99; static const int P_MAX_SOC = 4;
+static const double ALPHA_MIN_FRAC = 0.05;
+static const double DW_MIN = 1e-20, DW_0 = 1e-4, DW_MAX = 1e40, KW_MINUS = 1.0/3.0, KW_PLUS = 8.0, KW_PLUS_BAR = 100.0;
+static const double LAM_INIT_MAX = 1e3;
+static const double ACC_TOL = 1e-6; static const int ACC_ITER = 15;
+
+static int var_exists(const Ws *W, int i, int k)
+{
+    if (k == VT || k == VB) return 1;
+    if (i >= W->N) return 0;
+    if (k == VP) return W->P.withPn;
+    return 1;
+}
+
+static void setup_bounds(Ws *W)
+{
+    const Prob *P = &W->P; int N = W->N;
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i];
+        for (int k = 0; k < NV; k++) { B->lb[k] = -INFINITY; B->ub[k] = INFINITY; B->on[k] = var_exists(W, i, k); }
+        /* ocp.py:175-181 controls and slack */
+        B->lb[VF] = P->fmin; B->ub[VF] = P->fmax;
+        B->lb[VP] = P->fminPn; B->ub[VP] = 0;
+        B->lb[VS] = 0; B->ub[VS] = INFINITY;
+        /* ocp.py:247-272 states */
+        if (i == 0) { B->lb[VT] = B->ub[VT] = P->t0; B->lb[VB] = B->ub[VB] = P->v0sq; }
+        else if (i == N) { B->lb[VT] = P->t0; B->ub[VT] = P->tEnd; B->lb[VB] = B->ub[VB] = P->vNsq; }
+        else { B->lb[VT] = P->t0; B->ub[VT] = P->tEnd; B->lb[VB] = P->vminSq; B->ub[VB] = P->bmax[i]; }
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            if (B->lb[k] == B->ub[k]) { B->on[k] = 0; continue; }   /* fixed_variable_treatment = make_parameter */
+            B->hasL[k] = isfinite(B->lb[k]); B->hasU[k] = isfinite(B->ub[k]);
+            if (B->hasL[k]) B->lb[k] -= K_BOUND_RELAX*fmax(1.0, fabs(B->lb[k]));
+            if (B->hasU[k]) B->ub[k] += K_BOUND_RELAX*fmax(1.0, fabs(B->ub[k]));
+        }
+    }
+    /* rows (ocp.py:184-201, 225-229) */
+    for (int r = 0; r < NR; r++) { W->rowOn[r] = 0; W->dL[r] = -INFINITY; W->dU[r] = INFINITY; W->rs[r] = 1; }
+    if (P->hasPower) {
+        W->rowOn[RPW0] = W->rowOn[RPW1] = 1;
+        W->dL[RPW0] = W->dL[RPW1] = -fabs(P->pwL); W->dU[RPW0] = W->dU[RPW1] = fabs(P->pwU);
+    }
+    W->rowOn[RACC] = 1; W->dL[RACC] = P->accMin; W->dU[RACC] = P->accMax;
+    if (P->energyOpt) { W->rowOn[RLTR] = W->rowOn[RLRG] = 1; W->dL[RLTR] = W->dL[RLRG] = 0; }
+}
+
+static void relax_row_bounds(Ws *W)
+{
+    for (int r = 0; r < NR; r++) {
+        if (!W->rowOn[r]) continue;
+        W->dL[r] *= W->rs[r]; W->dU[r] *= W->rs[r];
+        W->rhasL[r] = isfinite(W->dL[r]); W->rhasU[r] = isfinite(W->dU[r]);
+        if (W->rhasL[r]) W->dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(W->dL[r]));
+        if (W->rhasU[r]) W->dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(W->dU[r]));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * function evaluation at an iterate; order 0: values only, 2: with derivatives
+ * ---------------------------------------------------------------------------------------- */
+static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int order)
+{
+    const Prob *P = &W->P;
+    const double *x = it[i].x, *x1 = it[i + 1].x;
+    double b = x[VB], f = x[VF], p = P->withPn ? x[VP] : 0.0, s = x[VS];
+    jet tau, bp;
+    interval_map(P, b, f + p, W->G[i], P->ds[i], &tau, &bp);
+    e->tau = tau.v; e->bplus = bp.v;
+    e->c[0] = x1[VT] - (x[VT] + tau.v);
+    e->c[1] = x1[VB] - bp.v;
+    double sb = sqrt(b), sb1 = sqrt(x1[VB]);
+    e->d[RPW0] = W->rs[RPW0]*f*sb;
+    e->d[RPW1] = W->rs[RPW1]*f*sb1;
+    e->d[RACC] = W->rs[RACC]*(f + p - (P->sr0 + P->sr1*sb + P->sr2*b) - W->G[i]);
+    e->d[RLTR] = W->rs[RLTR]*(s - P->ct*f);
+    e->d[RLRG] = W->rs[RLRG]*(s + P->cr*f);
+    if (order == 0) return;
+
+    e->tg[0] = tau.g0; e->tg[1] = tau.g1; e->th[0] = tau.h00; e->th[1] = tau.h01; e->th[2] = tau.h11;
+    e->bg[0] = bp.g0; e->bg[1] = bp.g1; e->bh[0] = bp.h00; e->bh[1] = bp.h01; e->bh[2] = bp.h11;
+
+    memset(e->gr, 0, sizeof e->gr); memset(e->hr, 0, sizeof e->hr);
+    memset(e->objg, 0, sizeof e->objg); memset(e->objh, 0, sizeof e->objh);
+
+    /* Fel*sqrt(b_i), Fel*sqrt(b_{i+1}) (ocp.py:189) */
+    e->gr[RPW0][LF] = sb; e->gr[RPW0][LB] = 0.5*f/sb;
+    e->hr[RPW0][LF][LB] = e->hr[RPW0][LB][LF] = 0.5/sb; e->hr[RPW0][LB][LB] = -0.25*f/(b*sb);
+    e->gr[RPW1][LF] = sb1; e->gr[RPW1][LB1] = 0.5*f/sb1;
+    e->hr[RPW1][LF][LB1] = e->hr[RPW1][LB1][LF] = 0.5/sb1; e->hr[RPW1][LB1][LB1] = -0.25*f/(x1[VB]*sb1);
+    /* acceleration at the interval start (ocp.py:199, train.py:251-254) */
+    e->gr[RACC][LF] = 1; e->gr[RACC][LP] = P->withPn ? 1 : 0; e->gr[RACC][LB] = -(0.5*P->sr1/sb + P->sr2);
+    e->hr[RACC][LB][LB] = 0.25*P->sr1/(b*sb);
+    /* static loss rows (ocp.py:225-226 with train.py:203 / utils.py:197-220) */
+    e->gr[RLTR][LS] = 1; e->gr[RLTR][LF] = -P->ct;
+    e->gr[RLRG][LS] = 1; e->gr[RLRG][LF] = P->cr;
+    for (int r = 0; r < NR; r++)
+        if (W->rs[r] != 1.0)
+            for (int a = 0; a < NL; a++) { e->gr[r][a] *= W->rs[r]; for (int c = 0; c < NL; c++) e->hr[r][a][c] *= W->rs[r]; }
+
+    /* objective of the interval (ocp.py:146-150, 223, 245, 276-284) */
+    double sc = W->sf/P->objDen;
+    if (P->energyOpt) {
+        e->objg[LF] = sc*P->ds[i]; e->objg[LS] = sc*P->ds[i];
+        if (i > 0) {
+            double q = it[i - 1].x[VF];
+            e->objg[LF] += sc*2e-3*(f - q); e->objg[LQ] = -sc*2e-3*(f - q);
+            e->objh[LF][LF] = sc*2e-3; e->objh[LQ][LQ] = sc*2e-3; e->objh[LF][LQ] = e->objh[LQ][LF] = -sc*2e-3;
+        }
+    } else {
+        e->objg[LF] = sc*2e-4*f; e->objh[LF][LF] = sc*2e-4;
+        if (P->withPn) { e->objg[LP] = sc*2e-4*p; e->objh[LP][LP] = sc*2e-4; }
+        if (i == W->N - 1) e->objg[LT1] = sc;
+    }
+}
+
+static double objective_value(const Ws *W, const StageIt *it)
+{
+    const Prob *P = &W->P; double J = 0;
+    for (int i = 0; i < W->N; i++) {
+        double f = it[i].x[VF], p = P->withPn ? it[i].x[VP] : 0.0, s = it[i].x[VS];
+        if (P->energyOpt) {
+            J += P->ds[i]*(f + s);
+            if (i > 0) { double q = it[i - 1].x[VF]; J += 1e-3*(f - q)*(f - q); }
+        } else J += 1e-4*(f*f + p*p);
+    }
+    if (!P->energyOpt) J += it[W->N].x[VT];
+    return W->sf*J/P->objDen;
+}
+
+/* barrier function value and constraint violation (1-norm of the scaled rows) at an iterate */
+static void merit_terms(const Ws *W, const StageIt *it, double mu, double *theta, double *phi, int *ok)
+{
+    int N = W->N; double th = 0, bar = 0; *ok = 1;
+    StageEv e;
+    for (int i = 0; i < N; i++) {
+        eval_interval(W, it, i, &e, 0);
+        th += W->sct[i]*fabs(e.c[0]) + W->scb[i]*fabs(e.c[1]);
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double sg = it[i].sig[r];
+            th += fabs(e.d[r] - sg);
+            if (W->rhasL[r]) { double s = sg - W->dL[r]; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (W->rhasU[r]) { double s = W->dU[r] - sg; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (W->rhasL[r] && !W->rhasU[r]) bar += K_D*mu*(sg - W->dL[r]);
+            if (!W->rhasL[r] && W->rhasU[r]) bar += K_D*mu*(W->dU[r] - sg);
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        const StageBd *B = &W->bd[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double x = it[i].x[k];
+            if (B->hasL[k]) { double s = x - B->lb[k]; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (B->hasU[k]) { double s = B->ub[k] - x; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (B->hasL[k] && !B->hasU[k]) bar += K_D*mu*(x - B->lb[k]);
+            if (!B->hasL[k] && B->hasU[k]) bar += K_D*mu*(B->ub[k] - x);
+        }
+    }
+    if (!isfinite(th) || !isfinite(bar)) *ok = 0;
+    *theta = th; *phi = objective_value(W, it) + bar;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * optimality error E_mu (W&B eq. (5)) of the scaled problem + unscaled infeasibilities
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double dual, primal, compl_, sd, sc, E, dual_u, primal_u, compl_u; } Err;
+
+static void kkt_error(Ws *W, double mu, Err *R)
+{
+    int N = W->N; const Prob *P = &W->P;
+    double dual = 0, prim = 0, comp = 0, prim_u = 0, comp0 = 0;
+    double sumlam = 0, sumz = 0; int nlam = 0, nz = 0;
+    /* gradient of the Lagrangian, accumulated per stage variable */
+    double (*gl)[NV] = calloc(N + 1, sizeof *gl);
+    for (int i = 0; i < N; i++) {
+        StageEv *e = &W->ev[i]; StageIt *I = &W->it[i];
+        double loc[NL];
+        for (int a = 0; a < NL; a++) loc[a] = e->objg[a];
+        for (int r = 0; r < NR; r++) if (W->rowOn[r]) for (int a = 0; a < NL; a++) loc[a] += I->nu[r]*e->gr[r][a];
+        /* dynamics: c_t = t1 - t - tau, c_b = b1 - bplus */
+        loc[LT1] += I->lam[0]; loc[LT] -= I->lam[0];
+        loc[LB] -= I->lam[0]*e->tg[0]; loc[LF] -= I->lam[0]*e->tg[1]; loc[LP] -= P->withPn ? I->lam[0]*e->tg[1] : 0;
+        loc[LB1] += I->lam[1];
+        loc[LB] -= I->lam[1]*e->bg[0]; loc[LF] -= I->lam[1]*e->bg[1]; loc[LP] -= P->withPn ? I->lam[1]*e->bg[1] : 0;
+        gl[i][VT] += loc[LT]; gl[i][VB] += loc[LB]; gl[i][VF] += loc[LF]; gl[i][VP] += loc[LP]; gl[i][VS] += loc[LS];
+        if (i > 0) gl[i - 1][VF] += loc[LQ];
+        gl[i + 1][VT] += loc[LT1]; gl[i + 1][VB] += loc[LB1];
+        prim = fmax(prim, fmax(W->sct[i]*fabs(e->c[0]), W->scb[i]*fabs(e->c[1])));
+        prim_u = fmax(prim_u, fmax(fabs(e->c[0]), fabs(e->c[1])));
+        sumlam += fabs(I->lam[0])/W->sct[i] + fabs(I->lam[1])/W->scb[i]; nlam += 2;
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double sg = I->sig[r];
+            prim = fmax(prim, fabs(e->d[r] - sg));
+            prim_u = fmax(prim_u, fabs(e->d[r] - sg)/W->rs[r]);
+            /* violation of the original row bounds by d(x) is covered by d - sigma and the slack bounds */
+            sumlam += fabs(I->nu[r]); nlam++;
+            /* stationarity wrt the slack: -nu - zL + zU */
+            double gs = -I->nu[r];
+            if (W->rhasL[r]) { gs -= I->zLs[r]; double c = (sg - W->dL[r])*I->zLs[r]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zLs[r]; nz++; }
+            if (W->rhasU[r]) { gs += I->zUs[r]; double c = (W->dU[r] - sg)*I->zUs[r]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zUs[r]; nz++; }
+            dual = fmax(dual, fabs(gs));
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double g = gl[i][k];
+            if (B->hasL[k]) { g -= I->zL[k]; double c = (I->x[k] - B->lb[k])*I->zL[k]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zL[k]; nz++; }
+            if (B->hasU[k]) { g += I->zU[k]; double c = (B->ub[k] - I->x[k])*I->zU[k]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zU[k]; nz++; }
+            dual = fmax(dual, fabs(g));
+        }
+    }
+    free(gl);
+    R->sd = fmax(K_SMAX, (sumlam + sumz)/fmax(1, nlam + nz))/K_SMAX;
+    R->sc = fmax(K_SMAX, sumz/fmax(1, nz))/K_SMAX;
+    R->dual = dual; R->primal = prim; R->compl_ = comp;
+    R->E = fmax(dual/R->sd, fmax(prim, comp/R->sc));
+    R->dual_u = dual/W->sf; R->primal_u = prim_u; R->compl_u = comp0/W->sf;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small dense helpers
+ * ---------------------------------------------------------------------------------------- */
+static int chol3(double A[3][3], int n, double L[3][3])
+{
+    memset(L, 0, 9*sizeof(double));
+    for (int j = 0; j < n; j++) {
+        double d = A[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k]*L[j][k];
+        if (!(d > 0) || !isfinite(d)) return 0;
+        L[j][j] = sqrt(d);
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i][j];
+            for (int k = 0; k < j; k++) s -= L[i][k]*L[j][k];
+            L[i][j] = s/L[j][j];
+        }
+    }
+    return 1;
+}
+static void chol3_solve(double L[3][3], int n, const double *b, double *x)
+{
+    double y[3];
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i][k]*y[k]; y[i] = s/L[i][i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k][i]*x[k]; x[i] = s/L[i][i]; }
+}
+
+/* Sigma and barrier gradient of one bounded scalar */
+static void bar_terms(double x, double lb, double ub, int hasL, int hasU, double zL, double zU, double mu, double *Sigma, double *gphi)
+{
+    double S = 0, g = 0;
+    if (hasL) { S += zL/(x - lb); g -= mu/(x - lb); }
+    if (hasU) { S += zU/(ub - x); g += mu/(ub - x); }
+    if (hasL && !hasU) g += K_D*mu;
+    if (!hasL && hasU) g -= K_D*mu;
+    *Sigma = S; *gphi = g;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * primal-dual direction: condensed stage systems + Riccati recursion.
+ *   res_c[i][2], res_d[i][NR]: the constraint values used as right-hand side (c and d - sigma;
+ *   replaced by the accumulated values in a second-order correction).
+ * returns 1 if the inertia is correct (all stage pivots positive), 0 otherwise.
+ * ---------------------------------------------------------------------------------------- */
+static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[2], const double (*res_d)[NR], StageDir *D)
+{
+    int N = W->N; const Prob *P = &W->P;
+
+    memset(W->HN, 0, sizeof W->HN); memset(W->hN, 0, sizeof W->hN);
+    for (int i = 0; i < N; i++) { memset(W->kk[i].H, 0, sizeof W->kk[i].H); memset(W->kk[i].h, 0, sizeof W->kk[i].h); memset(W->kk[i].E, 0, sizeof W->kk[i].E); }
+
+    /* --- assemble ------------------------------------------------------------------- */
+    for (int i = 0; i < N; i++) {
+        StageEv *e = &W->ev[i]; StageIt *I = &W->it[i]; StageKkt *Kk = &W->kk[i];
+        double Hl[NL][NL], hl[NL];
+        for (int a = 0; a < NL; a++) { hl[a] = e->objg[a]; for (int c = 0; c < NL; c++) Hl[a][c] = e->objh[a][c]; }
+        /* -lam_t * hess(tau) - lam_b * hess(bplus) on (b, w) with w = f + p */
+        {
+            double hbb = -(I->lam[0]*e->th[0] + I->lam[1]*e->bh[0]);
+            double hbw = -(I->lam[0]*e->th[1] + I->lam[1]*e->bh[1]);
+            double hww = -(I->lam[0]*e->th[2] + I->lam[1]*e->bh[2]);
+            Hl[LB][LB] += hbb; Hl[LB][LF] += hbw; Hl[LF][LB] += hbw; Hl[LF][LF] += hww;
+            if (P->withPn) { Hl[LB][LP] += hbw; Hl[LP][LB] += hbw; Hl[LF][LP] += hww; Hl[LP][LF] += hww; Hl[LP][LP] += hww; }
+        }
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double Sg, gphi;
+            bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gphi);
+            Sg += dw;
+            double coef = Sg*res_d[i][r] + gphi;
+            for (int a = 0; a < NL; a++) {
+                hl[a] += e->gr[r][a]*coef;
+                for (int c = 0; c < NL; c++) Hl[a][c] += I->nu[r]*e->hr[r][a][c] + Sg*e->gr[r][a]*e->gr[r][c];
+            }
+        }
+        for (int a = 0; a < 6; a++) { Kk->h[a] += hl[a]; for (int c = 0; c < 6; c++) Kk->H[a][c] += Hl[a][c]; }
+        for (int a = 0; a < 6; a++) { Kk->E[a][0] += Hl[a][LT1]; Kk->E[a][1] += Hl[a][LB1]; }
+        if (i + 1 < N) {
+            StageKkt *Kn = &W->kk[i + 1];
+            Kn->h[0] += hl[LT1]; Kn->h[1] += hl[LB1];
+            Kn->H[0][0] += Hl[LT1][LT1]; Kn->H[0][1] += Hl[LT1][LB1]; Kn->H[1][0] += Hl[LB1][LT1]; Kn->H[1][1] += Hl[LB1][LB1];
+        } else {
+            W->hN[0] += hl[LT1]; W->hN[1] += hl[LB1];
+            W->HN[0][0] += Hl[LT1][LT1]; W->HN[0][1] += Hl[LT1][LB1]; W->HN[1][0] += Hl[LB1][LT1]; W->HN[1][1] += Hl[LB1][LB1];
+        }
+        /* dynamics linearisation */
+        memset(Kk->F, 0, sizeof Kk->F);
+        Kk->F[0][0] = 1; Kk->F[0][1] = e->tg[0]; Kk->F[0][3] = e->tg[1]; Kk->F[0][4] = P->withPn ? e->tg[1] : 0;
+        Kk->F[1][1] = e->bg[0]; Kk->F[1][3] = e->bg[1]; Kk->F[1][4] = P->withPn ? e->bg[1] : 0;
+        Kk->F[2][3] = 1;
+        Kk->r[0] = -res_c[i][0]; Kk->r[1] = -res_c[i][1]; Kk->r[2] = 0;
+    }
+    /* variable bounds + regularisation */
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double Sg, gphi;
+            bar_terms(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], I->zL[k], I->zU[k], mu, &Sg, &gphi);
+            int a = var2loc[k];
+            if (i < N) { W->kk[i].H[a][a] += Sg + dw; W->kk[i].h[a] += gphi; }
+            else { W->HN[a][a] += Sg + dw; W->hN[a] += gphi; }
+        }
+    }
+
+    /* --- backward recursion ------------------------------------------------------------ */
+    double Pm[3][3], pv[3];
+    memcpy(Pm, W->HN, sizeof Pm); memcpy(pv, W->hN, sizeof pv);
+    /* b_N is a parameter: its row/column never enters */
+    for (int a = 0; a < 3; a++) { Pm[1][a] = Pm[a][1] = 0; } pv[1] = 0;
+
+    for (int i = N - 1; i >= 0; i--) {
+        StageKkt *Kk = &W->kk[i];
+        memcpy(Kk->Pn, Pm, sizeof Pm); memcpy(Kk->pn, pv, sizeof pv);
+        if (i == N - 1) for (int a = 0; a < 6; a++) Kk->E[a][1] = 0;   /* db_N = 0: no coupling with the parameter b_N */
+        double G[6][6], g[6], PF[3][6], Pr[3];
+        for (int a = 0; a < 3; a++) {
+            for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 3; m++) s += Pm[a][m]*Kk->F[m][c]; PF[a][c] = s; }
+            double s = pv[a]; for (int m = 0; m < 3; m++) s += Pm[a][m]*Kk->r[m]; Pr[a] = s;
+        }
+        for (int a = 0; a < 6; a++) {
+            for (int c = 0; c < 6; c++) {
+                double s = Kk->H[a][c];
+                for (int m = 0; m < 3; m++) s += Kk->F[m][a]*PF[m][c] + Kk->E[a][m]*Kk->F[m][c] + Kk->F[m][a]*Kk->E[c][m];
+                G[a][c] = s;
+            }
+            double s = Kk->h[a];
+            for (int m = 0; m < 3; m++) s += Kk->F[m][a]*Pr[m] + Kk->E[a][m]*Kk->r[m];
+            g[a] = s;
+        }
+        if (!P->withPn) { for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0; G[4][4] = 1; g[4] = 0; }
+        memcpy(Kk->Ghat, G, sizeof G); memcpy(Kk->ghat, g, sizeof g);
+
+        if (i == N - 1) {
+            /* b_N fixed: the b-row of the dynamics is an equality in (x, u); eliminate df through it */
+            double Bw = Kk->F[1][3];
+            double T[6][6]; memset(T, 0, sizeof T);
+            for (int a = 0; a < 6; a++) T[a][a] = 1;
+            T[3][3] = 0;
+            T[3][1] = -Kk->F[1][1]/Bw; T[3][4] = -Kk->F[1][4]/Bw;
+            double y0f = -Kk->r[1]/Bw;
+            memset(Kk->ef, 0, sizeof Kk->ef); Kk->ef[1] = T[3][1]; Kk->ef[4] = T[3][4]; Kk->e0 = y0f;
+            /* G~ = T^T G T, g~ = T^T (G y0 + g); column/row 3 of T is zero -> df decoupled, make it an identity pivot */
+            double GT[6][6], G2[6][6], gy[6], g2[6];
+            for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += G[a][m]*T[m][c]; GT[a][c] = s; } gy[a] = g[a] + G[a][3]*y0f; }
+            for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*GT[m][c]; G2[a][c] = s; } double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*gy[m]; g2[a] = s; }
+            for (int a = 0; a < 6; a++) G2[3][a] = G2[a][3] = 0; G2[3][3] = 1; g2[3] = 0;
+            memcpy(G, G2, sizeof G); memcpy(g, g2, sizeof g);
+        }
+
+        double Guu[3][3], L[3][3];
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) Guu[a][c] = G[3 + a][3 + c];
+        if (!chol3(Guu, 3, L)) return 0;
+        for (int c = 0; c < 3; c++) {
+            double rhs[3], sol[3];
+            for (int a = 0; a < 3; a++) rhs[a] = -G[3 + a][c];
+            chol3_solve(L, 3, rhs, sol);
+            for (int a = 0; a < 3; a++) Kk->K[a][c] = sol[a];
+        }
+        { double rhs[3]; for (int a = 0; a < 3; a++) rhs[a] = -g[3 + a]; chol3_solve(L, 3, rhs, Kk->k); }
+        for (int a = 0; a < 3; a++) {
+            for (int c = 0; c < 3; c++) { double s = G[a][c]; for (int m = 0; m < 3; m++) s += G[a][3 + m]*Kk->K[m][c]; Pm[a][c] = s; }
+            double s = g[a]; for (int m = 0; m < 3; m++) s += G[a][3 + m]*Kk->k[m]; pv[a] = s;
+        }
+        for (int a = 0; a < 3; a++) for (int c = a + 1; c < 3; c++) { double m = 0.5*(Pm[a][c] + Pm[c][a]); Pm[a][c] = Pm[c][a] = m; }
+    }
+
+    /* --- forward rollout ----------------------------------------------------------------- */
+    double dxs[3] = {0, 0, 0};   /* (dt, db, dq) of stage i; x_0 is a parameter */
+    for (int i = 0; i < N; i++) {
+        StageKkt *Kk = &W->kk[i]; StageDir *d = &D[i];
+        double du[3], y[6];
+        for (int a = 0; a < 3; a++) { double s = Kk->k[a]; for (int c = 0; c < 3; c++) s += Kk->K[a][c]*dxs[c]; du[a] = s; }
+        for (int a = 0; a < 3; a++) { y[a] = dxs[a]; y[3 + a] = du[a]; }
+        if (i == N - 1) { double s = Kk->e0; for (int a = 0; a < 6; a++) if (a != 3) s += Kk->ef[a]*y[a]; y[3] = s; }
+        if (!P->withPn) y[4] = 0;
+        double xn[3];
+        for (int a = 0; a < 3; a++) { double s = Kk->r[a]; for (int c = 0; c < 6; c++) s += Kk->F[a][c]*y[c]; xn[a] = s; }
+        if (i == N - 1) xn[1] = 0;
+        memset(d, 0, sizeof *d);
+        d->dx[VT] = y[0]; d->dx[VB] = y[1]; d->dx[VF] = y[3]; d->dx[VP] = y[4]; d->dx[VS] = y[5];
+        /* new dynamics multipliers: lam+ = -(P+ x+ + p+ + E^T y) */
+        double lp[3];
+        for (int a = 0; a < 3; a++) { double s = Kk->pn[a]; for (int c = 0; c < 3; c++) s += Kk->Pn[a][c]*xn[c]; for (int c = 0; c < 6; c++) s += Kk->E[c][a]*y[c]; lp[a] = -s; }
+        if (i == N - 1) {
+            /* multiplier of the eliminated row from stationarity wrt df: (G y + g)_f - lam_b * Bw = 0 */
+            double s = Kk->ghat[3]; for (int c = 0; c < 6; c++) s += Kk->Ghat[3][c]*y[c];
+            lp[1] = s/Kk->F[1][3];
+        }
+        d->dlam[0] = lp[0] - W->it[i].lam[0]; d->dlam[1] = lp[1] - W->it[i].lam[1];
+        dxs[0] = xn[0]; dxs[1] = xn[1]; dxs[2] = xn[2];
+    }
+    memset(&D[N], 0, sizeof D[N]);
+    D[N].dx[VT] = dxs[0]; D[N].dx[VB] = 0;
+
+    /* --- slacks, inequality multipliers, bound multipliers ----------------------------------- */
+    for (int i = 0; i < N; i++) {
+        StageEv *e = &W->ev[i]; StageIt *I = &W->it[i]; StageDir *d = &D[i];
+        double dl[NL];
+        dl[LT] = d->dx[VT]; dl[LB] = d->dx[VB]; dl[LQ] = i > 0 ? D[i - 1].dx[VF] : 0; dl[LF] = d->dx[VF]; dl[LP] = d->dx[VP]; dl[LS] = d->dx[VS];
+        dl[LT1] = D[i + 1].dx[VT]; dl[LB1] = D[i + 1].dx[VB];
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double Sg, gphi;
+            bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gphi);
+            double dsg = res_d[i][r];
+            for (int a = 0; a < NL; a++) dsg += e->gr[r][a]*dl[a];
+            d->dsig[r] = dsg;
+            d->dnu[r] = (Sg + dw)*dsg + gphi - I->nu[r];
+            if (W->rhasL[r]) { double s = I->sig[r] - W->dL[r]; d->dzLs[r] = mu/s - I->zLs[r] - I->zLs[r]/s*dsg; }
+            if (W->rhasU[r]) { double s = W->dU[r] - I->sig[r]; d->dzUs[r] = mu/s - I->zUs[r] + I->zUs[r]/s*dsg; }
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i]; StageDir *d = &D[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) { d->dx[k] = 0; continue; }
+            if (B->hasL[k]) { double s = I->x[k] - B->lb[k]; d->dzL[k] = mu/s - I->zL[k] - I->zL[k]/s*d->dx[k]; }
+            if (B->hasU[k]) { double s = B->ub[k] - I->x[k]; d->dzU[k] = mu/s - I->zU[k] + I->zU[k]/s*d->dx[k]; }
+        }
+    }
+    return 1;
+}
+
+/* maximum residual of the un-condensed Newton equations for a computed direction (debug aid) */
+static double direction_residual(Ws *W, double mu, double dw, const double (*res_c)[2], const double (*res_d)[NR], StageDir *D)
+{
+    int N = W->N; const Prob *P = &W->P; double worst = 0;
+    double (*rx)[NV] = calloc(N + 1, sizeof *rx);
+    for (int i = 0; i < N; i++) {
+        StageEv *e = &W->ev[i]; StageIt *I = &W->it[i];
+        double dl[NL], loc[NL];
+        dl[LT] = D[i].dx[VT]; dl[LB] = D[i].dx[VB]; dl[LQ] = i > 0 ? D[i - 1].dx[VF] : 0; dl[LF] = D[i].dx[VF]; dl[LP] = D[i].dx[VP]; dl[LS] = D[i].dx[VS];
+        dl[LT1] = D[i + 1].dx[VT]; dl[LB1] = D[i + 1].dx[VB];
+        double lt = I->lam[0] + D[i].dlam[0], lb = I->lam[1] + D[i].dlam[1];
+        /* W d (with current multipliers) + grad f + J^T (new multipliers) */
+        for (int a = 0; a < NL; a++) {
+            double s = e->objg[a];
+            for (int c = 0; c < NL; c++) {
+                double w = e->objh[a][c];
+                for (int r = 0; r < NR; r++) if (W->rowOn[r]) w += I->nu[r]*e->hr[r][a][c];
+                s += w*dl[c];
+            }
+            for (int r = 0; r < NR; r++) if (W->rowOn[r]) s += (I->nu[r] + D[i].dnu[r])*e->gr[r][a];
+            loc[a] = s;
+        }
+        double hbb = -(I->lam[0]*e->th[0] + I->lam[1]*e->bh[0]), hbw = -(I->lam[0]*e->th[1] + I->lam[1]*e->bh[1]), hww = -(I->lam[0]*e->th[2] + I->lam[1]*e->bh[2]);
+        double dw_ = dl[LF] + (P->withPn ? dl[LP] : 0);
+        loc[LB] += hbb*dl[LB] + hbw*dw_;
+        loc[LF] += hbw*dl[LB] + hww*dw_;
+        if (P->withPn) loc[LP] += hbw*dl[LB] + hww*dw_;
+        loc[LT1] += lt; loc[LT] -= lt; loc[LB] -= lt*e->tg[0]; loc[LF] -= lt*e->tg[1]; if (P->withPn) loc[LP] -= lt*e->tg[1];
+        loc[LB1] += lb; loc[LB] -= lb*e->bg[0]; loc[LF] -= lb*e->bg[1]; if (P->withPn) loc[LP] -= lb*e->bg[1];
+        rx[i][VT] += loc[LT]; rx[i][VB] += loc[LB]; rx[i][VF] += loc[LF]; rx[i][VP] += loc[LP]; rx[i][VS] += loc[LS];
+        if (i > 0) rx[i - 1][VF] += loc[LQ];
+        rx[i + 1][VT] += loc[LT1]; rx[i + 1][VB] += loc[LB1];
+        /* linearised dynamics */
+        double rt = dl[LT1] - dl[LT] - e->tg[0]*dl[LB] - e->tg[1]*dw_ + res_c[i][0];
+        double rb = dl[LB1] - e->bg[0]*dl[LB] - e->bg[1]*dw_ + res_c[i][1];
+        worst = fmax(worst, fmax(fabs(rt), fabs(rb)));
+        if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d dyn res %g %g\n", i, rt, rb);
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double lin = res_d[i][r] - D[i].dsig[r];
+            for (int a = 0; a < NL; a++) lin += e->gr[r][a]*dl[a];
+            worst = fmax(worst, fabs(lin));
+            if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d row %d lin res %g\n", i, r, lin);
+            /* slack stationarity: dw*dsig - nu+ - zL+ + zU+ = 0 */
+            double s = dw*D[i].dsig[r] - (I->nu[r] + D[i].dnu[r]);
+            if (W->rhasL[r]) { s -= I->zLs[r] + D[i].dzLs[r]; double sl = I->sig[r] - W->dL[r]; worst = fmax(worst, fabs(I->zLs[r]*D[i].dsig[r] + sl*D[i].dzLs[r] - (mu - sl*I->zLs[r]))); }
+            if (W->rhasU[r]) { s += I->zUs[r] + D[i].dzUs[r]; double su = W->dU[r] - I->sig[r]; worst = fmax(worst, fabs(-I->zUs[r]*D[i].dsig[r] + su*D[i].dzUs[r] - (mu - su*I->zUs[r]))); }
+            if (W->rhasL[r] && !W->rhasU[r]) s += K_D*mu;
+            if (!W->rhasL[r] && W->rhasU[r]) s -= K_D*mu;
+            worst = fmax(worst, fabs(s));
+            if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d row %d slackstat res %g\n", i, r, s);
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double s = rx[i][k] + dw*D[i].dx[k];
+            if (B->hasL[k]) s -= I->zL[k] + D[i].dzL[k];
+            if (B->hasU[k]) s += I->zU[k] + D[i].dzU[k];
+            if (B->hasL[k] && !B->hasU[k]) s += K_D*mu;
+            if (!B->hasL[k] && B->hasU[k]) s -= K_D*mu;
+            if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d var %d stat res %g\n", i, k, s);
+            worst = fmax(worst, fabs(s));
+        }
+    }
+    free(rx);
+    return worst;
+}
+
+/* fraction to the boundary for the primal variables of a direction */
+static double alpha_primal_max(const Ws *W, const StageDir *D, double tau)
+{
+    double a = 1.0; int N = W->N;
+    for (int i = 0; i <= N; i++) {
+        const StageBd *B = &W->bd[i]; const StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double dx = D[i].dx[k];
+            if (B->hasL[k] && dx < 0) a = fmin(a, -tau*(I->x[k] - B->lb[k])/dx);
+            if (B->hasU[k] && dx > 0) a = fmin(a, tau*(B->ub[k] - I->x[k])/dx);
+        }
+        if (i == N) break;
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double dsg = D[i].dsig[r];
+            if (W->rhasL[r] && dsg < 0) a = fmin(a, -tau*(I->sig[r] - W->dL[r])/dsg);
+            if (W->rhasU[r] && dsg > 0) a = fmin(a, tau*(W->dU[r] - I->sig[r])/dsg);
+        }
+    }
+    return a;
+}
+
+static double alpha_dual_max(const Ws *W, const StageDir *D, double tau)
+{
+    double a = 1.0; int N = W->N;
+    for (int i = 0; i <= N; i++) {
+        const StageBd *B = &W->bd[i]; const StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            if (B->hasL[k] && D[i].dzL[k] < 0) a = fmin(a, -tau*I->zL[k]/D[i].dzL[k]);
+            if (B->hasU[k] && D[i].dzU[k] < 0) a = fmin(a, -tau*I->zU[k]/D[i].dzU[k]);
+        }
+        if (i == N) break;
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            if (W->rhasL[r] && D[i].dzLs[r] < 0) a = fmin(a, -tau*I->zLs[r]/D[i].dzLs[r]);
+            if (W->rhasU[r] && D[i].dzUs[r] < 0) a = fmin(a, -tau*I->zUs[r]/D[i].dzUs[r]);
+        }
+    }
+    return a;
+}
+
+static void make_trial(Ws *W, const StageDir *D, double alpha)
+{
+    int N = W->N;
+    for (int i = 0; i <= N; i++) {
+        W->trial[i] = W->it[i];
+        for (int k = 0; k < NV; k++) if (W->bd[i].on[k]) W->trial[i].x[k] += alpha*D[i].dx[k];
+        if (i < N) for (int r = 0; r < NR; r++) if (W->rowOn[r]) W->trial[i].sig[r] += alpha*D[i].dsig[r];
+    }
+}
+
+static int filter_ok(const Ws *W, double theta, double phi)
+{
+    for (int j = 0; j < W->nfilt; j++)
+        if (theta >= W->filt_theta[j] && phi >= W->filt_phi[j]) return 0;
+    return 1;
+}
+
+/* lhs <= rhs up to round-off relative to basval (IPOPT's Compare_le) */
+static int cmp_le(double lhs, double rhs, double basval) { return lhs - rhs <= 10.0*DBL_EPSILON*fabs(basval); }
+
+/* ------------------------------------------------------------------------------------------
+ * driver
+ * ---------------------------------------------------------------------------------------- */
+static void ws_alloc(Ws *W, int N)
+{
+    W->N = N;
+    W->it = calloc(N + 1, sizeof(StageIt)); W->trial = calloc(N + 1, sizeof(StageIt));
+    W->bd = calloc(N + 1, sizeof(StageBd)); W->ev = calloc(N + 1, sizeof(StageEv)); W->kk = calloc(N + 1, sizeof(StageKkt));
+    W->dir = calloc(N + 1, sizeof(StageDir)); W->soc = calloc(N + 1, sizeof(StageDir));
+    W->sct = calloc(N + 1, sizeof(double)); W->scb = calloc(N + 1, sizeof(double)); W->G = calloc(N + 1, sizeof(double));
+}
+static void ws_free(Ws *W)
+{
+    free(W->it); free(W->trial); free(W->bd); free(W->ev); free(W->kk); free(W->dir); free(W->soc); free(W->sct); free(W->scb); free(W->G);
+}
+
+static double push_in(double x, double lb, double ub, int hasL, int hasU)
+{
+    if (hasL && hasU) {
+        double pL = fmin(K_PUSH*fmax(1.0, fabs(lb)), K_FRAC*(ub - lb));
+        double pU = fmin(K_PUSH*fmax(1.0, fabs(ub)), K_FRAC*(ub - lb));
+        if (x < lb + pL) x = lb + pL;
+        if (x > ub - pU) x = ub - pU;
+    } else if (hasL) { double pL = K_PUSH*fmax(1.0, fabs(lb)); if (x < lb + pL) x = lb + pL; }
+    else if (hasU) { double pU = K_PUSH*fmax(1.0, fabs(ub)); if (x > ub - pU) x = ub - pU; }
+    return x;
+}
+
+static int debug_level(void) { const char *s = getenv("ORACLE_DEBUG"); return s ? atoi(s) : 0; }
+
+int oracle_solve(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                 const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+{
+    Ws Wst; Ws *W = &Wst; memset(W, 0, sizeof *W);
+    prob_init(&W->P, ip, dp, ds, grad, curv, bmax);
+    const Prob *P = &W->P; int N = P->N; int dbg = debug_level();
+    ws_alloc(W, N);
+    setup_bounds(W);
+    for (int i = 0; i < N; i++) W->G[i] = track_resistance(P, grad[i], curv[i]);
+
+    /* ---- starting point (ocp.py:325-339): Fel 0.5, Fpb -0.1, s 1, t linear, b (60/3.6)^2 ------------ */
+    {
+        double dt = (P->tEnd - P->t0)/N, vel0 = (60/3.6)*(60/3.6);
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i];
+            I->x[VT] = P->t0 + dt*i; I->x[VB] = vel0; I->x[VF] = 0.5; I->x[VP] = P->withPn ? -0.1 : 0.0; I->x[VS] = 1;
+        }
+    }
+    /* ---- gradient-based scaling at the user's starting point (nlp_scaling_method = gradient-based, max gradient 100) ---- */
+    W->sf = 1;
+    for (int i = 0; i <= N; i++) { W->sct[i] = 1; W->scb[i] = 1; }
+    {
+        /* fixed variables take their values before scaling/evaluation */
+        W->it[0].x[VT] = P->t0; W->it[0].x[VB] = P->v0sq; W->it[N].x[VB] = P->vNsq;
+        double gmax = 0, rmax[NR] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < N; i++) {
+            eval_interval(W, W->it, i, &W->ev[i], 2);
+            StageEv *e = &W->ev[i];
+            for (int a = 0; a < NL; a++) if (a != LQ) gmax = fmax(gmax, fabs(e->objg[a]));
+            double mb = 1.0;    /* entry of b_{i+1} (or none when it is a parameter) */
+            if (i == N - 1) mb = 0;
+            if (i > 0) mb = fmax(mb, fabs(e->bg[0]));
+            mb = fmax(mb, fabs(e->bg[1]));
+            W->scb[i] = mb > 100 ? 100/mb : 1;
+            double mt = 1.0;
+            if (i > 0) mt = fmax(mt, fabs(e->tg[0]));
+            mt = fmax(mt, fabs(e->tg[1]));
+            W->sct[i] = mt > 100 ? 100/mt : 1;
+            for (int r = 0; r < NR; r++) for (int a = 0; a < NL; a++) {
+                if (i == 0 && (a == LT || a == LB)) continue;
+                if (i == N - 1 && a == LB1) continue;
+                rmax[r] = fmax(rmax[r], fabs(e->gr[r][a]));
+            }
+        }
+        gmax *= 1.0;   /* sf is still 1 here */
+        if (gmax > 100) W->sf = 100/gmax;
+        for (int r = 0; r < NR; r++) if (W->rowOn[r] && rmax[r] > 100) W->rs[r] = 100/rmax[r];
+    }
+    relax_row_bounds(W);
+
+    /* ---- push the starting point into the interior, initialise slacks and multipliers ------------------------------ */
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            I->x[k] = push_in(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k]);
+            I->zL[k] = B->hasL[k] ? 1 : 0; I->zU[k] = B->hasU[k] ? 1 : 0;
+        }
+    }
+    for (int i = 0; i < N; i++) {
+        eval_interval(W, W->it, i, &W->ev[i], 2);
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            W->it[i].sig[r] = push_in(W->ev[i].d[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r]);
+            W->it[i].zLs[r] = W->rhasL[r] ? 1 : 0; W->it[i].zUs[r] = W->rhasU[r] ? 1 : 0;
+        }
+    }
+
+    double mu = K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
+    double (*res_c)[2] = calloc(N + 1, sizeof *res_c);
+    double (*res_d)[NR] = calloc(N + 1, sizeof *res_d);
+    double (*soc_c)[2] = calloc(N + 1, sizeof *soc_c);
+    double (*soc_d)[NR] = calloc(N + 1, sizeof *soc_d);
+
+    /* least-squares multiplier estimate (W&B section 3.6): solve with W = 0, Sigma = I, no barrier terms.
+     * Realised with the same machinery: a temporary iterate whose Sigma are 1 and whose gradient is
+     * grad f - zL + zU; constraint residuals zero. */
+    {
+        /* build h = grad f - zL + zU by tricking bar_terms: use a private assembly */
+        StageIt *save = malloc((N + 1)*sizeof(StageIt)); memcpy(save, W->it, (N + 1)*sizeof(StageIt));
+        /* zero multipliers -> W = objective Hessian only; we want W = 0 exactly, so use a copy of ev with zero obj Hessian */
+        StageEv *evs = malloc((N + 1)*sizeof(StageEv)); memcpy(evs, W->ev, (N + 1)*sizeof(StageEv));
+        for (int i = 0; i < N; i++) { memset(W->ev[i].objh, 0, sizeof W->ev[i].objh); memset(W->ev[i].hr, 0, sizeof W->ev[i].hr); W->it[i].lam[0] = W->it[i].lam[1] = 0; for (int r = 0; r < NR; r++) W->it[i].nu[r] = 0; }
+        /* Sigma = 1 and gphi = -zL + zU: choose x - lb = 1 style values through direct assembly is awkward; instead
+         * emulate: mu_ls = 0, and set z/(slack) = 1 by scaling z temporarily: zL' = (x - lb) * 1 (only one of the two if both exist) */
+        for (int i = 0; i <= N; i++) {
+            StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                if (B->hasL[k]) { I->zL[k] = (I->x[k] - B->lb[k]); if (B->hasU[k]) I->zU[k] = 0; }
+                else if (B->hasU[k]) I->zU[k] = (B->ub[k] - I->x[k]);
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                if (W->rhasL[r]) { I->zLs[r] = (I->sig[r] - W->dL[r]); if (W->rhasU[r]) I->zUs[r] = 0; }
+                else if (W->rhasU[r]) I->zUs[r] = (W->dU[r] - I->sig[r]);
+            }
+        }
+        /* gradient part: with mu = 0 bar_terms gives gphi = 0; add -zL + zU (= -1 + 1 pattern) through objg of a scratch: handled by
+         * adding to the direction rhs afterwards is not possible in the condensed form, so fold into ev.objg / a slack gradient array */
+        for (int i = 0; i <= N; i++) {
+            StageBd *B = &W->bd[i];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                double gadd = -(B->hasL[k] ? 1.0 : 0.0) + (B->hasU[k] ? 1.0 : 0.0);
+                int a = var2loc[k];
+                if (i < N) W->ev[i].objg[a] += gadd;
+                else W->ev[N - 1].objg[k == VT ? LT1 : LB1] += gadd;
+            }
+        }
+        /* slack gradient -zLs + zUs: enters as gphi in the row condensation; emulate through res_d: coef = Sg*res_d + gphi with Sg = 1 */
+        for (int i = 0; i < N; i++) { res_c[i][0] = res_c[i][1] = 0; for (int r = 0; r < NR; r++) res_d[i][r] = W->rowOn[r] ? (-(W->rhasL[r] ? 1.0 : 0.0) + (W->rhasU[r] ? 1.0 : 0.0)) : 0; }
+        int ok = compute_direction(W, 0.0, 0.0, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
+        double lmax = 0;
+        if (ok) {
+            for (int i = 0; i < N; i++) {
+                /* dlam = lam+ (lam was zero); nu+ = Sg*dsig + gphi, with the emulation dsig already contains res_d -> nu+ = dsig */
+                double lt = W->dir[i].dlam[0], lb = W->dir[i].dlam[1];
+                lmax = fmax(lmax, fmax(fabs(lt)/W->sct[i], fabs(lb)/W->scb[i]));
+                for (int r = 0; r < NR; r++) if (W->rowOn[r]) lmax = fmax(lmax, fabs(W->dir[i].dsig[r]));
+            }
+        }
+        memcpy(W->ev, evs, (N + 1)*sizeof(StageEv)); free(evs);
+        StageDir *Dl = W->dir;
+        for (int i = 0; i <= N; i++) {
+            double lt = ok ? Dl[i].dlam[0] : 0, lb = ok ? Dl[i].dlam[1] : 0, nus[NR];
+            for (int r = 0; r < NR; r++) nus[r] = ok ? Dl[i].dsig[r] : 0;
+            W->it[i] = save[i];
+            if (i < N) {
+                if (ok && lmax <= LAM_INIT_MAX && isfinite(lmax)) { W->it[i].lam[0] = lt; W->it[i].lam[1] = lb; for (int r = 0; r < NR; r++) W->it[i].nu[r] = W->rowOn[r] ? nus[r] : 0; }
+                else { W->it[i].lam[0] = W->it[i].lam[1] = 0; for (int r = 0; r < NR; r++) W->it[i].nu[r] = 0; }
+            }
+        }
+        free(save);
+        if (dbg) fprintf(stderr, "[oracle] LS multipliers: ok=%d max=%g\n", ok, lmax);
+    }
+
+    /* ---- filter initialisation ------------------------------------------------------------------------------------------ */
+    double theta, phi; int okp;
+    merit_terms(W, W->it, mu, &theta, &phi, &okp);
+    W->theta_max = 1e4*fmax(1.0, theta); W->theta_min = 1e-4*fmax(1.0, theta);
+    W->nfilt = 0; W->delta_last = 0;
+
+    int status = OR_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
+    Err R; memset(&R, 0, sizeof R);
+    double alpha_pr = 0, alpha_du = 0, dnorm = 0;
+
+    for (iter = 0; ; iter++) {
+        for (int i = 0; i < N; i++) eval_interval(W, W->it, i, &W->ev[i], 2);
+        kkt_error(W, 0.0, &R);
+        if (hist && iter < hist_cap) {
+            double *hh = hist + 8*iter;
+            hh[0] = iter; hh[1] = objective_value(W, W->it)/W->sf; hh[2] = R.primal; hh[3] = R.dual; hh[4] = log10(mu); hh[5] = dnorm; hh[6] = alpha_du; hh[7] = alpha_pr;
+        }
+        if (dbg) fprintf(stderr, "[oracle] it %3d obj %.8e inf_pr %.2e inf_du %.2e compl %.2e lg(mu) %5.1f |d| %.2e a_du %.2e a_pr %.2e nf %d\n",
+                         iter, objective_value(W, W->it)/W->sf, R.primal, R.dual, R.compl_, log10(mu), dnorm, alpha_du, alpha_pr, W->nfilt);
+        /* convergence (scaled tol + unscaled dual_inf_tol = 1, constr_viol_tol = 1e-4, compl_inf_tol = 1e-4) */
+        if (R.E <= P->tol && R.dual_u <= 1.0 && R.primal_u <= 1e-4 && R.compl_u <= 1e-4) { status = OR_STATUS_SOLVED; break; }
+        if (R.E <= ACC_TOL && R.dual_u <= 1e10 && R.primal_u <= 1e-2 && R.compl_u <= 1e-2) { if (++acc_count >= ACC_ITER) { status = OR_STATUS_ACCEPTABLE; break; } }
+        else acc_count = 0;
+        if (iter >= P->maxIter) { status = OR_STATUS_MAXITER; break; }
+
+        /* barrier parameter update (monotone Fiacco-McCormick, W&B eq. (7)) */
+        {
+            Err Rm; kkt_error(W, mu, &Rm);
+            double mu_floor = fmin(P->tol, 1e-4)/(K_EPS + 1.0);
+            int changed = 0;
+            while (Rm.E <= K_EPS*mu && mu > mu_floor) {
+                double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, pow(mu, K_MU_SUP)));
+                if (nm >= mu) break;
+                mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = 1;
+                kkt_error(W, mu, &Rm);
+            }
+            if (changed) { W->nfilt = 0; }
+        }
+        merit_terms(W, W->it, mu, &theta, &phi, &okp);
+
+        /* search direction with inertia correction (W&B Algorithm IC) */
+        for (int i = 0; i < N; i++) { res_c[i][0] = W->ev[i].c[0]; res_c[i][1] = W->ev[i].c[1]; for (int r = 0; r < NR; r++) res_d[i][r] = W->rowOn[r] ? W->ev[i].d[r] - W->it[i].sig[r] : 0; }
+        double dw = 0; int ok = compute_direction(W, mu, 0.0, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
+        if (!ok) {
+            W->n_reg++;
+            dw = (W->delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*W->delta_last);
+            for (;;) {
+                ok = compute_direction(W, mu, dw, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
+                if (ok) break;
+                dw *= (W->delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
+                if (dw > DW_MAX) break;
+            }
+            if (!ok) { status = OR_STATUS_REGULARIZATION; break; }
+            W->delta_last = dw;
+        }
+        if (dbg >= 2) fprintf(stderr, "[oracle]    dw %.2e newton residual %.3e\n", dw, direction_residual(W, mu, dw, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir));
+
+        /* directional derivative of the barrier function and step norms */
+        double gphid = 0; dnorm = 0; double rel_step = 0;
+        for (int i = 0; i <= N; i++) {
+            StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                double Sg, gp; bar_terms(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], I->zL[k], I->zU[k], mu, &Sg, &gp);
+                double go = 0;
+                if (i < N) go = W->ev[i].objg[var2loc[k]];
+                if (i > 0 && k == VT) go += W->ev[i - 1].objg[LT1];
+                if (i > 0 && k == VB) go += W->ev[i - 1].objg[LB1];
+                if (k == VF && i + 1 < N) go += W->ev[i + 1].objg[LQ];
+                gphid += (go + gp)*W->dir[i].dx[k];
+                dnorm = fmax(dnorm, fabs(W->dir[i].dx[k]));
+                rel_step = fmax(rel_step, fabs(W->dir[i].dx[k])/(1 + fabs(I->x[k])));
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                double Sg, gp; bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gp);
+                gphid += gp*W->dir[i].dsig[r];
+                dnorm = fmax(dnorm, fabs(W->dir[i].dsig[r]));
+                rel_step = fmax(rel_step, fabs(W->dir[i].dsig[r])/(1 + fabs(I->sig[r])));
+            }
+        }
+
+        double amax = alpha_primal_max(W, W->dir, tau);
+        alpha_du = alpha_dual_max(W, W->dir, tau);
+
+        /* tiny step (IPOPT tiny_step_tol = 10 eps): accept the full step without line search */
+        int tiny = rel_step < 10*DBL_EPSILON;
+        double alpha = amax; int accepted = 0; const StageDir *Dacc = W->dir; int ftype_armijo = 0;
+        if (tiny) {
+            accepted = 1; make_trial(W, W->dir, alpha);
+            if (++tiny_count >= 2 && mu <= fmin(P->tol, 1e-4)/(K_EPS + 1.0)*(1 + 1e-12)) { status = OR_STATUS_TINY_STEP; break; }
+        } else tiny_count = 0;
+
+        /* alpha_min (W&B eq. (23)) */
+        double amin;
+        if (gphid < 0) {
+            amin = G_THETA;
+            amin = fmin(amin, G_PHI*theta/(-gphid));
+            if (theta <= W->theta_min) amin = fmin(amin, K_DELTA*pow(theta, S_THETA)/pow(-gphid, S_PHI));
+        } else amin = G_THETA;
+        amin *= ALPHA_MIN_FRAC;
+
+        int ls = 0;
+        while (!accepted) {
+            make_trial(W, W->dir, alpha);
+            double th_t, ph_t; int okt;
+            merit_terms(W, W->trial, mu, &th_t, &ph_t, &okt);
+            int acc = 0;
+            int ftype = (gphid < 0) && (alpha*pow(-gphid, S_PHI) > K_DELTA*pow(theta, S_THETA));
+            if (okt && th_t <= W->theta_max) {
+                if (ftype && theta <= W->theta_min) acc = cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
+                else acc = cmp_le(th_t, (1 - G_THETA)*theta, theta) || cmp_le(ph_t - phi, -G_PHI*theta, phi);
+                if (acc) acc = filter_ok(W, th_t, ph_t);
+            }
+            if (acc) { accepted = 1; Dacc = W->dir; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi); break; }
+
+            /* second-order correction (W&B section 2.4) on the first trial step if infeasibility grew */
+            if (ls == 0 && okt && th_t >= theta) {
+                double th_old = theta, th_prev = th_t; int nsoc = 0;
+                for (int i = 0; i < N; i++) { soc_c[i][0] = W->ev[i].c[0]; soc_c[i][1] = W->ev[i].c[1]; for (int r = 0; r < NR; r++) soc_d[i][r] = res_d[i][r]; }
+                double alpha_soc = alpha;
+                while (nsoc < P_MAX_SOC) {
+                    /* c_soc = alpha_soc * c_soc + c(trial) */
+                    StageEv e;
+                    for (int i = 0; i < N; i++) {
+                        eval_interval(W, W->trial, i, &e, 0);
+                        soc_c[i][0] = alpha_soc*soc_c[i][0] + e.c[0]; soc_c[i][1] = alpha_soc*soc_c[i][1] + e.c[1];
+                        for (int r = 0; r < NR; r++) if (W->rowOn[r]) soc_d[i][r] = alpha_soc*soc_d[i][r] + (e.d[r] - W->trial[i].sig[r]);
+                    }
+                    if (!compute_direction(W, mu, dw, (const double (*)[2])soc_c, (const double (*)[NR])soc_d, W->soc)) break;
+                    alpha_soc = alpha_primal_max(W, W->soc, tau);
+                    make_trial(W, W->soc, alpha_soc);
+                    double th_s, ph_s; int oks;
+                    merit_terms(W, W->trial, mu, &th_s, &ph_s, &oks);
+                    nsoc++; W->n_soc++;
+                    int accs = 0;
+                    if (oks && th_s <= W->theta_max) {
+                        if (ftype && th_old <= W->theta_min) accs = cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
+                        else accs = cmp_le(th_s, (1 - G_THETA)*th_old, th_old) || cmp_le(ph_s - phi, -G_PHI*th_old, phi);
+                        if (accs) accs = filter_ok(W, th_s, ph_s);
+                    }
+                    if (accs) { accepted = 1; Dacc = W->soc; ftype_armijo = ftype && cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi); alpha = alpha_soc; break; }
+                    if (!oks || th_s > K_SOC*th_prev) break;
+                    th_prev = th_s;
+                }
+                if (accepted) break;
+            }
+            alpha *= 0.5; ls++; W->n_back++;
+            if (alpha < amin) break;
+        }
+        if (!accepted) { status = OR_STATUS_LINESEARCH; break; }
+        alpha_pr = alpha;
+
+        /* filter augmentation (W&B eq. (22)) */
+        if (!tiny && !ftype_armijo) {
+            if (W->nfilt < 512) { W->filt_theta[W->nfilt] = (1 - G_THETA)*theta; W->filt_phi[W->nfilt] = phi - G_PHI*theta; W->nfilt++; }
+        }
+
+        /* accept: primal from the trial point, equality multipliers with the primal step, bound multipliers with the
+         * fraction-to-the-boundary step of the direction that was actually taken (the corrected one after a SOC) */
+        if (Dacc != W->dir) alpha_du = alpha_dual_max(W, Dacc, tau);
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i]; StageBd *B = &W->bd[i]; const StageDir *d = &Dacc[i];
+            for (int k = 0; k < NV; k++) if (B->on[k]) I->x[k] = W->trial[i].x[k];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                if (B->hasL[k]) I->zL[k] += alpha_du*d->dzL[k];
+                if (B->hasU[k]) I->zU[k] += alpha_du*d->dzU[k];
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                I->sig[r] = W->trial[i].sig[r];
+                I->nu[r] += alpha_pr*d->dnu[r];
+                if (W->rhasL[r]) I->zLs[r] += alpha_du*d->dzLs[r];
+                if (W->rhasU[r]) I->zUs[r] += alpha_du*d->dzUs[r];
+            }
+            I->lam[0] += alpha_pr*d->dlam[0]; I->lam[1] += alpha_pr*d->dlam[1];
+        }
+        /* keep Sigma within [mu/(kappa_Sigma s), kappa_Sigma mu / s] (W&B eq. (16)) */
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i]; StageBd *B = &W->bd[i];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                if (B->hasL[k]) { double s = I->x[k] - B->lb[k]; I->zL[k] = fmax(fmin(I->zL[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                if (B->hasU[k]) { double s = B->ub[k] - I->x[k]; I->zU[k] = fmax(fmin(I->zU[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                if (W->rhasL[r]) { double s = I->sig[r] - W->dL[r]; I->zLs[r] = fmax(fmin(I->zLs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                if (W->rhasU[r]) { double s = W->dU[r] - I->sig[r]; I->zUs[r] = fmax(fmin(I->zUs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+            }
+        }
+    }
+
+    /* ---- outputs ------------------------------------------------------------------------------------------------------------- */
+    int stp = 4 + P->withPn;
+    for (int i = 0; i < N; i++) {
+        double *zi = z_out + stp*i; int c = 0;
+        zi[c++] = W->it[i].x[VF]; if (P->withPn) zi[c++] = W->it[i].x[VP];
+        zi[c++] = W->it[i].x[VS]; zi[c++] = W->it[i].x[VT]; zi[c++] = W->it[i].x[VB];
+    }
+    z_out[stp*N] = W->it[N].x[VT]; z_out[stp*N + 1] = W->it[N].x[VB];
+    if (lam_out) {
+        int rpi = rows_per_interval(P);
+        for (int i = 0; i < N; i++) {
+            double *l = lam_out + rpi*i; int c = 0;
+            if (P->hasPower) { l[c++] = W->it[i].nu[RPW0]*W->rs[RPW0]/W->sf; l[c++] = W->it[i].nu[RPW1]*W->rs[RPW1]/W->sf; }
+            l[c++] = W->it[i].nu[RACC]*W->rs[RACC]/W->sf;
+            l[c++] = W->it[i].lam[0]/W->sf; l[c++] = W->it[i].lam[1]/W->sf;
+            if (P->energyOpt) { l[c++] = W->it[i].nu[RLTR]*W->rs[RLTR]/W->sf; l[c++] = W->it[i].nu[RLRG]*W->rs[RLRG]/W->sf; }
+        }
+    }
+    if (stats) {
+        stats[OR_ST_STATUS] = status; stats[OR_ST_ITERS] = iter; stats[OR_ST_OBJ] = objective_value(W, W->it)/W->sf;
+        stats[OR_ST_KKT] = R.E; stats[OR_ST_MU] = mu; stats[OR_ST_DUAL_INF] = R.dual_u; stats[OR_ST_CONSTR_VIOL] = R.primal_u; stats[OR_ST_COMPL] = R.compl_u;
+        stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back;
+    }
+    free(res_c); free(res_d); free(soc_c); free(soc_d);
+    ws_free(W);
+    return status;
+}
+
+int oracle_solve_batch(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                       const double *bmax, int nscen, const double *scen, double *z_out, double *stats, int nthreads)
+{
+    int N = ip[OR_IP_N], nz = (4 + ip[OR_IP_WITH_PN])*N + 2, nfail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+:nfail)
+    for (int k = 0; k < nscen; k++) {
+        double dpl[OR_DP_COUNT];
+        memcpy(dpl, dp, sizeof dpl);
+        dpl[OR_DP_T0] = scen[4*k]; dpl[OR_DP_TEND] = scen[4*k + 1]; dpl[OR_DP_V0SQ] = scen[4*k + 2]; dpl[OR_DP_VNSQ] = scen[4*k + 3];
+        int st = oracle_solve(ip, dpl, ds, grad, curv, bmax, z_out + (size_t)nz*k, NULL, stats + (size_t)OR_ST_COUNT*k, NULL, 0);
+        if (st < 0) nfail++;
+    }
+    return nfail;
+}

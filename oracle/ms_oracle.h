@@ -1,0 +1,119 @@
+/*
+ * ms_oracle.h -- CPU ORACLE for the multiple-shooting train-control hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product path is the HIP library declared in include/mseetc_hip.h.
+ *
+ * What it restates (reference = dkouzoup/ms-eetc, paths relative to the reference):
+ *   - the NLP transcription of mseetc/ocp.py:96-284 (variables, bounds, constraint rows,
+ *     objective, scaling) on the grid of mseetc/track.py:91-107,
+ *   - the interval integrator of mseetc/train.py:225-277,294-301,324-344 (RK4 via
+ *     casadi.simpleRK semantics + trapezoidal time update), with first and second
+ *     derivatives (CasADi AD in the reference),
+ *   - the static loss rows of mseetc/train.py:199-216 + mseetc/utils.py:197-220,
+ *   - the NLP solver: the reference calls casadi.nlpsol('ipopt') (ocp.py:290,359), i.e.
+ *     the third-party IPOPT bundled with casadi==3.6.3 (setup.py:12; IPOPT 3.14.x with
+ *     MUMPS), which is NOT present under /root/reference and not installable here.  Its
+ *     published algorithm (Waechter & Biegler, "On the implementation of an interior-point
+ *     filter line-search algorithm for large-scale nonlinear programming", Math. Prog.
+ *     106(1), 2006 -- Algorithm A with IPOPT's default option values) is restated in
+ *     ms_oracle.c; the linear algebra (MUMPS LDL^T + inertia) is replaced by a Riccati
+ *     recursion over the stages, whose pivots carry the same inertia information.
+ *
+ * PARITY STATUS: the NLP/integrator/grid restatement is pinned by the reference's own
+ * stored numbers (tests/test_oracle_pins.py: GPOPS energies, figure4/figure5 constants).
+ * At the IPOPT boundary parity is UNPINNED: the repository stores no casadiSolver output and
+ * casadi cannot run here.  Substitute evidence: an independent numpy KKT +
+ * second-order certificate of every oracle solution (tests/kkt_certificate.py).
+ */
+#ifndef MS_ORACLE_H
+#define MS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* integer parameters (ip[]) */
+enum {
+    OR_IP_N = 0,          /* number of shooting intervals                                    */
+    OR_IP_WITH_PN,        /* pneumatic brake variable present (train.forceMinPn != 0)        */
+    OR_IP_HAS_POWER,      /* power rows present (powerMax or powerMin set, ocp.py:184)       */
+    OR_IP_ENERGY_OPT,     /* 1: energy optimal, 0: time optimal                              */
+    OR_IP_NUM_STEPS,      /* RK4 steps per interval                                          */
+    OR_IP_NUM_APPROX,     /* trapezoidal time sub-intervals (0: integrate time with RK4)     */
+    OR_IP_LOSS_KIND,      /* 0 none, 1 static efficiencies                                   */
+    OR_IP_MAX_ITER,
+    OR_IP_COUNT
+};
+
+/* real parameters (dp[]) -- "specific" = per kg of mass*rho */
+enum {
+    OR_DP_SR0 = 0, OR_DP_SR1, OR_DP_SR2,  /* specific Davis coefficients (train.py:181-183)  */
+    OR_DP_G, OR_DP_RHO,
+    OR_DP_FMAX,           /* upper bound on Fel                                              */
+    OR_DP_FMIN,           /* lower bound on Fel (0 without regenerative brake)               */
+    OR_DP_FMIN_PN,        /* lower bound on Fpb                                              */
+    OR_DP_PW_UPPER,       /* abs(upper) of the power rows (ocp.py:186,191)                   */
+    OR_DP_PW_LOWER,       /* abs(lower) of the power rows (ocp.py:187,192)                   */
+    OR_DP_ACC_MIN, OR_DP_ACC_MAX,
+    OR_DP_LOSS_CT,        /* s >= ct*Fel   (static model, (1-eta_t)/eta_t)                   */
+    OR_DP_LOSS_CR,        /* s >= -cr*Fel  (static model, 1-eta_r)                           */
+    OR_DP_VMIN_SQ,        /* minimumVelocity^2                                               */
+    OR_DP_OBJ_DEN,        /* scalingFactorObjective (ocp.py:278,282)                         */
+    OR_DP_TOL,            /* IPOPT tol (1e-8)                                                */
+    OR_DP_T0, OR_DP_TEND, OR_DP_V0SQ, OR_DP_VNSQ,   /* scenario (already clipped, ocp.py:343-344) */
+    OR_DP_COUNT
+};
+
+/* stats[] */
+enum {
+    OR_ST_STATUS = 0,     /* 0 solved, 1 solved to acceptable level, <0 failure              */
+    OR_ST_ITERS,
+    OR_ST_OBJ,            /* NLP objective (kWh for the energy problem, scaled time otherwise) */
+    OR_ST_KKT,            /* final scaled NLP error E_0                                       */
+    OR_ST_MU,
+    OR_ST_DUAL_INF, OR_ST_CONSTR_VIOL, OR_ST_COMPL,
+    OR_ST_N_REG,          /* iterations that needed inertia correction                       */
+    OR_ST_N_SOC,          /* second-order corrections taken                                  */
+    OR_ST_N_BACKTRACK,    /* total backtracking steps                                        */
+    OR_ST_COUNT
+};
+
+#define OR_STATUS_SOLVED 0
+#define OR_STATUS_ACCEPTABLE 1
+#define OR_STATUS_MAXITER (-1)
+#define OR_STATUS_LINESEARCH (-2)    /* step became too small: IPOPT would enter restoration  */
+#define OR_STATUS_REGULARIZATION (-3)
+#define OR_STATUS_NUMERIC (-4)
+#define OR_STATUS_TINY_STEP (-5)
+
+/*
+ * Solve one OCP.  ds/grad/curv have N entries (grad already divided by 1000, ocp.py:195),
+ * bmax has N+1 entries (bmax[i] = min(vlim_i, vmax, vlim_{i-1})^2 for interior nodes,
+ * ocp.py:266-269; entries 0 and N unused).
+ *   z_out   : nz = (4+withPn)*N + 2 doubles in the reference's layout (ocp.py:166-272)
+ *   lam_out : multipliers of the 7N (or fewer) constraint rows in the reference's row order, may be NULL
+ *   hist    : optional iteration log, 8 doubles per iteration (iter, obj, inf_pr, inf_du, lg(mu), |d|, alpha_du, alpha_pr), may be NULL
+ */
+int oracle_solve(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                 const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+
+/* Batch of scenarios (t0, T, v0sq, vNsq per scenario, 4 doubles each) with OpenMP over scenarios. */
+int oracle_solve_batch(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                       const double *bmax, int nscen, const double *scen, double *z_out, double *stats, int nthreads);
+
+/*
+ * One shooting interval (train.py:347-364): out = {tau, bplus, dtau/db, dtau/dw, dbplus/db, dbplus/dw,
+ * d2tau/dbdb, d2tau/dbdw, d2tau/dwdw, d2bplus/dbdb, d2bplus/dbdw, d2bplus/dwdw} where tau = t+ - t and w = Fel+Fpb.
+ */
+void oracle_stage_eval(const int *ip, const double *dp, double b, double w, double ds, double grad, double curv, double *out12);
+
+/* NLP functions at z (reference layout): objective and the constraint rows in the reference's order. */
+void oracle_nlp_eval(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                     const double *z, double *obj, double *g_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

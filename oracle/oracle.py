@@ -1,0 +1,256 @@
+"""
+ctypes front end of the CPU oracle (oracle/ms_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() as the
+checker and by bench.py's cpu_baseline leg; never by the product package.
+
+`pack_problem` restates, independently of the product's host code, how the reference
+turns (train, track, options) into NLP data: mseetc/ocp.py:96-125 (specific bounds,
+accInf = 10, power bounds, grid) and :266-269 (interior speed bound).
+"""
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+
+IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, COUNT=8)
+DP = dict(SR0=0, SR1=1, SR2=2, G=3, RHO=4, FMAX=5, FMIN=6, FMIN_PN=7, PW_UPPER=8, PW_LOWER=9, ACC_MIN=10, ACC_MAX=11,
+          LOSS_CT=12, LOSS_CR=13, VMIN_SQ=14, OBJ_DEN=15, TOL=16, T0=17, TEND=18, V0SQ=19, VNSQ=20, COUNT=21)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, COUNT=11)
+
+_lib = None
+
+
+def build(force=False):
+    "Compile oracle/libms_oracle.so with gcc (no-op when up to date)."
+
+    so = HERE / 'libms_oracle.so'
+    src = [HERE / 'ms_oracle.c', HERE / 'ms_oracle.h']
+
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in src if s.exists()):
+        subprocess.run(['make', '-C', str(HERE), 'libms_oracle.so'], check=True, capture_output=True)
+
+    return so
+
+
+def lib():
+
+    global _lib
+
+    if _lib is None:
+
+        so = HERE / 'libms_oracle.so'
+
+        if not so.exists():
+            build()
+
+        _lib = ctypes.CDLL(str(so))
+
+        dptr = ctypes.POINTER(ctypes.c_double)
+        iptr = ctypes.POINTER(ctypes.c_int)
+
+        _lib.oracle_solve.restype = ctypes.c_int
+        _lib.oracle_solve.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int]
+        _lib.oracle_solve_batch.restype = ctypes.c_int
+        _lib.oracle_solve_batch.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
+        _lib.oracle_stage_eval.restype = None
+        _lib.oracle_stage_eval.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
+        _lib.oracle_nlp_eval.restype = None
+        _lib.oracle_nlp_eval.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr]
+
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+class Problem():
+    "Flat NLP data of one (train, track, options) triple."
+
+    def __init__(self, ip, dp, ds, grad, curv, bmax, vlim0, vlimN, totalMass, positions):
+        self.ip = np.ascontiguousarray(ip, dtype=np.int32)
+        self.dp = np.ascontiguousarray(dp, dtype=np.float64)
+        self.ds = np.ascontiguousarray(ds, dtype=np.float64)
+        self.grad = np.ascontiguousarray(grad, dtype=np.float64)
+        self.curv = np.ascontiguousarray(curv, dtype=np.float64)
+        self.bmax = np.ascontiguousarray(bmax, dtype=np.float64)
+        self.vlim0, self.vlimN = vlim0, vlimN
+        self.totalMass = totalMass
+        self.positions = positions
+
+    @property
+    def N(self):
+        return int(self.ip[IP['N']])
+
+    @property
+    def withPn(self):
+        return int(self.ip[IP['WITH_PN']])
+
+    @property
+    def nz(self):
+        return (4 + self.withPn)*self.N + 2
+
+    @property
+    def rowsPerInterval(self):
+        return (2 if self.ip[IP['HAS_POWER']] else 0) + 3 + (2 if self.ip[IP['ENERGY_OPT']] else 0)
+
+    def scenario(self, terminalTime, initialTime=0.0, terminalVelocity=1.0, initialVelocity=1.0):
+        "dp with the four real-time parameters substituted (ocp.py:343-355)."
+
+        vmin = np.sqrt(self.dp[DP['VMIN_SQ']])
+        v0 = min(max(initialVelocity, vmin), self.vlim0)
+        vN = min(max(terminalVelocity, vmin), self.vlimN)
+
+        dp = self.dp.copy()
+        dp[DP['T0']], dp[DP['TEND']], dp[DP['V0SQ']], dp[DP['VNSQ']] = initialTime, terminalTime, v0**2, vN**2
+
+        return dp
+
+
+def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
+    """
+    (train attribute bag, grid frame, option dict) -> Problem.
+    `points`: DataFrame of computeDiscretizationPoints (index = positions).
+    `opts`: dict with numIntervals, maxIterations, energyOptimal, minimumVelocity, numSteps, numApproxSteps.
+    """
+
+    N = int(opts['numIntervals'])
+    pos = points.index.values.astype(float)
+
+    assert len(pos) == N + 1
+
+    totalMass = train.mass*train.rho   # ocp.py:97
+
+    withRg = train.forceMin != 0       # ocp.py:101-102
+    withPn = train.forceMinPn != 0
+
+    accInf = 10.0                      # ocp.py:104
+
+    fmax = train.forceMax/totalMass if train.forceMax is not None else accInf
+    fminRg = train.forceMin/totalMass if train.forceMin is not None else -accInf
+    fminPn = train.forceMinPn/totalMass if train.forceMinPn is not None else -accInf
+
+    pmax = train.powerMax/totalMass if train.powerMax is not None else None
+    pmin = train.powerMin/totalMass if train.powerMin is not None else None
+
+    accMax = min(accInf, train.accMax if train.accMax is not None else accInf)          # ocp.py:113
+    accMin = max(-accInf, -abs(train.accMin) if train.accMin is not None else -accInf)  # ocp.py:114
+
+    hasPower = pmax is not None or pmin is not None   # ocp.py:184
+
+    if hasPower:
+        upper = pmax if pmax is not None else fmax*train.velocityMax                                        # ocp.py:186
+        lower = 0 if not withRg else (pmin if pmin is not None else fminRg*train.velocityMax)               # ocp.py:187
+    else:
+        upper = lower = 0.0
+
+    vlim = points['Speed limit [m/s]'].values.astype(float)
+
+    bmax = np.zeros(N + 1)
+
+    for i in range(1, N):
+        bmax[i] = min(vlim[i], train.velocityMax, vlim[i - 1])**2   # ocp.py:266-269
+
+    energyOptimal = bool(opts['energyOptimal'])
+
+    objDen = 3.6/(1e-6*totalMass) if energyOptimal else trackLength/train.velocityMax   # ocp.py:278,282
+
+    ip = np.zeros(IP['COUNT'], dtype=np.int32)
+    ip[IP['N']] = N
+    ip[IP['WITH_PN']] = int(withPn)
+    ip[IP['HAS_POWER']] = int(hasPower)
+    ip[IP['ENERGY_OPT']] = int(energyOptimal)
+    ip[IP['NUM_STEPS']] = int(opts.get('numSteps', 1))
+    ip[IP['NUM_APPROX']] = int(opts.get('numApproxSteps', 0))
+    ip[IP['LOSS_KIND']] = int(lossKind)
+    ip[IP['MAX_ITER']] = int(opts.get('maxIterations', 1000))
+
+    dp = np.zeros(DP['COUNT'])
+    dp[DP['SR0']], dp[DP['SR1']], dp[DP['SR2']] = train.r0/totalMass, train.r1/totalMass, train.r2/totalMass
+    dp[DP['G']], dp[DP['RHO']] = train.g, train.rho
+    dp[DP['FMAX']] = fmax
+    dp[DP['FMIN']] = fminRg if withRg else 0.0     # ocp.py:175
+    dp[DP['FMIN_PN']] = fminPn
+    dp[DP['PW_UPPER']], dp[DP['PW_LOWER']] = abs(upper), abs(lower)
+    dp[DP['ACC_MIN']], dp[DP['ACC_MAX']] = accMin, accMax
+    dp[DP['LOSS_CT']], dp[DP['LOSS_CR']] = ct, cr
+    dp[DP['VMIN_SQ']] = float(opts.get('minimumVelocity', 1))**2
+    dp[DP['OBJ_DEN']] = objDen
+    dp[DP['TOL']] = tol
+
+    grad = points['Gradient [permil]'].values[:N].astype(float)/1e3   # ocp.py:195
+    curv = points['Curvature [1/m]'].values[:N].astype(float)         # ocp.py:196
+
+    return Problem(ip, dp, np.diff(pos), grad, curv, bmax, float(vlim[0]), float(vlim[-1]), totalMass, pos)
+
+
+def solve(prob, dp, history=False):
+    "One solve -> dict(z, lam_g, stats[, hist])."
+
+    L = lib()
+    z = np.zeros(prob.nz)
+    lam = np.zeros(prob.rowsPerInterval*prob.N)
+    st = np.zeros(ST['COUNT'])
+    cap = int(prob.ip[IP['MAX_ITER']]) + 2 if history else 0
+    hist = np.zeros((max(cap, 1), 8))
+    dp = np.ascontiguousarray(dp, dtype=np.float64)
+
+    L.oracle_solve(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), _d(z), _d(lam), _d(st),
+                   _d(hist) if history else None, cap)
+
+    out = dict(z=z, lam_g=lam, stats={k: st[v] for k, v in ST.items() if k != 'COUNT'})
+
+    if history:
+        out['hist'] = hist[:int(st[ST['ITERS']]) + 1]
+
+    return out
+
+
+def solve_batch(prob, scen, nthreads=0):
+    "scen: (B,4) array of (t0, T, v0sq, vNsq).  Returns (z (B,nz), stats (B,ST_COUNT), nfail)."
+
+    L = lib()
+    scen = np.ascontiguousarray(scen, dtype=np.float64)
+    B = scen.shape[0]
+    z = np.zeros((B, prob.nz))
+    st = np.zeros((B, ST['COUNT']))
+
+    nfail = L.oracle_solve_batch(_i(prob.ip), _d(prob.dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), B, _d(scen),
+                                 _d(z), _d(st), int(nthreads))
+
+    return z, st, nfail
+
+
+def stage_eval(prob_or_ipdp, b, w, ds, grad=0.0, curv=0.0):
+    "tau, bplus and their first/second derivatives wrt (b, w) for one interval."
+
+    L = lib()
+    ip, dp = (prob_or_ipdp.ip, prob_or_ipdp.dp) if isinstance(prob_or_ipdp, Problem) else prob_or_ipdp
+    out = np.zeros(12)
+    L.oracle_stage_eval(_i(np.ascontiguousarray(ip, dtype=np.int32)), _d(np.ascontiguousarray(dp, dtype=np.float64)),
+                        float(b), float(w), float(ds), float(grad), float(curv), _d(out))
+
+    return out
+
+
+def nlp_eval(prob, dp, z):
+    "Objective and the constraint rows (reference order) at z."
+
+    L = lib()
+    obj = np.zeros(1)
+    g = np.zeros(prob.rowsPerInterval*prob.N)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    dp = np.ascontiguousarray(dp, dtype=np.float64)
+    L.oracle_nlp_eval(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(z), _d(obj), _d(g))
+
+    return float(obj[0]), g

@@ -1,0 +1,87 @@
+"""
+Problem configurations used across the tests and adapters that
+turn them into (a) the oracle's flat problem and (b) the independent numpy NLP.
+"""
+
+import numpy as np
+
+from mseetc.track import Track, computeDiscretizationPoints
+from mseetc.train import Train
+
+from oracle import oracle
+from oracle.oracle import DP, IP
+
+import nlp_numpy
+
+CONFIG_JSON = dict(maxIterations=500, numIntervals=300, integrationMethod='RK',
+                   integrationOptions=dict(order=4, numSteps=1, numApproxSteps=1))   # simulations/config.json
+
+
+def train_default():
+    return Train(config={'id': 'NL_Intercity_VIRM6'})
+
+
+def train_fig10():
+    "figure10.py:16-22 / gpops/trainMain.m configuration"
+    train = train_default()
+    train.forceMinPn = 0
+    train.forceMin = -train.forceMax
+    train.powerMax = 3129277
+    train.powerMin = -train.powerMax
+    train.etaTraction = 0.73
+    train.etaRgBrake = 0.73
+    return train
+
+
+def train_fig5():
+    "figure5.py:87-94 after the side effects of totalLossesFunction (efficiency.py:56-71)"
+    train = train_default()
+    train.forceMinPn = 0
+    hz = lambda f: ((f - 20)/(170 - 20))*(160 - 20) + 20
+    pmax = train.forceMax*hz(55)/3.6
+    train.powerMax = pmax
+    train.powerMin = -pmax
+    train.forceMin = -train.forceMax*(train.forceMin != 0)
+    train.velocityMax = 160/3.6
+    return train
+
+
+def track_00(crop=None):
+    track = Track(config={'id': '00_var_speed_limit_100'})
+    if crop is not None:
+        track.updateLimits(positionEnd=crop)
+    return track
+
+
+def track_CH():
+    return Track(config={'id': 'CH_StGallen_Wil'})
+
+
+def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1):
+    pts = computeDiscretizationPoints(track, N)
+    opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal, minimumVelocity=vmin,
+                numSteps=numSteps, numApproxSteps=numApproxSteps)
+    if losses == 'static':
+        kind, ct, cr = 1, (1 - train.etaTraction)/train.etaTraction, 1 - train.etaRgBrake
+    else:
+        kind, ct, cr = 0, 0.0, 0.0
+    return oracle.pack_problem(train, pts, opts, kind, ct, cr, track.length)
+
+
+def numpy_nlp(prob):
+    ip, dp = prob.ip, prob.dp
+    return nlp_numpy.NLP(N=int(ip[IP['N']]), withPn=bool(ip[IP['WITH_PN']]), hasPower=bool(ip[IP['HAS_POWER']]),
+                         energyOptimal=bool(ip[IP['ENERGY_OPT']]), numSteps=int(ip[IP['NUM_STEPS']]), numApprox=int(ip[IP['NUM_APPROX']]),
+                         ds=prob.ds, grad=prob.grad, curv=prob.curv, sr0=dp[DP['SR0']], sr1=dp[DP['SR1']], sr2=dp[DP['SR2']],
+                         g=dp[DP['G']], rho=dp[DP['RHO']], fmax=dp[DP['FMAX']], fmin=dp[DP['FMIN']], fminPn=dp[DP['FMIN_PN']],
+                         pwUpper=dp[DP['PW_UPPER']], pwLower=dp[DP['PW_LOWER']], accMin=dp[DP['ACC_MIN']], accMax=dp[DP['ACC_MAX']],
+                         ct=dp[DP['LOSS_CT']], cr=dp[DP['LOSS_CR']], vminSq=dp[DP['VMIN_SQ']], objDen=dp[DP['OBJ_DEN']], bmax=prob.bmax)
+
+
+def c1_times(B, seed=20260612):
+    "Config 1 running times (SURVEY.md section 8d): T_i = 1541 (1 + 0.15 u_i)"
+    return 1541*(1 + 0.15*np.random.default_rng(seed).random(B))
+
+
+def c2_times(B, seed=20260613):
+    return 1242*(1 + 0.15*np.random.default_rng(seed).random(B))
