@@ -1,0 +1,156 @@
+/*
+ * mseetc_hip.h -- C ABI of the MI355X (gfx950) multiple-shooting train-control solver.
+ *
+ * This is the drop-in boundary for the one hot path of dkouzoup/ms-eetc: what
+ * `casadiSolver(train, track, opts).solve(...)` hands to `casadi.nlpsol('ipopt')`
+ * (reference mseetc/ocp.py:288-290 construction, :359 the call) -- here solved for a whole
+ * batch of independent scenarios by hand-written HIP kernels.  Plain pointers and sizes only;
+ * the caller owns every buffer; every entry point returns 0 on success and a negative MSD_E_*
+ * code otherwise (msd_last_error() gives the text); no exception crosses the boundary.
+ * A handle may be used from one host thread at a time.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  The Python binding a maintainer would add is shown in INTEGRATION.md and
+ * implemented in ms-eetc_amd/mseetc/_device.py.
+ */
+#ifndef MSEETC_HIP_H
+#define MSEETC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSD_ABI_VERSION 1
+
+/* error codes */
+#define MSD_OK 0
+#define MSD_E_INVALID (-1)     /* bad argument (ValueError on the Python side)            */
+#define MSD_E_HIP (-2)         /* HIP runtime error                                       */
+#define MSD_E_UNSUPPORTED (-3) /* option outside the device path (e.g. N too large)       */
+#define MSD_E_NODEVICE (-4)
+
+/* per-scenario solver status (stats[MSD_ST_STATUS]); >= 0 is success, like IPOPT's
+ * Solve_Succeeded / Solved_To_Acceptable_Level (ocp.py:362-364) */
+#define MSD_STATUS_SOLVED 0
+#define MSD_STATUS_ACCEPTABLE 1
+#define MSD_STATUS_MAXITER (-1)
+#define MSD_STATUS_LINESEARCH (-2)
+#define MSD_STATUS_REGULARIZATION (-3)
+#define MSD_STATUS_NUMERIC (-4)
+#define MSD_STATUS_TINY_STEP (-5)
+
+/* stats record: MSD_ST_COUNT doubles per scenario */
+enum {
+    MSD_ST_STATUS = 0,
+    MSD_ST_ITERS,        /* interior-point iterations ('IP iterations', ocp.py:362)         */
+    MSD_ST_OBJ,          /* NLP objective: kWh (energy optimal) or scaled time               */
+    MSD_ST_KKT,          /* final scaled optimality error                                    */
+    MSD_ST_MU,
+    MSD_ST_DUAL_INF, MSD_ST_CONSTR_VIOL, MSD_ST_COMPL,
+    MSD_ST_N_REG, MSD_ST_N_SOC, MSD_ST_N_BACKTRACK,
+    MSD_ST_COUNT
+};
+
+/* scenario record: MSD_SC_COUNT doubles per scenario */
+enum {
+    MSD_SC_T0 = 0,       /* initialTime          (ocp.py:310,346-355)                        */
+    MSD_SC_TEND,         /* terminalTime                                                     */
+    MSD_SC_V0SQ,         /* clipped initialVelocity^2  (ocp.py:343)                          */
+    MSD_SC_VNSQ,         /* clipped terminalVelocity^2 (ocp.py:344)                          */
+    MSD_SC_COUNT
+};
+
+/*
+ * Problem description = everything casadiSolver.__init__ derives from (train, track, options)
+ * (ocp.py:96-125, 134-284): specific force/power/acceleration bounds, the shooting grid and the
+ * piecewise-constant track profile on it, the integrator options and the loss model.
+ * "specific" = per kg of mass*rho (ocp.py:97).
+ */
+typedef struct msd_problem_desc {
+    int abi_version;         /* MSD_ABI_VERSION */
+    int num_intervals;       /* N (OptionsCasadiSolver.numIntervals, ocp.py:16)              */
+    int with_pn_brake;       /* train.forceMinPn != 0 (ocp.py:102)                            */
+    int has_power_rows;      /* powerMax or powerMin set (ocp.py:184)                         */
+    int energy_optimal;      /* ocp.py:20                                                     */
+    int num_steps;           /* OptionsRK.numSteps (train.py:463)                             */
+    int num_approx_steps;    /* OptionsRK.numApproxSteps (train.py:465)                       */
+    int loss_kind;           /* 0 none, 1 static efficiencies (train.py:199-212)              */
+    int max_iterations;      /* ocp.py:18,290                                                 */
+    int reserved_i[7];
+    double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
+    double g, rho;
+    double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */
+    double f_min_pn;         /* lower bound of Fpb                                            */
+    double pw_upper, pw_lower; /* abs() bounds of the power rows (ocp.py:186-192)             */
+    double acc_min, acc_max; /* ocp.py:113-114                                                */
+    double loss_ct, loss_cr; /* static loss rows s >= ct*Fel, s >= -cr*Fel                    */
+    double vmin_sq;          /* minimumVelocity^2 (ocp.py:22,271)                             */
+    double obj_den;          /* scalingFactorObjective (ocp.py:278,282)                       */
+    double tol;              /* IPOPT tol, 1e-8                                               */
+    double reserved_d[7];
+    const double *ds;        /* [N]   interval lengths (ocp.py:125)                           */
+    const double *grad;      /* [N]   gradient, permil/1000 (ocp.py:195)                      */
+    const double *curv;      /* [N]   curvature 1/m (ocp.py:196)                              */
+    const double *bmax;      /* [N+1] upper bound of b at interior nodes (ocp.py:266-269)     */
+} msd_problem_desc;
+
+typedef struct msd_problem *msd_handle;
+
+/* number of GPUs visible to the process */
+int msd_device_count(void);
+
+/* Replaces casadiSolver.__init__ (ocp.py:80-307): validates, uploads the grid/profile to `device`. */
+int msd_problem_create(const msd_problem_desc *desc, int device, msd_handle *out);
+
+int msd_problem_destroy(msd_handle h);
+
+/* nz = (4 + with_pn_brake)*N + 2 (ocp.py:166-272) and rows of g per interval (ocp.py:183-229) */
+int msd_problem_nz(msd_handle h);
+int msd_problem_rows_per_interval(msd_handle h);
+
+/*
+ * Replaces the body of casadiSolver.solve (ocp.py:325-362) for `nscen` scenarios at once: cold start
+ * (ocp.py:325-339), interior-point solve (ocp.py:359), z* in the reference's layout and the statistics.
+ * Host buffers; the call uploads, runs, downloads and synchronises.
+ *   scen   [nscen][MSD_SC_COUNT]
+ *   z_out  [nscen][nz]
+ *   lam_out[nscen][rows_per_interval*N]  multipliers of g in the reference's row order, may be NULL
+ *   stats  [nscen][MSD_ST_COUNT]
+ *   kernel_ms: if not NULL receives the solve kernel's duration measured with HIP events on the launch stream
+ */
+int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, double *lam_out, double *stats,
+                    float *kernel_ms);
+
+/*
+ * Same with buffers already resident in device memory (the benchmark path): nothing is copied, the kernel is
+ * enqueued on the handle's stream; msd_synchronize() waits.  Used to time throughput with inputs in HBM.
+ */
+int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats);
+int msd_synchronize(msd_handle h);
+
+/* device scratch management for callers without their own allocator (ctypes): */
+int msd_device_alloc(msd_handle h, unsigned long long bytes, void **dptr);
+int msd_device_free(msd_handle h, void *dptr);
+int msd_copy_to_device(msd_handle h, void *dst, const void *src, unsigned long long bytes);
+int msd_copy_to_host(msd_handle h, void *dst, const void *src, unsigned long long bytes);
+/* HIP-event timing of everything enqueued on the handle's stream between begin and end (ms) */
+int msd_timer_begin(msd_handle h);
+int msd_timer_end(msd_handle h, float *ms);
+
+/*
+ * Replaces TrainIntegrator.solve (train.py:347-364) for `n` independent intervals: out[k][0..11] =
+ * {t+ - t, b+, d/db, d/dw of both, second derivatives (bb, bw, ww) of both}, w = Fel + Fpb.
+ */
+int msd_stage_eval(msd_handle h, int n, const double *b, const double *w, const double *ds, const double *grad,
+                   const double *curv, double *out12);
+
+/* per-iteration log of scenario 0 of the next msd_solve_batch call: 8 doubles per iteration
+ * (iter, objective, inf_pr, inf_du, lg(mu), |d|, alpha_du, alpha_pr); cap = number of rows. */
+int msd_set_history(msd_handle h, double *host_hist, int cap);
+
+const char *msd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

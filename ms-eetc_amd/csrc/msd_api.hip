@@ -1,0 +1,294 @@
+/*
+ * msd_api.hip -- host side of the C ABI declared in include/mseetc_hip.h.
+ *
+ * A handle owns: the problem record with the grid/profile arrays resident in HBM, one HIP stream,
+ * two HIP events, and grow-only device buffers for the host-buffer entry point.  Launch geometry:
+ * one workgroup of NT = roundup(N + 1, 64) threads per scenario, grid = min(nscen, resident workgroups)
+ * (workgroups stride through the batch), dynamic LDS = lds_doubles(N, NT) * 8 bytes.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "msd_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(MSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+using KernelFn = void (*)(msd::DevProb, int, const double *, double *, double *, double *, double *, int);
+
+KernelFn pick_kernel(int NT)
+{
+    switch (NT) {
+    case 64: return msd::solve_kernel<64>;
+    case 128: return msd::solve_kernel<128>;
+    case 192: return msd::solve_kernel<192>;
+    case 256: return msd::solve_kernel<256>;
+    case 320: return msd::solve_kernel<320>;
+    case 384: return msd::solve_kernel<384>;
+    case 448: return msd::solve_kernel<448>;
+    case 512: return msd::solve_kernel<512>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace
+
+struct msd_problem {
+    msd::DevProb P;
+    int device = 0;
+    int NT = 0;
+    size_t lds_bytes = 0;
+    int max_grid = 0;
+    KernelFn kernel = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr;
+    /* grow-only scratch of the host-buffer entry point */
+    double *d_scen = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr;
+    int cap_scen = 0;
+    double *h_hist = nullptr;
+    int hist_cap = 0;
+};
+
+extern "C" {
+
+const char *msd_last_error(void) { return g_err.c_str(); }
+
+int msd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
+{
+    if (!d || !out) return fail(MSD_E_INVALID, "null argument");
+    if (d->abi_version != MSD_ABI_VERSION) return fail(MSD_E_INVALID, "ABI version mismatch");
+    if (d->num_intervals < 1) return fail(MSD_E_INVALID, "Number of intervals must be a strictly positive integer!");
+    if (d->max_iterations < 1) return fail(MSD_E_INVALID, "Maximum number of iterations must be a strictly positive integer!");
+    if (d->num_steps < 1 || d->num_approx_steps < 0) return fail(MSD_E_INVALID, "bad integrator options");
+    if (!d->ds || !d->grad || !d->curv || !d->bmax) return fail(MSD_E_INVALID, "null profile array");
+    if (!(d->vmin_sq > 0) || !(d->obj_den > 0) || !(d->tol > 0)) return fail(MSD_E_INVALID, "vmin_sq, obj_den and tol must be positive");
+    if (d->loss_kind != 0 && d->loss_kind != 1) return fail(MSD_E_UNSUPPORTED, "loss model not available on the device");
+    for (int i = 0; i < d->num_intervals; i++)
+        if (!(d->ds[i] > 0)) return fail(MSD_E_INVALID, "interval lengths must be positive");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MSD_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(MSD_E_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    const int N = d->num_intervals;
+    const int NT = ((N + 1 + 63)/64)*64;
+    KernelFn k = pick_kernel(NT);
+    if (!k) return fail(MSD_E_UNSUPPORTED, "numIntervals > 511 is not supported by the stage-per-thread kernel");
+    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, NT);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (lds > (size_t)prop.maxSharedMemoryPerMultiProcessor && lds > 160*1024)
+        return fail(MSD_E_UNSUPPORTED, "problem does not fit the 160 KB of LDS of a compute unit");
+
+    msd_problem *h = new msd_problem();
+    h->device = device; h->NT = NT; h->lds_bytes = lds; h->kernel = k;
+    msd::DevProb &P = h->P;
+    P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
+    P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
+    P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
+    P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
+    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
+
+#define UPLOAD(dst, src, n)                                                                    \
+    do {                                                                                       \
+        if (hipMalloc((void **)&(dst), sizeof(double)*(n)) != hipSuccess ||                    \
+            hipMemcpy((dst), (src), sizeof(double)*(n), hipMemcpyHostToDevice) != hipSuccess) { \
+            msd_problem_destroy(h);                                                            \
+            return fail(MSD_E_HIP, "profile upload failed");                                   \
+        }                                                                                      \
+    } while (0)
+    UPLOAD(h->d_ds, d->ds, N); UPLOAD(h->d_grad, d->grad, N); UPLOAD(h->d_curv, d->curv, N); UPLOAD(h->d_bmax, d->bmax, N + 1);
+#undef UPLOAD
+    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax;
+
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        msd_problem_destroy(h);
+        return fail(MSD_E_HIP, "stream/event creation failed");
+    }
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        msd_problem_destroy(h);
+        return fail(MSD_E_HIP, "cannot reserve dynamic LDS");
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    h->max_grid = per_cu*prop.multiProcessorCount;
+    *out = h;
+    return MSD_OK;
+}
+
+int msd_problem_destroy(msd_handle h)
+{
+    if (!h) return MSD_OK;
+    hipSetDevice(h->device);
+    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax);
+    hipFree(h->d_scen); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MSD_OK;
+}
+
+int msd_problem_nz(msd_handle h) { return h ? (4 + h->P.withPn)*h->P.N + 2 : 0; }
+int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 : 0) + 3 + (h->P.energyOpt ? 2 : 0) : 0; }
+
+static int launch(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap)
+{
+    const int grid = nscen < h->max_grid ? nscen : h->max_grid;
+    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, h->P, nscen, d_scen, d_z, d_lam, d_stats, d_hist, hist_cap);
+    HIP_TRY(hipGetLastError());
+    return MSD_OK;
+}
+
+int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats)
+{
+    if (!h || nscen < 1 || !d_scen || !d_z || !d_stats) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch(h, nscen, d_scen, d_z, d_lam, d_stats, nullptr, 0);
+}
+
+int msd_synchronize(msd_handle h)
+{
+    if (!h) return fail(MSD_E_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MSD_OK;
+}
+
+int msd_set_history(msd_handle h, double *host_hist, int cap)
+{
+    if (!h) return fail(MSD_E_INVALID, "null handle");
+    h->h_hist = host_hist; h->hist_cap = host_hist ? cap : 0;
+    return MSD_OK;
+}
+
+int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
+    if (!h || nscen < 1 || !scen || !z_out || !stats) return fail(MSD_E_INVALID, "bad argument");
+    for (int k = 0; k < nscen; k++) {
+        const double *s = scen + (size_t)MSD_SC_COUNT*k;
+        if (!(s[MSD_SC_T0] >= 0)) return fail(MSD_E_INVALID, "Initial time must be a positive number!");
+        if (!(s[MSD_SC_TEND] > 0)) return fail(MSD_E_INVALID, "Terminal time must be a strictly positive number!");
+        if (!(s[MSD_SC_V0SQ] > 0) || !(s[MSD_SC_VNSQ] > 0)) return fail(MSD_E_INVALID, "velocities must be positive");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
+    if (nscen > h->cap_scen) {
+        hipFree(h->d_scen); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats);
+        h->d_scen = h->d_z = h->d_lam = h->d_stats = nullptr; h->cap_scen = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_scen, sizeof(double)*MSD_SC_COUNT*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_z, sizeof(double)*nz*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_lam, sizeof(double)*nl*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen));
+        h->cap_scen = nscen;
+    }
+    double *d_hist = nullptr;
+    if (h->h_hist && h->hist_cap > 0) {
+        hipFree(h->d_hist); h->d_hist = nullptr;
+        HIP_TRY(hipMalloc((void **)&h->d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap));
+        HIP_TRY(hipMemsetAsync(h->d_hist, 0, sizeof(double)*msd::HIST_COLS*h->hist_cap, h->stream));
+        d_hist = h->d_hist;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_scen, scen, sizeof(double)*MSD_SC_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    int rc = launch(h, nscen, h->d_scen, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap);
+    if (rc != MSD_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));
+    if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
+    if (d_hist) HIP_TRY(hipMemcpyAsync(h->h_hist, d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    return MSD_OK;
+}
+
+int msd_device_alloc(msd_handle h, unsigned long long bytes, void **dptr)
+{
+    if (!h || !dptr) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMalloc(dptr, bytes));
+    return MSD_OK;
+}
+int msd_device_free(msd_handle h, void *dptr)
+{
+    if (!h) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipFree(dptr));
+    return MSD_OK;
+}
+int msd_copy_to_device(msd_handle h, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!h) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MSD_OK;
+}
+int msd_copy_to_host(msd_handle h, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!h) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MSD_OK;
+}
+int msd_timer_begin(msd_handle h)
+{
+    if (!h) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return MSD_OK;
+}
+int msd_timer_end(msd_handle h, float *ms)
+{
+    if (!h || !ms) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MSD_OK;
+}
+
+int msd_stage_eval(msd_handle h, int n, const double *b, const double *w, const double *ds, const double *grad, const double *curv, double *out12)
+{
+    if (!h || n < 1 || !b || !w || !ds || !grad || !curv || !out12) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, sizeof(double)*5*n));
+    if (hipMalloc((void **)&d_out, sizeof(double)*12*n) != hipSuccess) { hipFree(d_in); return fail(MSD_E_HIP, "hipMalloc failed"); }
+    const double *src[5] = {b, w, ds, grad, curv};
+    for (int k = 0; k < 5; k++) hipMemcpyAsync(d_in + (size_t)k*n, src[k], sizeof(double)*n, hipMemcpyHostToDevice, h->stream);
+    hipLaunchKernelGGL(msd::stage_eval_kernel, dim3((n + 255)/256), dim3(256), 0, h->stream, h->P, n, d_in, d_in + n, d_in + 2*(size_t)n, d_in + 3*(size_t)n,
+                       d_in + 4*(size_t)n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out12, d_out, sizeof(double)*12*n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_in); hipFree(d_out);
+    if (e != hipSuccess) return fail(MSD_E_HIP, hipGetErrorString(e));
+    return MSD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""
+ctypes binding of the HIP solver library (C ABI: include/mseetc_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible,
+every entry point raises.  The library is built in-tree by `__graft_entry__.build()`
+(hipcc --offload-arch=gfx950) as ms-eetc_amd/lib/libmseetc_hip.so.
+"""
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'
+
+ABI_VERSION = 1
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, COUNT=11)
+SC_COUNT = 4
+HIST_COLS = 8
+
+STATUS_TEXT = {0: 'Solve_Succeeded', 1: 'Solved_To_Acceptable_Level', -1: 'Maximum_Iterations_Exceeded',
+               -2: 'Restoration_Failed', -3: 'Error_In_Step_Computation', -4: 'Invalid_Number_Detected',
+               -5: 'Search_Direction_Becomes_Too_Small'}
+
+_dptr = ctypes.POINTER(ctypes.c_double)
+
+
+class ProblemDesc(ctypes.Structure):
+    "struct msd_problem_desc"
+
+    _fields_ = [('abi_version', ctypes.c_int), ('num_intervals', ctypes.c_int), ('with_pn_brake', ctypes.c_int),
+                ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
+                ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
+                ('reserved_i', ctypes.c_int*7),
+                ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
+                ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
+                ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
+                ('loss_ct', ctypes.c_double), ('loss_cr', ctypes.c_double), ('vmin_sq', ctypes.c_double), ('obj_den', ctypes.c_double),
+                ('tol', ctypes.c_double), ('reserved_d', ctypes.c_double*7),
+                ('ds', _dptr), ('grad', _dptr), ('curv', _dptr), ('bmax', _dptr)]
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    "Load the HIP library; raises DeviceError when it has not been built."
+
+    global _lib
+
+    if _lib is None:
+
+        if not LIB_PATH.exists():
+            raise DeviceError("HIP solver library {} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc, gfx950). There is no CPU fallback.".format(LIB_PATH))
+
+        L = ctypes.CDLL(str(LIB_PATH))
+        vp = ctypes.c_void_p
+
+        L.msd_last_error.restype = ctypes.c_char_p
+        L.msd_device_count.restype = ctypes.c_int
+        L.msd_problem_create.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, ctypes.POINTER(vp)]
+        L.msd_problem_destroy.argtypes = [vp]
+        L.msd_problem_nz.argtypes = [vp]
+        L.msd_problem_rows_per_interval.argtypes = [vp]
+        L.msd_solve_batch.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
+        L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
+        L.msd_synchronize.argtypes = [vp]
+        L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
+        L.msd_device_free.argtypes = [vp, vp]
+        L.msd_copy_to_device.argtypes = [vp, vp, vp, ctypes.c_ulonglong]
+        L.msd_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_ulonglong]
+        L.msd_timer_begin.argtypes = [vp]
+        L.msd_timer_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.msd_stage_eval.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, _dptr]
+        L.msd_set_history.argtypes = [vp, _dptr, ctypes.c_int]
+
+        _lib = L
+
+    return _lib
+
+
+def _check(rc):
+
+    if rc != 0:
+        msg = lib().msd_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise DeviceError("msd error {}: {}".format(rc, msg))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dptr)
+
+
+def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
+              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax):
+    "Fill a ProblemDesc; the numpy arrays are kept alive on the returned object."
+
+    d = ProblemDesc()
+    d.abi_version = ABI_VERSION
+    d.num_intervals, d.with_pn_brake, d.has_power_rows, d.energy_optimal = int(N), int(withPn), int(hasPower), int(energyOptimal)
+    d.num_steps, d.num_approx_steps, d.loss_kind, d.max_iterations = int(numSteps), int(numApproxSteps), int(lossKind), int(maxIterations)
+    d.sr0, d.sr1, d.sr2 = sr
+    d.g, d.rho = g, rho
+    d.f_max, d.f_min, d.f_min_pn = fmax, fmin, fminPn
+    d.pw_upper, d.pw_lower, d.acc_min, d.acc_max = pwUpper, pwLower, accMin, accMax
+    d.loss_ct, d.loss_cr, d.vmin_sq, d.obj_den, d.tol = ct, cr, vminSq, objDen, tol
+    keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (ds, grad, curv, bmax)]
+    d.ds, d.grad, d.curv, d.bmax = [_d(a) for a in keep]
+    d._keep = keep
+
+    return d
+
+
+class DeviceProblem():
+    "Owner of an msd_handle."
+
+    def __init__(self, desc, device=0):
+
+        L = lib()
+        self._h = ctypes.c_void_p()
+        self.desc = desc
+        _check(L.msd_problem_create(ctypes.byref(desc), int(device), ctypes.byref(self._h)))
+        self.N = desc.num_intervals
+        self.nz = L.msd_problem_nz(self._h)
+        self.rowsPerInterval = L.msd_problem_rows_per_interval(self._h)
+        self.device = device
+
+    def close(self):
+
+        if getattr(self, '_h', None):
+            lib().msd_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve_batch(self, scen, want_multipliers=False, history=0):
+        "scen: (B,4) host array (t0, T, v0sq, vNsq) -> dict(z, stats, lam_g, kernel_ms[, hist])"
+
+        L = lib()
+        scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
+        B = scen.shape[0]
+        z = np.zeros((B, self.nz))
+        st = np.zeros((B, ST['COUNT']))
+        lam = np.zeros((B, self.rowsPerInterval*self.N)) if want_multipliers else None
+        ms = ctypes.c_float(0)
+        hist = None
+
+        if history:
+            hist = np.zeros((int(history), HIST_COLS))
+            _check(L.msd_set_history(self._h, _d(hist), int(history)))
+
+        _check(L.msd_solve_batch(self._h, B, _d(scen), _d(z), _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+
+        out = dict(z=z, stats=st, lam_g=lam, kernel_ms=float(ms.value))
+
+        if history:
+            L.msd_set_history(self._h, None, 0)
+            out['hist'] = hist[:int(st[0, ST['ITERS']]) + 1]
+
+        return out
+
+    # ---- device-resident path (benchmark) ------------------------------------------------
+
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(lib().msd_device_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p
+
+    def free(self, p):
+        _check(lib().msd_device_free(self._h, p))
+
+    def to_device(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().msd_copy_to_device(self._h, dptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def to_host(self, arr, dptr):
+        _check(lib().msd_copy_to_host(self._h, arr.ctypes.data_as(ctypes.c_void_p), dptr, arr.nbytes))
+
+    def solve_batch_device(self, B, d_scen, d_z, d_lam, d_stats):
+        _check(lib().msd_solve_batch_device(self._h, int(B), d_scen, d_z, d_lam, d_stats))
+
+    def synchronize(self):
+        _check(lib().msd_synchronize(self._h))
+
+    def timer_begin(self):
+        _check(lib().msd_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_float(0)
+        _check(lib().msd_timer_end(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def stage_eval(self, b, w, ds, grad, curv):
+        arrs = [np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64) for a in (b, w, ds, grad, curv)]
+        n = len(arrs[0])
+        out = np.zeros((n, 12))
+        _check(lib().msd_stage_eval(self._h, n, *[_d(a) for a in arrs], _d(out)))
+        return out
+
+
+def stage_eval(model, optsRK, time, velocitySquared, ds, force, gradient, curvature):
+    "TrainIntegrator.solve on the device for arrays of intervals (train.py:347-364)."
+
+    n = len(np.atleast_1d(velocitySquared))
+    one = np.ones(1)
+    desc = make_desc(1, model.withPnBrake, False, True, optsRK.numSteps, optsRK.numApproxSteps, 0, 1, (model.sr0, model.sr1, model.sr2),
+                     model.g, model.rho, 1.0, -1.0, -1.0, 0.0, 0.0, -1.0, 1.0, 0.0, 0.0, 1.0, 1.0, 1e-8, one, 0*one, 0*one, np.ones(2))
+    prob = DeviceProblem(desc)
+
+    try:
+        out = prob.stage_eval(velocitySquared, force, ds, gradient, curvature)
+    finally:
+        prob.close()
+
+    return {'time': np.atleast_1d(np.asarray(time, dtype=float)) + out[:, 0], 'velSquared': out[:, 1], 'sens': out}

@@ -1,0 +1,268 @@
+"""
+Optimal-control front end of the MI355X solver: same surface as the reference's
+`mseetc/ocp.py` (`OptionsCasadiSolver` :12-74, `casadiSolver` :77-409) -- but the NLP is
+not built symbolically and handed to IPOPT; `__init__` packs the problem data that the
+reference's transcription is made of (ocp.py:96-125, 166-284) into the C-ABI record of
+include/mseetc_hip.h and `solve` / `solveBatch` run the HIP interior-point kernels
+(csrc/msd_kernel.hpp), one workgroup per scenario.
+
+`solveBatch` is the addition that makes the device worth using: many (T, t0, v0, vN)
+scenarios of the same (train, track, options) in one launch.
+"""
+
+import numpy as np
+import pandas as pd
+
+from .train import OptionsRK, OptionsIRK, OptionsCVODES
+from .track import computeDiscretizationPoints
+from .utils import Options, classifyLosses, postProcessDataFrame, LOSS_NONE
+from . import _device
+
+
+class OptionsCasadiSolver(Options):
+
+    def __init__(self, paramsDict):
+
+        self.numIntervals = 100  # number of shooting intervals with piece-wise constant controls [-]
+
+        self.maxIterations = 1e3  # maximum number of interior-point iterations
+
+        self.energyOptimal = True  # False means time optimal, True energy optimal
+
+        self.minimumVelocity = 1  # lower bound on velocity [m/s]
+
+        self.integrationMethod = 'RK'  # 'RK', 'IRK' or 'CVODES' (only 'RK' runs on the device)
+
+        self.integrationOptions = {}  # method-dependent integration options
+
+        self.integrateLosses = False  # integrate losses or take mid-point rule
+
+        super().__init__(paramsDict)
+
+    def overwriteDefaults(self, paramsDict):
+
+        super().overwriteDefaults(paramsDict)
+
+        nested = paramsDict['integrationOptions'] if 'integrationOptions' in paramsDict else {}
+
+        if self.integrationMethod == 'RK':
+            self.integrationOptions = OptionsRK(nested)
+
+        elif self.integrationMethod == 'IRK':
+            self.integrationOptions = OptionsIRK(nested)
+
+        elif self.integrationMethod == 'CVODES':
+            self.integrationOptions = OptionsCVODES(nested)
+
+    def checkValues(self):
+
+        self.checkPositiveInteger(self.numIntervals, 'Number of intervals', allowZero=False)
+
+        self.checkPositiveInteger(self.maxIterations, 'Maximum number of iterations', allowZero=False)
+
+        if not isinstance(self.energyOptimal, bool):
+            raise ValueError("'energyOptimal' flag must be a boolean!")
+
+        if type(self.minimumVelocity) not in {int, float} or self.minimumVelocity <= 0:
+            raise ValueError("Minimum velocity should be a strictly positive number!")
+
+        if self.integrationMethod not in {'RK', 'IRK', 'CVODES'}:
+            raise ValueError("Unknown integration method!")
+
+        if not isinstance(self.integrateLosses, bool):
+            raise ValueError("'integrateLosses' flag must be a boolean!")
+
+
+class casadiSolver():
+    "Batched multiple-shooting NLP solver on the GPU (name kept from the reference for drop-in use)."
+
+    TOLERANCE = 1e-8   # IPOPT default `tol`; the reference passes only max_iter (ocp.py:290)
+
+    def __init__(self, train, track, optsDict={}, device=0):
+
+        track.checkFields()
+        train.checkFields()
+
+        opts = OptionsCasadiSolver(optsDict)
+
+        if opts.integrationMethod != 'RK':
+            raise NotImplementedError("Only the explicit Runge-Kutta transcription runs on the device.")
+
+        if opts.integrateLosses:
+            raise NotImplementedError("integrateLosses=True is outside the device hot path.")
+
+        N = int(opts.numIntervals)
+
+        # train parameters per kg of total mass (ocp.py:96-116)
+        rho = train.rho
+        totalMass = train.mass*rho
+
+        withRgBrake = train.forceMin != 0
+        withPnBrake = train.forceMinPn != 0
+
+        accInf = 10  # acceleration bound when a limit is not defined
+
+        forceMax = train.forceMax/totalMass if train.forceMax is not None else accInf
+        forceMin = train.forceMin/totalMass if train.forceMin is not None else -accInf
+        forceMinPn = train.forceMinPn/totalMass if train.forceMinPn is not None else -accInf
+
+        powerMax = train.powerMax/totalMass if train.powerMax is not None else None
+        powerMin = train.powerMin/totalMass if train.powerMin is not None else None
+
+        accMax = min(accInf, train.accMax if train.accMax is not None else accInf)
+        accMin = max(-accInf, -abs(train.accMin) if train.accMin is not None else -accInf)
+
+        hasPower = powerMax is not None or powerMin is not None
+
+        if hasPower:   # ocp.py:186-187
+            pwUpper = powerMax if powerMax is not None else forceMax*train.velocityMax
+            pwLower = 0 if not withRgBrake else powerMin if powerMin is not None else forceMin*train.velocityMax
+        else:
+            pwUpper = pwLower = 0.0
+
+        # loss model -> slack rows (ocp.py:99, 225-226)
+        if opts.energyOptimal:
+            lossKind, ct, cr = classifyLosses(train.lossesCallable())
+        else:
+            lossKind, ct, cr = LOSS_NONE, 0.0, 0.0
+
+        # shooting grid and profile on it (ocp.py:124-125, 195-196, 266-269)
+        self.points = computeDiscretizationPoints(track, N)
+        self.steps = np.diff(self.points.index)
+
+        vlim = self.points['Speed limit [m/s]'].values
+        bmax = np.zeros(N + 1)
+        bmax[1:N] = np.minimum(np.minimum(vlim[1:N], train.velocityMax), vlim[0:N - 1])**2
+
+        scaling = 3.6/(1e-6*totalMass) if opts.energyOptimal else track.length/train.velocityMax   # ocp.py:278,282
+
+        model = train.exportModel()
+        io = opts.integrationOptions
+
+        self._desc = _device.make_desc(
+            N, withPnBrake, hasPower, opts.energyOptimal, io.numSteps, io.numApproxSteps, lossKind, int(opts.maxIterations),
+            (model.sr0, model.sr1, model.sr2), train.g, rho, forceMax, forceMin if withRgBrake else 0.0, forceMinPn,
+            abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
+            self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax)
+
+        self._device = device
+        self._problem = None   # created on first use: construction stays possible on a machine without GPU
+
+        self.totalMass = totalMass
+        self.velocityMin = opts.minimumVelocity
+        self.numIntervals = N
+        self.withRgBrake = withRgBrake
+        self.withPnBrake = withPnBrake
+        self.train = train
+        self.energyOptimal = opts.energyOptimal
+        self.scalingFactorObjective = scaling
+        self.opts = opts
+
+    # ---- device problem ---------------------------------------------------------------
+
+    @property
+    def problem(self):
+
+        if self._problem is None:
+            self._problem = _device.DeviceProblem(self._desc, self._device)
+
+        return self._problem
+
+    def close(self):
+
+        if self._problem is not None:
+            self._problem.close()
+            self._problem = None
+
+    # ---- scenarios --------------------------------------------------------------------------
+
+    def _scenarios(self, terminalTime, initialTime, terminalVelocity, initialVelocity):
+        "(B,4) records (t0, T, v0^2, vN^2) with the reference's checks and clipping (ocp.py:314-320, 343-344)."
+
+        T, t0, vN, v0 = np.broadcast_arrays(*[np.atleast_1d(np.asarray(a, dtype=float)) for a in
+                                               (terminalTime, initialTime, terminalVelocity, initialVelocity)])
+
+        if np.any(~np.isfinite(t0)) or np.any(t0 < 0):
+            raise ValueError("Initial time must be a positive number, not {}!".format(initialTime))
+
+        if np.any(~np.isfinite(T)) or np.any(T <= 0):
+            raise ValueError("Terminal time must be a strictly positive number, not {}!".format(terminalTime))
+
+        vlim = self.points['Speed limit [m/s]'].values
+
+        v0 = np.minimum(np.maximum(v0, self.velocityMin), vlim[0])
+        vN = np.minimum(np.maximum(vN, self.velocityMin), vlim[-1])
+
+        return np.stack([t0, T, v0**2, vN**2], axis=1)
+
+    def solveBatch(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1, multipliers=False):
+        """
+        Solve many scenarios of this problem in one launch.  Arguments broadcast against each other.
+        Returns dict: 'z' (B, nz) in the reference's variable layout, 'status' (B,), 'iterations' (B,), 'cost' (B,)
+        [kWh or s], 'stats' (raw records), 'kernel_ms', optionally 'lam_g'.
+        """
+
+        scen = self._scenarios(terminalTime, initialTime, terminalVelocity, initialVelocity)
+
+        out = self.problem.solve_batch(scen, want_multipliers=multipliers)
+
+        st = out['stats']
+        ST = _device.ST
+        cost = st[:, ST['OBJ']]*(1.0 if self.energyOptimal else self.scalingFactorObjective)   # ocp.py:361
+
+        return dict(z=out['z'], status=st[:, ST['STATUS']].astype(int), iterations=st[:, ST['ITERS']].astype(int), cost=cost,
+                    stats=st, kernel_ms=out['kernel_ms'], lam_g=out['lam_g'], scenarios=scen)
+
+    def unpack(self, z):
+        "z (reference layout, ocp.py:376-405) -> DataFrame indexed by time."
+
+        N = self.numIntervals
+        stp = 4 + int(self.withPnBrake)
+        body = np.asarray(z[:stp*N]).reshape(N, stp)
+        pn = int(self.withPnBrake)
+
+        nan = np.array([np.nan])
+        Fel = np.concatenate([body[:, 0], nan])
+        Fpb = np.concatenate([body[:, 1], nan]) if pn else np.zeros(N + 1)
+        s = np.concatenate([body[:, 1 + pn], nan])
+        t = np.concatenate([body[:, 2 + pn], [z[stp*N]]])
+        b = np.concatenate([body[:, 3 + pn], [z[stp*N + 1]]])
+
+        df = pd.DataFrame({'Time [s]': t, 'Position [m]': self.points.index.values}).set_index('Time [s]')
+        df['Velocity [m/s]'] = np.sqrt(b)
+        df['Force (el) [N]'] = Fel*self.totalMass
+        df['Force (pnb) [N]'] = Fpb*self.totalMass
+        df['Slacks'] = s*self.totalMass
+
+        return df
+
+    def solve(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1):
+        "One scenario; returns (DataFrame or None, stats) like the reference (ocp.py:310-409)."
+
+        if not isinstance(initialTime, (int, float)) or initialTime < 0:
+            raise ValueError("Initial time must be a positive number, not {}!".format(initialTime))
+
+        if not isinstance(terminalTime, (int, float)) or terminalTime <= 0:
+            raise ValueError("Terminal time must be a strictly positive number, not {}!".format(terminalTime))
+
+        res = self.solveBatch(terminalTime, initialTime, terminalVelocity, initialVelocity)
+
+        status = int(res['status'][0])
+
+        stats = {'Solver status': _device.STATUS_TEXT.get(status, str(status)), 'IP iterations': int(res['iterations'][0]),
+                 'CPU time [s]': res['kernel_ms']*1e-3, 'Cost': float(res['cost'][0])}
+
+        if status < 0:
+
+            print("Solver failed with status '{}'".format(stats['Solver status']))
+
+            return None, stats
+
+        print("Solver converged in {:4d} iterations.".format(stats['IP iterations']))
+
+        df = postProcessDataFrame(self.unpack(res['z'][0]), self.points, self.train)
+
+        return df, stats
+
+
+OCP = casadiSolver   # BASELINE.json's north_star calls the class OCP; the reference's name is casadiSolver (ocp.py:77)

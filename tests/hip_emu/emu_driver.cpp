@@ -1,0 +1,55 @@
+/*
+ * TEST-ONLY driver: runs msd::solve_kernel<NT> from ms-eetc_amd/csrc/msd_kernel.hpp on host threads
+ * (see hip/hip_runtime.h in this directory).  Build: tests/hip_emu/build.sh.  Used by
+ * tests/test_kernel_emulation.py to compare the kernel's logic with the oracle without a GPU.
+ */
+#include <hip/hip_runtime.h>
+
+#include <thread>
+#include <vector>
+
+#include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
+
+thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+thread_local emu_block *emu_blk;
+
+template <int NT>
+static void run_blocks(msd::DevProb P, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
+{
+    for (int b = 0; b < nscen; b++) {
+        emu_block blk;
+        blk.nthreads = NT;
+        pthread_barrier_init(&blk.bar, nullptr, NT);
+        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT));
+        blk.shfl = shfl.data(); blk.lds = lds.data();
+        std::vector<std::thread> th;
+        for (int t = 0; t < NT; t++)
+            th.emplace_back([&, t]() {
+                threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
+                emu_blk = &blk;
+                msd::solve_kernel<NT>(P, nscen, scen, z, lam, stats, hist, cap);
+            });
+        for (auto &t : th) t.join();
+        pthread_barrier_destroy(&blk.bar);
+    }
+}
+
+extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
+{
+    msd::DevProb P;
+    P.N = d->num_intervals; P.withPn = d->with_pn_brake; P.hasPower = d->has_power_rows; P.energyOpt = d->energy_optimal;
+    P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
+    P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
+    P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
+    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax;
+    int NT = ((P.N + 1 + 63)/64)*64;
+    switch (NT) {
+    case 64: run_blocks<64>(P, nscen, scen, z, lam, stats, hist, cap); break;
+    case 128: run_blocks<128>(P, nscen, scen, z, lam, stats, hist, cap); break;
+    case 192: run_blocks<192>(P, nscen, scen, z, lam, stats, hist, cap); break;
+    case 256: run_blocks<256>(P, nscen, scen, z, lam, stats, hist, cap); break;
+    case 320: run_blocks<320>(P, nscen, scen, z, lam, stats, hist, cap); break;
+    default: return -3;
+    }
+    return 0;
+}

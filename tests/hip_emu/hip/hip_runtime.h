@@ -1,0 +1,50 @@
+/*
+ * TEST-ONLY stand-in for <hip/hip_runtime.h>: lets g++ compile the device header
+ * ms-eetc_amd/csrc/msd_kernel.hpp and run one workgroup as NT host threads, so that the kernel's
+ * control flow can be debugged and run under AddressSanitizer/UBSan in a container without a GPU
+ * (GPU sanitizers are not available on the pool).  It is never part of the product: the shipped
+ * library is built by hipcc from the same header with the real HIP runtime, and nothing in
+ * ms-eetc_amd/ references this directory.  Only what the kernel uses is provided.
+ */
+#pragma once
+
+#include <pthread.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __launch_bounds__(...)
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+
+struct emu_dim3 { unsigned x, y, z; };
+
+struct emu_block {
+    pthread_barrier_t bar;
+    unsigned nthreads;
+    double *shfl;          /* nthreads doubles */
+    void *lds;
+};
+
+extern thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local emu_block *emu_blk;
+
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)emu_blk->lds;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu_blk->bar); }
+
+/* wave64 butterfly: every thread of the block calls it (the kernel only shuffles in block-wide reductions) */
+static inline double __shfl_xor(double v, int mask)
+{
+    emu_blk->shfl[threadIdx.x] = v;
+    pthread_barrier_wait(&emu_blk->bar);
+    double r = emu_blk->shfl[threadIdx.x ^ (unsigned)mask];
+    pthread_barrier_wait(&emu_blk->bar);
+    return r;
+}
+
+using std::isfinite;
