@@ -161,12 +161,14 @@ def main():
             from oracle import oracle
             oprob = cases.oracle_problem(train, track, N)
             ncores = os.cpu_count() or 1
-            sample = min(B, 1024)
+            reps = max(1, int(np.ceil(16*ncores/B)))          # ~10-30 s of CPU work: at least 16 solves per core
+            sc = np.tile(scen, (reps, 1))
+            sample = sc.shape[0]
             t1 = time.perf_counter()
-            zc, stc, nfail = oracle.solve_batch(oprob, scen[:sample], nthreads=ncores)
+            zc, stc, nfail = oracle.solve_batch(oprob, sc, nthreads=ncores)
             dt = time.perf_counter() - t1
             line["cpu_baseline"] = {"value": sample/dt, "unit": "solves/s", "cores": ncores, "kind": "port",
-                                    "sample": "first {} scenarios of the same batch, CPU oracle (oracle/ms_oracle.c, same algorithm, gcc -O2, OpenMP over scenarios), {:.1f} s wall, {} failed".format(sample, dt, nfail)}
+                                    "sample": "{} solves (the same batch, repeated), CPU oracle (oracle/ms_oracle.c, same algorithm, gcc -O2, OpenMP over scenarios), {:.1f} s wall, {} failed".format(sample, dt, nfail)}
 
         print(json.dumps(line), flush=True)
 

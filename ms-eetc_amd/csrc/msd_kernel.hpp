@@ -952,14 +952,13 @@ struct Solver {
             double gphid, rel_step;
             {
                 double gd = 0, dn = 0, rel = 0;
+                double of = 0, op = 0, os = 0, oq = 0, off = 0, opp = 0;
+                if (n.i <= N) obj_grads(nb_q(), of, op, os, oq, off, opp);
+                /* d(obj)/dq of the next interval belongs to this node's f (barrier in uniform control flow) */
+                c.o1[c.tid] = oq;
+                __syncthreads();
                 if (n.i <= N) {
-                    const double q = nb_q();
-                    double of, op, os, oq, off, opp;
-                    obj_grads(q, of, op, os, oq, off, opp);
                     double og[NV] = {(n.i == N && !P.energyOpt) ? sf/P.objDen : 0.0, 0.0, of, op, os};
-                    /* d(obj)/dq of the next interval belongs to this node's f */
-                    c.o1[c.tid] = oq;
-                    __syncthreads();
                     if (n.i + 1 < N) og[VF] += c.o1[c.tid + 1];
 #pragma unroll
                     for (int k = 0; k < NV; k++) {
@@ -977,7 +976,7 @@ struct Solver {
                             dn = fmax(dn, fabs(n.dsg[r])); rel = fmax(rel, fabs(n.dsg[r])/(1 + fabs(n.sg[r])));
                         }
                     }
-                } else { c.o1[c.tid] = 0; __syncthreads(); }
+                }
                 double v1[1] = {gd}; block_reduce<1>(v1, OpSum(), c);
                 double v2[2] = {dn, rel}; block_reduce<2>(v2, OpMax(), c);
                 gphid = v1[0]; dnorm = v2[0]; rel_step = v2[1];
