@@ -151,10 +151,11 @@ def main():
             "config": {"workload": "config 1: B={} scenarios per GPU, N={}, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 (JSON defaults, both brakes), "
                                    "RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1541(1+0.15u_i) seed 20260612+rank, cold start, KKT<=1e-8".format(B, N),
                        "batch_per_gpu": B, "num_intervals": N, "converged": n_ok_all, "scenarios": B*world,
+                       "kkt_cycle_share": float(np.sum(st[:, ST['CYC_KKT']])/max(1.0, np.sum(st[:, ST['CYC_TOTAL']]))), "cycles_per_solve_mean": float(np.mean(st[:, ST['CYC_TOTAL']])),
                        "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)), "parallelism": "scenarios sharded, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
                          "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d); iterate is LDS/register resident, so real HBM traffic is far below S",
-                         "kernel": "msd::solve_kernel<128>", "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters},
+                         "kernel": "msd::solve_kernel<64,2,1> (one wave per scenario, two shooting nodes per lane)", "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters},
         }
 
         if not args.no_cpu_baseline and world == 1:

@@ -48,6 +48,8 @@ enum {
     MSD_ST_MU,
     MSD_ST_DUAL_INF, MSD_ST_CONSTR_VIOL, MSD_ST_COMPL,
     MSD_ST_N_REG, MSD_ST_N_SOC, MSD_ST_N_BACKTRACK,
+    MSD_ST_CYC_TOTAL,    /* shader clock cycles the scenario's workgroup spent in the solve (telemetry)       */
+    MSD_ST_CYC_KKT,      /* ... of which inside the serial stage recursion of the KKT solves                 */
     MSD_ST_COUNT
 };
 

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -29,19 +30,22 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 using KernelFn = void (*)(msd::DevProb, int, const double *, double *, double *, double *, double *, int);
 
-KernelFn pick_kernel(int NT)
+/* launch geometry by horizon length: NT threads, SPT shooting nodes per thread (NT*SPT >= N + 1) */
+struct Geometry { int NT, SPT; KernelFn fn; };
+
+Geometry pick_geometry(int N)
 {
-    switch (NT) {
-    case 64: return msd::solve_kernel<64>;
-    case 128: return msd::solve_kernel<128>;
-    case 192: return msd::solve_kernel<192>;
-    case 256: return msd::solve_kernel<256>;
-    case 320: return msd::solve_kernel<320>;
-    case 384: return msd::solve_kernel<384>;
-    case 448: return msd::solve_kernel<448>;
-    case 512: return msd::solve_kernel<512>;
-    default: return nullptr;
-    }
+    const int nodes = N + 1;
+    /* MSD_GEOMETRY=128x1 selects the one-node-per-thread variant (tuning experiments only) */
+    const char *g = getenv("MSD_GEOMETRY");
+    if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, msd::solve_kernel<128, 1, 2>};
+    if (nodes <= 64) return {64, 1, msd::solve_kernel<64, 1, 1>};
+    if (nodes <= 128) return {64, 2, msd::solve_kernel<64, 2, 1>};     /* one wave per scenario, one wave per SIMD */
+    if (nodes <= 256) return {128, 2, msd::solve_kernel<128, 2, 1>};
+    if (nodes <= 384) return {192, 2, msd::solve_kernel<192, 2, 1>};
+    if (nodes <= 512) return {256, 2, msd::solve_kernel<256, 2, 1>};
+    if (nodes <= 640) return {320, 2, msd::solve_kernel<320, 2, 2>};
+    return {0, 0, nullptr};
 }
 
 }  // namespace
@@ -93,13 +97,14 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     HIP_TRY(hipSetDevice(device));
 
     const int N = d->num_intervals;
-    const int NT = ((N + 1 + 63)/64)*64;
-    KernelFn k = pick_kernel(NT);
-    if (!k) return fail(MSD_E_UNSUPPORTED, "numIntervals > 511 is not supported by the stage-per-thread kernel");
-    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, NT);
+    const Geometry geo = pick_geometry(N);
+    KernelFn k = geo.fn;
+    if (!k) return fail(MSD_E_UNSUPPORTED, "numIntervals > 639 is not supported by the LDS-resident kernel");
+    const int NT = geo.NT;
+    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (lds > (size_t)prop.maxSharedMemoryPerMultiProcessor && lds > 160*1024)
+    if (lds > 160*1024)
         return fail(MSD_E_UNSUPPORTED, "problem does not fit the 160 KB of LDS of a compute unit");
 
     msd_problem *h = new msd_problem();

@@ -35,6 +35,19 @@
 
 #include "../../include/mseetc_hip.h"
 
+/* build-time tuning switches (defaults = what measured fastest on MI355X) */
+#ifndef MSD_PHASE_FENCE
+#define MSD_PHASE_FENCE 1
+#endif
+#ifndef MSD_RICCATI_INLINE
+#define MSD_RICCATI_INLINE 1
+#endif
+#if MSD_RICCATI_INLINE
+#define MSD_RICCATI_ATTR __forceinline__
+#else
+#define MSD_RICCATI_ATTR __noinline__
+#endif
+
 namespace msd {
 
 struct DevProb {
@@ -75,7 +88,7 @@ constexpr int S_DT = 6, S_DB = 7, S_DF = 8, S_DP = 9, S_DS = 10, S_LT = 11, S_LB
 
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NT)
 {
-    return S_STRIDE*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 16;
+    return S_STRIDE*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -167,8 +180,19 @@ __device__ __forceinline__ double track_resistance(const DevProb &P, double grad
  * ---------------------------------------------------------------------------------------- */
 struct Ctx {
     double *S, *xt, *xb, *xf, *o1, *o2, *o3, *filt, *red, *misc;
-    int tid, lane, wave, nw, red_slot;
+    int tid, lane, wave, nw, nt, red_slot;
+    unsigned long long tmark;
+    /* telemetry: thread 0 accumulates the shader cycles spent since the previous mark into misc[2 + phase] */
+    __device__ __forceinline__ void mark(int phase)
+    {
+        if (tid == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            misc[2 + phase] += (double)(t - tmark);
+            tmark = t;
+        }
+    }
 };
+enum { PH_EVAL = 0, PH_KKT, PH_ASSEMBLE, PH_RICCATI, PH_READBACK, PH_GPHID, PH_STEPLEN, PH_MERIT, PH_UPDATE, PH_OTHER, PH_COUNT };
 
 struct OpMax { __device__ double operator()(double a, double b) const { return fmax(a, b); } };
 struct OpMin { __device__ double operator()(double a, double b) const { return fmin(a, b); } };
@@ -182,6 +206,7 @@ template <int K, class Op> __device__ __forceinline__ void block_reduce(double (
         for (int off = 32; off >= 1; off >>= 1) x = op(x, __shfl_xor(x, off));
         v[k] = x;
     }
+    if (c.nw == 1) return;         /* one wave per workgroup: the butterfly already left the result in every lane */
     double *buf = c.red + (c.red_slot & (RED_SLOTS - 1))*(MAX_WAVES*RED_K);
     c.red_slot++;
     if (c.lane == 0) {
@@ -223,63 +248,85 @@ __device__ __forceinline__ double push_in(double x, double lb, double ub, bool h
 __device__ __forceinline__ bool cmp_le(double lhs, double rhs, double basval) { return lhs - rhs <= 10.0*DBL_EPSILON*fabs(basval); }
 
 /* ------------------------------------------------------------------------------------------
- * per-thread (= per shooting node) state
+ * per-thread (= per shooting node) state.  Kept small on purpose: it has to stay in VGPRs for the
+ * whole solve next to the temporaries of the jet arithmetic (256 registers at 2 waves per SIMD).
+ * Bounds are not stored per variable: only the upper bound of b is node dependent.
  * ---------------------------------------------------------------------------------------- */
+constexpr unsigned F_ON_T = 1u, F_ON_B = 2u, F_ON_F = 4u, F_ON_P = 8u, F_ON_S = 16u, F_IVAL = 32u, F_NODE = 64u;
+
 struct Node {
-    /* static */
     int i;
-    bool ival;                 /* has an interval (i < N)                */
-    bool on[NV], hasL[NV], hasU[NV];
-    double lb[NV], ub[NV];
-    double ds, G, sct, scb;
+    unsigned flags;
+    double ds, G, sct, scb, ubB;
     /* iterate */
     double x[NV], sg[NR], lam[2], nu[NR], zL[NV], zU[NV], zLs[NR], zUs[NR];
-    /* direction */
-    double dx[NV], dsg[NR], dlam[2], dnu[NR];
+    /* slack part of the direction; (dx, new dynamics multipliers) stay in the node's LDS stage block */
+    double dsg[NR];
+    __device__ __forceinline__ bool ival() const { return (flags & F_IVAL) != 0; }
+    __device__ __forceinline__ bool node() const { return (flags & F_NODE) != 0; }
+    __device__ __forceinline__ bool on(int k) const { return (flags >> k) & 1u; }
 };
 
-struct Rows {                  /* workgroup-uniform row data */
-    bool on[NR], hasL[NR], hasU[NR];
-    double dL[NR], dU[NR], rs[NR];
+/* workgroup-uniform data (scalar registers) */
+struct Uni {
+    double tlo, thi, blo, flo, fhi, plo, phi, slo;     /* relaxed variable bounds */
+    bool rowOn[NR], rL[NR], rU[NR];
+    double dL[NR], dU[NR], rs[NR];                     /* relaxed (scaled) row bounds, row scaling */
+    double sf;                                         /* objective scaling */
 };
 
-/* values of the interval functions */
+/* keeps the instruction scheduler from interleaving the work of a thread's nodes (which would double the live registers) */
+__device__ __forceinline__ void node_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+/* value the optimiser must treat as redefined here (no instruction is emitted) */
+__device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); }
+
+/* a workgroup-uniform double into scalar registers */
+__device__ __forceinline__ double uni(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+/* derivatives of the interval map kept between the evaluation and the KKT assembly */
 struct Ev {
-    double c[2], d[NR];
     double sb, sb1, b1;
     double tb, tw, tbb, tbw, tww, Bb, Bw, Bbb, Bbw, Bww;
 };
 
+/* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
 template <bool DERIV>
-__device__ __forceinline__ void eval_interval(const DevProb &P, const Rows &R, const Node &n, const double *x, double t1, double b1, Ev &e)
+__device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const Node &n, const double (&x)[NV], double t1, double b1,
+                                              double (&cv)[2], double (&dv)[NR], Ev &e)
 {
-    double b = x[VB], f = x[VF], p = P.withPn ? x[VP] : 0.0, s = x[VS];
+    const double b = x[VB], f = x[VF], p = P.withPn ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
         interval_map<Jet>(P, b, f + p, n.G, n.ds, tau, bp);
-        e.c[0] = t1 - (x[VT] + tau.v); e.c[1] = b1 - bp.v;
+        cv[0] = t1 - (x[VT] + tau.v); cv[1] = b1 - bp.v;
         e.tb = tau.g0; e.tw = tau.g1; e.tbb = tau.h00; e.tbw = tau.h01; e.tww = tau.h11;
         e.Bb = bp.g0; e.Bw = bp.g1; e.Bbb = bp.h00; e.Bbw = bp.h01; e.Bww = bp.h11;
     } else {
         double tau, bp;
         interval_map<double>(P, b, f + p, n.G, n.ds, tau, bp);
-        e.c[0] = t1 - (x[VT] + tau); e.c[1] = b1 - bp;
+        cv[0] = t1 - (x[VT] + tau); cv[1] = b1 - bp;
     }
-    double sb = sqrt(b), sb1 = sqrt(b1);
-    e.sb = sb; e.sb1 = sb1; e.b1 = b1;
-    e.d[RPW0] = R.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
-    e.d[RPW1] = R.rs[RPW1]*f*sb1;
-    e.d[RACC] = R.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - n.G);     /* ocp.py:199 */
-    e.d[RLTR] = R.rs[RLTR]*(s - P.ct*f);                                     /* ocp.py:225 */
-    e.d[RLRG] = R.rs[RLRG]*(s + P.cr*f);                                     /* ocp.py:226 */
+    const double sb = sqrt(b), sb1 = sqrt(b1);
+    if (DERIV) { e.sb = sb; e.sb1 = sb1; e.b1 = b1; }
+    dv[RPW0] = U.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
+    dv[RPW1] = U.rs[RPW1]*f*sb1;
+    dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - n.G);     /* ocp.py:199 */
+    dv[RLTR] = U.rs[RLTR]*(s - P.ct*f);                                     /* ocp.py:225 */
+    dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);                                     /* ocp.py:226 */
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
-__device__ __forceinline__ double objective_term(const DevProb &P, const Node &n, const double *x, double q, double sf)
+__device__ __forceinline__ double objective_term(const DevProb &P, const Node &n, const double (&x)[NV], double q, double sf)
 {
     double J = 0;
-    if (n.ival) {
-        double f = x[VF], p = P.withPn ? x[VP] : 0.0;
+    if (n.ival()) {
+        const double f = x[VF], p = P.withPn ? x[VP] : 0.0;
         if (P.energyOpt) {
             J = n.ds*(f + x[VS]);                                             /* ocp.py:223 */
             if (n.i > 0) J += 1e-3*(f - q)*(f - q);                           /* ocp.py:245 */
@@ -288,6 +335,7 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const Node &n
     return sf*J/P.objDen;
 }
 
+
 /* ------------------------------------------------------------------------------------------
  * the serial part: Riccati recursion over the stage blocks in LDS (one thread).
  * Stage i: y = (dt, db, dq | df, dp, ds), next state = F y + r with
@@ -295,7 +343,7 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const Node &n
  * The last interval eliminates df through db_N = 0 (b_N is a parameter of the NLP).
  * Returns false when a pivot is not positive (wrong inertia of the KKT matrix).
  * ---------------------------------------------------------------------------------------- */
-__device__ __noinline__ bool riccati_solve(const DevProb &P, double *S)
+__device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
 {
     const int N = P.N;
     const bool pn = P.withPn != 0;
@@ -420,326 +468,476 @@ __device__ __noinline__ bool riccati_solve(const DevProb &P, double *S)
 }
 
 /* ------------------------------------------------------------------------------------------
- * the solver
+ * the solver.  SPT = shooting nodes per thread: node j of thread `tid` is node tid + j*NT.
+ * The benchmark geometry is one wave per scenario (NT = 64) with SPT = 2: four single-wave
+ * workgroups per CU, one per SIMD, each with the whole 512-entry register file of its SIMD,
+ * so the complete iterate of two nodes stays in registers and barriers are wave-local.
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
+template <int SPT>
 struct Solver {
     const DevProb &P;
     Ctx &c;
-    Node n;
-    Rows R;
-    Ev e;
-    double sf, mu, tau;
-    double resc[2], resd[NR];     /* right-hand sides of the linearised constraints (c, d - sigma or their SOC accumulation) */
+    Node n[SPT];
+    Uni U;
+    double resc[SPT][2], resd[SPT][NR];   /* right-hand sides of the linearised constraints: c and d - sigma (or their SOC accumulation) */
 
-    __device__ Solver(const DevProb &P_, Ctx &c_) : P(P_), c(c_) {}
+    __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_) : P(P_), c(c_) {}
+
+    /* every free variable has a lower bound; all but the loss slack have an upper bound (ocp.py:175-181, 263-272) */
+    __device__ __forceinline__ double lbv(int k) const { return k == VT ? U.tlo : k == VB ? U.blo : k == VF ? U.flo : k == VP ? U.plo : U.slo; }
+    __device__ __forceinline__ double ubv(int j, int k) const { return k == VT ? U.thi : k == VB ? n[j].ubB : k == VF ? U.fhi : k == VP ? U.phi : INFINITY; }
+    __device__ static __forceinline__ bool hasU(int k) { return k != VS; }
+
+    /* phase boundary: keeps the optimiser from carrying subexpressions of the state (slacks, reciprocals, Sigma ...) from one
+     * phase to the next in registers -- recomputing them is cheaper than the spills they cause */
+    __device__ __forceinline__ void phase_fence()
+    {
+#if MSD_PHASE_FENCE
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            Node &nd = n[j];
+#pragma unroll
+            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); opaque(nd.zL[k]); opaque(nd.zU[k]); }
+#pragma unroll
+            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); opaque(nd.nu[r]); opaque(nd.zLs[r]); opaque(nd.zUs[r]); opaque(nd.dsg[r]); opaque(resd[j][r]); }
+            opaque(nd.lam[0]); opaque(nd.lam[1]); opaque(resc[j][0]); opaque(resc[j][1]);
+        }
+#endif
+    }
 
     /* publish (t, b, f) of a point so that neighbours can read them */
-    __device__ __forceinline__ void publish(const double *x)
+    __device__ __forceinline__ void publish(const double (&x)[SPT][NV])
     {
         __syncthreads();
-        c.xt[c.tid] = x[VT]; c.xb[c.tid] = x[VB]; c.xf[c.tid] = x[VF];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) { const int i = n[j].i; c.xt[i] = x[j][VT]; c.xb[i] = x[j][VB]; c.xf[i] = x[j][VF]; }
         __syncthreads();
     }
-    __device__ __forceinline__ double nb_q() const { return (n.i > 0 && n.i <= P.N) ? c.xf[c.tid - 1] : 0.0; }
-
-    __device__ __forceinline__ void row_slack_terms(int r, double mu_, double dw, double &Sg, double &gphi) const
+    __device__ __forceinline__ void publish_current()
     {
-        bar_terms(n.sg[r], R.dL[r], R.dU[r], R.hasL[r], R.hasU[r], n.zLs[r], n.zUs[r], mu_, Sg, gphi);
-        Sg += dw;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) { const int i = n[j].i; c.xt[i] = n[j].x[VT]; c.xb[i] = n[j].x[VB]; c.xf[i] = n[j].x[VF]; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ double nb_q(int j) const { return (n[j].i > 0 && n[j].node()) ? c.xf[n[j].i - 1] : 0.0; }
+
+    __device__ __forceinline__ void var_terms(int j, int k, double mu_, double &Sg, double &gphi) const
+    {
+        bar_terms(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k), n[j].zL[k], n[j].zU[k], mu_, Sg, gphi);
+    }
+    __device__ __forceinline__ void row_terms(int j, int r, double mu_, double &Sg, double &gphi) const
+    {
+        bar_terms(n[j].sg[r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], n[j].zLs[r], n[j].zUs[r], mu_, Sg, gphi);
     }
 
     /* gradient entries of the rows wrt (b, f, p, s, b1) */
-    __device__ __forceinline__ void row_grads(double f, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], double (&gs)[NR], double (&gb1)[NR]) const
+    __device__ __forceinline__ void row_grads(int j, const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], double (&gs)[NR], double (&gb1)[NR]) const
     {
+        const double f = n[j].x[VF];
 #pragma unroll
         for (int r = 0; r < NR; r++) { gb[r] = gf[r] = gp[r] = gs[r] = gb1[r] = 0; }
-        gf[RPW0] = e.sb; gb[RPW0] = 0.5*f/e.sb;
-        gf[RPW1] = e.sb1; gb1[RPW1] = 0.5*f/e.sb1;
-        gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/e.sb + P.sr2);
+        gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
+        gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
+        gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
         gs[RLTR] = 1; gf[RLTR] = -P.ct;
         gs[RLRG] = 1; gf[RLRG] = P.cr;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { gb[r] *= R.rs[r]; gf[r] *= R.rs[r]; gp[r] *= R.rs[r]; gs[r] *= R.rs[r]; gb1[r] *= R.rs[r]; }
+        for (int r = 0; r < NR; r++) { gb[r] *= U.rs[r]; gf[r] *= U.rs[r]; gp[r] *= U.rs[r]; gs[r] *= U.rs[r]; gb1[r] *= U.rs[r]; }
     }
 
-    /* objective gradient wrt (f, p, s, q) of the interval; terminal time handled by node N */
-    __device__ __forceinline__ void obj_grads(double q, double &of, double &op, double &os, double &oq, double &off, double &opp) const
+    /* objective gradient wrt (f, p, s, q) of the interval and its (constant) curvature; terminal time handled by node N */
+    __device__ __forceinline__ void obj_grads(int j, double q, double &of, double &op, double &os, double &oq, double &off, double &opp) const
     {
-        double sc = sf/P.objDen;
+        const double sc = U.sf/P.objDen;
         of = op = os = oq = off = opp = 0;
-        if (!n.ival) return;
-        double f = n.x[VF], p = P.withPn ? n.x[VP] : 0.0;
+        if (!n[j].ival()) return;
+        const double f = n[j].x[VF], p = P.withPn ? n[j].x[VP] : 0.0;
         if (P.energyOpt) {
-            of = sc*n.ds; os = sc*n.ds;
-            if (n.i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
+            of = sc*n[j].ds; os = sc*n[j].ds;
+            if (n[j].i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
         } else {
             of = sc*2e-4*f; off = sc*2e-4;
             if (P.withPn) { op = sc*2e-4*p; opp = sc*2e-4; }
         }
     }
 
-    /*
-     * Optimality error of the scaled problem (W&B eq. (5)) with the current evaluation `e`.
-     * out: dual, primal (scaled), cmax/cmin of the complementarity products, sum|lam|, sum z, counts, unscaled primal
-     */
-    struct Err { double dual, primal, primal_u, cmax, cmin, sd, sc; };
-
-    __device__ __noinline__ void kkt_error(Err &E)
+    /* primal direction and new dynamics multipliers of node j, as the Riccati sweep left them in the node's stage block */
+    struct Dir { double dx[NV], lt, lb; };
+    __device__ __forceinline__ void load_dir(int j, Dir &d) const
     {
-        const double q = nb_q();
-        double gl[NV] = {0, 0, 0, 0, 0};
-        double out_q = 0, out_t1 = 0, out_b1 = 0;
+        const Node &nd = n[j];
+#pragma unroll
+        for (int k = 0; k < NV; k++) d.dx[k] = 0;
+        d.lt = d.lb = 0;
+        if (!nd.node()) return;
+        const double *s = c.S + nd.i*S_STRIDE;
+        if (nd.on(VT)) d.dx[VT] = s[S_DT];
+        if (nd.on(VB)) d.dx[VB] = s[S_DB];
+        if (nd.ival()) {
+            if (nd.on(VF)) d.dx[VF] = s[S_DF];
+            if (nd.on(VP)) d.dx[VP] = s[S_DP];
+            if (nd.on(VS)) d.dx[VS] = s[S_DS];
+            d.lt = s[S_LT]; d.lb = s[S_LB];
+        }
+    }
+
+    /*
+     * One pass over the current point (evaluation `e`, residuals in resc/resd): optimality error of the scaled
+     * problem (W&B eq. (5)), and the pieces of the filter's merit pair: theta, and phi(mu) = obj - mu L + kappa_d mu D.
+     */
+    struct Err { double dual, primal, primal_u, cmax, cmin, sd, sc, theta, L, D, obj; };
+
+    __device__ __forceinline__ void kkt_pass(const Ev (&e)[SPT], Err &E)
+    {
+        double gl[SPT][NV];
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;
-        if (n.ival) {
-            double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-            row_grads(n.x[VF], gb, gf, gp, gs, gb1);
-            double of, op, os, oq, off, opp;
-            obj_grads(q, of, op, os, oq, off, opp);
-            gl[VF] = of; gl[VP] = op; gl[VS] = os; out_q = oq;
+        double th = 0, logs = 0, damp = 0, obj = 0;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                gl[VB] += n.nu[r]*gb[r]; gl[VF] += n.nu[r]*gf[r]; gl[VP] += n.nu[r]*gp[r]; gl[VS] += n.nu[r]*gs[r]; out_b1 += n.nu[r]*gb1[r];
-            }
-            /* dynamics rows: c_t = t1 - t - tau, c_b = b1 - b+ */
-            out_t1 += n.lam[0]; gl[VT] -= n.lam[0];
-            gl[VB] -= n.lam[0]*e.tb + n.lam[1]*e.Bb;
-            gl[VF] -= n.lam[0]*e.tw + n.lam[1]*e.Bw;
-            if (P.withPn) gl[VP] -= n.lam[0]*e.tw + n.lam[1]*e.Bw;
-            out_b1 += n.lam[1];
-            prim = fmax(n.sct*fabs(e.c[0]), n.scb*fabs(e.c[1]));
-            prim_u = fmax(fabs(e.c[0]), fabs(e.c[1]));
-            sumlam = fabs(n.lam[0])/n.sct + fabs(n.lam[1])/n.scb; nlam = 2;
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            const double q = nb_q(j);
+            double out_q = 0, out_t1 = 0, out_b1 = 0, prod = 1.0;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                double viol = fabs(e.d[r] - n.sg[r]);
-                prim = fmax(prim, viol); prim_u = fmax(prim_u, viol/R.rs[r]);
-                sumlam += fabs(n.nu[r]); nlam += 1;
-                double gsl = -n.nu[r];
-                if (R.hasL[r]) { gsl -= n.zLs[r]; double cp = (n.sg[r] - R.dL[r])*n.zLs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += n.zLs[r]; nz += 1; }
-                if (R.hasU[r]) { gsl += n.zUs[r]; double cp = (R.dU[r] - n.sg[r])*n.zUs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += n.zUs[r]; nz += 1; }
-                dual = fmax(dual, fabs(gsl));
+            for (int k = 0; k < NV; k++) gl[j][k] = 0;
+            if (nd.ival()) {
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
+                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                double of, op, os, oq, off, opp;
+                obj_grads(j, q, of, op, os, oq, off, opp);
+                gl[j][VF] = of; gl[j][VP] = op; gl[j][VS] = os; out_q = oq;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    gl[j][VB] += nd.nu[r]*gb[r]; gl[j][VF] += nd.nu[r]*gf[r]; gl[j][VP] += nd.nu[r]*gp[r]; gl[j][VS] += nd.nu[r]*gs[r]; out_b1 += nd.nu[r]*gb1[r];
+                }
+                /* dynamics rows: c_t = t1 - t - tau, c_b = b1 - b+ */
+                out_t1 += nd.lam[0]; gl[j][VT] -= nd.lam[0];
+                gl[j][VB] -= nd.lam[0]*e[j].tb + nd.lam[1]*e[j].Bb;
+                gl[j][VF] -= nd.lam[0]*e[j].tw + nd.lam[1]*e[j].Bw;
+                if (P.withPn) gl[j][VP] -= nd.lam[0]*e[j].tw + nd.lam[1]*e[j].Bw;
+                out_b1 += nd.lam[1];
+                prim = fmax(prim, fmax(nd.sct*fabs(resc[j][0]), nd.scb*fabs(resc[j][1])));
+                prim_u = fmax(prim_u, fmax(fabs(resc[j][0]), fabs(resc[j][1])));
+                th += nd.sct*fabs(resc[j][0]) + nd.scb*fabs(resc[j][1]);
+                sumlam += fabs(nd.lam[0])/nd.sct + fabs(nd.lam[1])/nd.scb; nlam += 2;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    const double viol = fabs(resd[j][r]);
+                    prim = fmax(prim, viol); prim_u = fmax(prim_u, viol/U.rs[r]); th += viol;
+                    sumlam += fabs(nd.nu[r]); nlam += 1;
+                    double gsl = -nd.nu[r];
+                    if (U.rL[r]) { const double s = nd.sg[r] - U.dL[r]; gsl -= nd.zLs[r]; const double cp = s*nd.zLs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zLs[r]; nz += 1; prod *= s; }
+                    if (U.rU[r]) { const double s = U.dU[r] - nd.sg[r]; gsl += nd.zUs[r]; const double cp = s*nd.zUs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zUs[r]; nz += 1; prod *= s; }
+                    if (U.rL[r] && !U.rU[r]) damp += nd.sg[r] - U.dL[r];
+                    if (!U.rL[r] && U.rU[r]) damp += U.dU[r] - nd.sg[r];
+                    dual = fmax(dual, fabs(gsl));
+                }
+            } else if (nd.i == P.N && !P.energyOpt) gl[j][VT] = U.sf/P.objDen;
+            if (nd.node()) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    prod *= nd.x[k] - lbv(k);
+                    if (hasU(k)) prod *= ubv(j, k) - nd.x[k];
+                    else damp += nd.x[k] - lbv(k);
+                }
+                obj += objective_term(P, nd, nd.x, q, U.sf);
             }
-        } else if (n.i == P.N && !P.energyOpt) gl[VT] = sf/P.objDen;
-        /* exchange the contributions that belong to the neighbours' variables */
-        c.o1[c.tid] = out_q; c.o2[c.tid] = out_t1; c.o3[c.tid] = out_b1;
+            logs += log(prod);
+            /* the contributions that belong to the neighbours' variables */
+            c.o1[nd.i] = out_q; c.o2[nd.i] = out_t1; c.o3[nd.i] = out_b1;
+        }
         __syncthreads();
-        if (n.i <= P.N) {
-            if (n.i > 0) { gl[VT] += c.o2[c.tid - 1]; gl[VB] += c.o3[c.tid - 1]; }
-            if (n.i + 1 < P.N) gl[VF] += c.o1[c.tid + 1];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            if (!nd.node()) continue;
+            if (nd.i > 0) { gl[j][VT] += c.o2[nd.i - 1]; gl[j][VB] += c.o3[nd.i - 1]; }
+            if (nd.i + 1 < P.N) gl[j][VF] += c.o1[nd.i + 1];
 #pragma unroll
             for (int k = 0; k < NV; k++) {
-                if (!n.on[k]) continue;
-                double g = gl[k];
-                if (n.hasL[k]) { g -= n.zL[k]; double cp = (n.x[k] - n.lb[k])*n.zL[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += n.zL[k]; nz += 1; }
-                if (n.hasU[k]) { g += n.zU[k]; double cp = (n.ub[k] - n.x[k])*n.zU[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += n.zU[k]; nz += 1; }
+                if (!nd.on(k)) continue;
+                double g = gl[j][k];
+                { const double s = nd.x[k] - lbv(k); g -= nd.zL[k]; const double cp = s*nd.zL[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zL[k]; nz += 1; }
+                if (hasU(k)) { const double s = ubv(j, k) - nd.x[k]; g += nd.zU[k]; const double cp = s*nd.zU[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zU[k]; nz += 1; }
                 dual = fmax(dual, fabs(g));
             }
         }
         double vm[5] = {dual, prim, prim_u, cmax, -cmin};
         block_reduce<5>(vm, OpMax(), c);
-        double vs[4] = {sumlam, sumz, nlam, nz};
-        block_reduce<4>(vs, OpSum(), c);
-        E.dual = vm[0]; E.primal = vm[1]; E.primal_u = vm[2]; E.cmax = vm[3]; E.cmin = -vm[4];
-        E.sd = fmax(K_SMAX, (vs[0] + vs[1])/fmax(1.0, vs[2] + vs[3]))/K_SMAX;
-        E.sc = fmax(K_SMAX, vs[1]/fmax(1.0, vs[3]))/K_SMAX;
+        double vs[8] = {sumlam, sumz, nlam, nz, th, logs, damp, obj};
+        block_reduce<8>(vs, OpSum(), c);
+        E.dual = uni(vm[0]); E.primal = uni(vm[1]); E.primal_u = uni(vm[2]); E.cmax = uni(vm[3]); E.cmin = -uni(vm[4]);
+        E.sd = uni(fmax(K_SMAX, (vs[0] + vs[1])/fmax(1.0, vs[2] + vs[3]))/K_SMAX);
+        E.sc = uni(fmax(K_SMAX, vs[1]/fmax(1.0, vs[3]))/K_SMAX);
+        E.theta = uni(vs[4]); E.L = uni(vs[5]); E.D = uni(vs[6]); E.obj = uni(vs[7]);
     }
     __device__ static __forceinline__ double compl_err(const Err &E, double mu_) { return (E.cmax >= E.cmin) ? fmax(fabs(E.cmax - mu_), fabs(E.cmin - mu_)) : 0.0; }
     __device__ static __forceinline__ double total_err(const Err &E, double mu_) { return fmax(E.dual/E.sd, fmax(E.primal, compl_err(E, mu_)/E.sc)); }
 
     /*
-     * Condensed stage block of node i into LDS (W&B eq. (13) with slacks and bound multipliers eliminated).
+     * Condensed stage block of every node into LDS (W&B eq. (13) with slacks and bound multipliers eliminated).
      * MODE_LSQ: least-squares multiplier system (W = 0, Sigma = I, gradient = grad f - zL + zU).
      */
-    template <int MODE> __device__ __forceinline__ void assemble(double mu_, double dw)
+    __device__ __forceinline__ void assemble(const Ev (&e)[SPT], const int mode, double mu_, double dw)
     {
-        const double q = nb_q();
-        double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
-        double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
-        double nHbb = 0, nHbq = 0, nhb = 0;
-        if (n.ival) {
-            const double f = n.x[VF];
-            double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-            row_grads(f, gb, gf, gp, gs, gb1);
-            double of, op, os, oq, off, opp;
-            obj_grads(q, of, op, os, oq, off, opp);
-            hf = of; hp = op; hs = os; hq = oq;
-            if (MODE == MODE_NEWTON) {
-                Hff = off; Hpp = opp;
-                if (P.energyOpt && n.i > 0) { Hqq = off; Hqf = -off; }
-                /* - lam_t hess(tau) - lam_b hess(b+) */
-                const double hbb = -(n.lam[0]*e.tbb + n.lam[1]*e.Bbb), hbw = -(n.lam[0]*e.tbw + n.lam[1]*e.Bbw), hww = -(n.lam[0]*e.tww + n.lam[1]*e.Bww);
-                Hbb += hbb; Hbf += hbw; Hff += hww;
-                if (P.withPn) { Hbp += hbw; Hfp += hww; Hpp += hww; }
-                /* nu * hess(row) */
-                const double b = n.x[VB];
-                if (R.on[RPW0]) { Hbf += n.nu[RPW0]*R.rs[RPW0]*0.5/e.sb; Hbb += n.nu[RPW0]*R.rs[RPW0]*(-0.25*f/(b*e.sb)); }
-                if (R.on[RPW1]) { nHbq += n.nu[RPW1]*R.rs[RPW1]*0.5/e.sb1; nHbb += n.nu[RPW1]*R.rs[RPW1]*(-0.25*f/(e.b1*e.sb1)); }
-                if (R.on[RACC]) Hbb += n.nu[RACC]*R.rs[RACC]*0.25*P.sr1/(b*e.sb);
-            }
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                double Sg, coef;
-                if (MODE == MODE_NEWTON) { double gphi; row_slack_terms(r, mu_, dw, Sg, gphi); coef = Sg*resd[r] + gphi; }
-                else { Sg = 1.0; coef = -(R.hasL[r] ? 1.0 : 0.0) + (R.hasU[r] ? 1.0 : 0.0); }
-                hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
-                Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
-                Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
-                Hpp += Sg*gp[r]*gp[r]; Hss += Sg*gs[r]*gs[r];
-                nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
-            }
-        } else if (n.i == P.N && !P.energyOpt) ht = sf/P.objDen;
-        /* bounds of the node's own variables + regularisation */
-        if (n.i <= P.N) {
-            double Sv[NV], gv[NV];
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            const double q = nb_q(j);
+            double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
+            double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
+            double nHbb = 0, nHbq = 0, nhb = 0;
+            if (nd.ival()) {
+                const double f = nd.x[VF];
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
+                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                double of, op, os, oq, off, opp;
+                obj_grads(j, q, of, op, os, oq, off, opp);
+                hf = of; hp = op; hs = os; hq = oq;
+                if (mode == MODE_NEWTON) {
+                    Hff = off; Hpp = opp;
+                    if (P.energyOpt && nd.i > 0) { Hqq = off; Hqf = -off; }
+                    /* - lam_t hess(tau) - lam_b hess(b+) */
+                    const double hbb = -(nd.lam[0]*e[j].tbb + nd.lam[1]*e[j].Bbb), hbw = -(nd.lam[0]*e[j].tbw + nd.lam[1]*e[j].Bbw),
+                                 hww = -(nd.lam[0]*e[j].tww + nd.lam[1]*e[j].Bww);
+                    Hbb += hbb; Hbf += hbw; Hff += hww;
+                    if (P.withPn) { Hbp += hbw; Hfp += hww; Hpp += hww; }
+                    /* nu * hess(row) */
+                    const double b = nd.x[VB];
+                    if (U.rowOn[RPW0]) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
+                    if (U.rowOn[RPW1]) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
+                    if (U.rowOn[RACC]) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
+                }
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                Sv[k] = 0; gv[k] = 0;
-                if (!n.on[k]) continue;
-                if (MODE == MODE_NEWTON) { bar_terms(n.x[k], n.lb[k], n.ub[k], n.hasL[k], n.hasU[k], n.zL[k], n.zU[k], mu_, Sv[k], gv[k]); Sv[k] += dw; }
-                else { Sv[k] = 1.0; gv[k] = -(n.hasL[k] ? 1.0 : 0.0) + (n.hasU[k] ? 1.0 : 0.0); }
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    double Sg, coef;
+                    if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*resd[j][r] + gphi; }
+                    else { Sg = 1.0; coef = -(U.rL[r] ? 1.0 : 0.0) + (U.rU[r] ? 1.0 : 0.0); }
+                    hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
+                    Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
+                    Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
+                    Hpp += Sg*gp[r]*gp[r]; Hss += Sg*gs[r]*gs[r];
+                    nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
+                }
+            } else if (nd.i == P.N && !P.energyOpt) ht = U.sf/P.objDen;
+            /* bounds of the node's own variables + regularisation */
+            if (nd.node()) {
+                double Sv[NV], gv[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    Sv[k] = 0; gv[k] = 0;
+                    if (!nd.on(k)) continue;
+                    if (mode == MODE_NEWTON) { var_terms(j, k, mu_, Sv[k], gv[k]); Sv[k] += dw; }
+                    else { Sv[k] = 1.0; gv[k] = -1.0 + (hasU(k) ? 1.0 : 0.0); }
+                }
+                Htt += Sv[VT]; ht += gv[VT]; Hbb += Sv[VB]; hb += gv[VB]; Hff += Sv[VF]; hf += gv[VF]; Hpp += Sv[VP]; hp += gv[VP]; Hss += Sv[VS]; hs += gv[VS];
+                double *s = c.S + nd.i*S_STRIDE;
+                if (nd.ival()) {
+                    s[S_TB] = e[j].tb; s[S_TW] = e[j].tw; s[S_BB] = e[j].Bb; s[S_BW] = e[j].Bw;
+                    s[S_RT] = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0; s[S_RB] = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
+                }
+                s[S_HTT] = Htt; s[S_HBB] = Hbb; s[S_HBQ] = Hbq; s[S_HBF] = Hbf; s[S_HBP] = Hbp; s[S_HQQ] = Hqq; s[S_HQF] = Hqf;
+                s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HFS] = Hfs; s[S_HPP] = Hpp; s[S_HSS] = Hss;
+                s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp; s[S_HS] = hs;
             }
-            Htt += Sv[VT]; ht += gv[VT]; Hbb += Sv[VB]; hb += gv[VB]; Hff += Sv[VF]; hf += gv[VF]; Hpp += Sv[VP]; hp += gv[VP]; Hss += Sv[VS]; hs += gv[VS];
+            /* the end-of-interval power row lives in the next stage's (b, q) block */
+            c.o1[nd.i] = nHbb; c.o2[nd.i] = nHbq; c.o3[nd.i] = nhb;
         }
-        /* the end-of-interval power row lives in the next stage's (b, q) block */
-        c.o1[c.tid] = nHbb; c.o2[c.tid] = nHbq; c.o3[c.tid] = nhb;
         __syncthreads();
-        if (n.i <= P.N) {
-            if (n.i > 0) { Hbb += c.o1[c.tid - 1]; Hbq += c.o2[c.tid - 1]; hb += c.o3[c.tid - 1]; }
-            double *s = c.S + n.i*S_STRIDE;
-            if (n.ival) {
-                s[S_TB] = e.tb; s[S_TW] = e.tw; s[S_BB] = e.Bb; s[S_BW] = e.Bw;
-                s[S_RT] = (MODE == MODE_NEWTON) ? -resc[0] : 0.0; s[S_RB] = (MODE == MODE_NEWTON) ? -resc[1] : 0.0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            if (nd.node() && nd.i > 0) {
+                double *s = c.S + nd.i*S_STRIDE;
+                s[S_HBB] += c.o1[nd.i - 1]; s[S_HBQ] += c.o2[nd.i - 1]; s[S_HB] += c.o3[nd.i - 1];
             }
-            s[S_HTT] = Htt; s[S_HBB] = Hbb; s[S_HBQ] = Hbq; s[S_HBF] = Hbf; s[S_HBP] = Hbp; s[S_HQQ] = Hqq; s[S_HQF] = Hqf;
-            s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HFS] = Hfs; s[S_HPP] = Hpp; s[S_HSS] = Hss;
-            s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp; s[S_HS] = hs;
         }
         __syncthreads();
     }
 
     /* KKT solve: assemble, serial Riccati, read the direction back.  Returns the inertia flag (uniform). */
-    template <int MODE> __device__ __noinline__ bool direction(double mu_, double dw)
+    __device__ __forceinline__ bool direction(const Ev (&e)[SPT], const int mode, double mu_, double dw)
     {
-        assemble<MODE>(mu_, dw);
-        if (c.tid == 0) c.misc[0] = riccati_solve(P, c.S) ? 1.0 : 0.0;
-        __syncthreads();
-        const bool ok = c.misc[0] != 0.0;
-        if (ok && n.i <= P.N) {
-            const double *s = c.S + n.i*S_STRIDE;
-            n.dx[VT] = s[S_DT]; n.dx[VB] = s[S_DB];
-            if (n.ival) {
-                n.dx[VF] = s[S_DF]; n.dx[VP] = s[S_DP]; n.dx[VS] = s[S_DS];
-                const double lt = s[S_LT], lb = s[S_LB];
-                const double *s1 = s + S_STRIDE;
-                const double db1 = s1[S_DB];
-                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                row_grads(n.x[VF], gb, gf, gp, gs, gb1);
-                if (MODE == MODE_NEWTON) { n.dlam[0] = lt - n.lam[0]; n.dlam[1] = lb - n.lam[1]; }
-                else { n.dlam[0] = lt; n.dlam[1] = lb; }
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    n.dsg[r] = 0; n.dnu[r] = 0;
-                    if (!R.on[r]) continue;
-                    double lin = gb[r]*n.dx[VB] + gf[r]*n.dx[VF] + gp[r]*n.dx[VP] + gs[r]*n.dx[VS] + gb1[r]*db1;
-                    if (MODE == MODE_NEWTON) {
-                        double Sg, gphi; row_slack_terms(r, mu_, dw, Sg, gphi);
-                        n.dsg[r] = resd[r] + lin;
-                        n.dnu[r] = Sg*n.dsg[r] + gphi - n.nu[r];
-                    } else {
-                        /* nu = Sigma dsigma + (-zL + zU) with Sigma = 1 */
-                        n.dnu[r] = lin + (-(R.hasL[r] ? 1.0 : 0.0) + (R.hasU[r] ? 1.0 : 0.0));
-                    }
-                }
-            } else { n.dx[VF] = n.dx[VP] = n.dx[VS] = 0; }
-#pragma unroll
-            for (int k = 0; k < NV; k++) if (!n.on[k]) n.dx[k] = 0;
+        c.mark(PH_OTHER); phase_fence();
+        assemble(e, mode, mu_, dw);
+        c.mark(PH_ASSEMBLE); phase_fence();
+        if (c.tid == 0) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            c.misc[0] = riccati_solve(P, c.S) ? 1.0 : 0.0;
+            c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
         }
         __syncthreads();
+        c.mark(PH_RICCATI); phase_fence();
+        const bool ok = uni(c.misc[0]) != 0.0;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                node_fence();
+                Node &nd = n[j];
+#pragma unroll
+                for (int r = 0; r < NR; r++) nd.dsg[r] = 0;
+                if (!nd.ival()) continue;
+                Dir d; load_dir(j, d);
+                const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
+                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    const double lin = gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1;
+                    /* Newton: slack step; least squares: nu = Sigma dsigma + (-zL + zU) with Sigma = 1, parked in dsg */
+                    nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-(U.rL[r] ? 1.0 : 0.0) + (U.rU[r] ? 1.0 : 0.0));
+                }
+            }
+        }
+        __syncthreads();
+        c.mark(PH_READBACK); phase_fence();
         return ok;
     }
 
-    __device__ __forceinline__ double dzL_var(int k, double mu_) const { double s = n.x[k] - n.lb[k]; return mu_/s - n.zL[k] - n.zL[k]/s*n.dx[k]; }
-    __device__ __forceinline__ double dzU_var(int k, double mu_) const { double s = n.ub[k] - n.x[k]; return mu_/s - n.zU[k] + n.zU[k]/s*n.dx[k]; }
-    __device__ __forceinline__ double dzL_row(int r, double mu_) const { double s = n.sg[r] - R.dL[r]; return mu_/s - n.zLs[r] - n.zLs[r]/s*n.dsg[r]; }
-    __device__ __forceinline__ double dzU_row(int r, double mu_) const { double s = R.dU[r] - n.sg[r]; return mu_/s - n.zUs[r] + n.zUs[r]/s*n.dsg[r]; }
+    __device__ __forceinline__ double dzL_var(int j, int k, double mu_, double dxk) const { const double s = n[j].x[k] - lbv(k); return mu_/s - n[j].zL[k] - n[j].zL[k]/s*dxk; }
+    __device__ __forceinline__ double dzU_var(int j, int k, double mu_, double dxk) const { const double s = ubv(j, k) - n[j].x[k]; return mu_/s - n[j].zU[k] + n[j].zU[k]/s*dxk; }
+    __device__ __forceinline__ double dzL_row(int j, int r, double mu_) const { const double s = n[j].sg[r] - U.dL[r]; return mu_/s - n[j].zLs[r] - n[j].zLs[r]/s*n[j].dsg[r]; }
+    __device__ __forceinline__ double dzU_row(int j, int r, double mu_) const { const double s = U.dU[r] - n[j].sg[r]; return mu_/s - n[j].zUs[r] + n[j].zUs[r]/s*n[j].dsg[r]; }
 
     /* fraction-to-the-boundary step lengths of the current direction: primal, dual */
-    __device__ __noinline__ void step_lengths(double mu_, double tau_, double &apr, double &adu)
+    __device__ __forceinline__ void step_lengths(double mu_, double tau_, double &apr, double &adu)
     {
         double ap = 1.0, ad = 1.0;
-        if (n.i <= P.N) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                if (!n.on[k]) continue;
-                double d = n.dx[k];
-                if (n.hasL[k]) { if (d < 0) ap = fmin(ap, -tau_*(n.x[k] - n.lb[k])/d); double dz = dzL_var(k, mu_); if (dz < 0) ad = fmin(ad, -tau_*n.zL[k]/dz); }
-                if (n.hasU[k]) { if (d > 0) ap = fmin(ap, tau_*(n.ub[k] - n.x[k])/d); double dz = dzU_var(k, mu_); if (dz < 0) ad = fmin(ad, -tau_*n.zU[k]/dz); }
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            if (nd.node()) {
+                Dir dd; load_dir(j, dd);
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    const double d = dd.dx[k];
+                    { if (d < 0) ap = fmin(ap, -tau_*(nd.x[k] - lbv(k))/d); const double dz = dzL_var(j, k, mu_, d); if (dz < 0) ad = fmin(ad, -tau_*nd.zL[k]/dz); }
+                    if (hasU(k)) { if (d > 0) ap = fmin(ap, tau_*(ubv(j, k) - nd.x[k])/d); const double dz = dzU_var(j, k, mu_, d); if (dz < 0) ad = fmin(ad, -tau_*nd.zU[k]/dz); }
+                }
             }
-        }
-        if (n.ival) {
+            if (nd.ival()) {
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                double d = n.dsg[r];
-                if (R.hasL[r]) { if (d < 0) ap = fmin(ap, -tau_*(n.sg[r] - R.dL[r])/d); double dz = dzL_row(r, mu_); if (dz < 0) ad = fmin(ad, -tau_*n.zLs[r]/dz); }
-                if (R.hasU[r]) { if (d > 0) ap = fmin(ap, tau_*(R.dU[r] - n.sg[r])/d); double dz = dzU_row(r, mu_); if (dz < 0) ad = fmin(ad, -tau_*n.zUs[r]/dz); }
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    const double d = nd.dsg[r];
+                    if (U.rL[r]) { if (d < 0) ap = fmin(ap, -tau_*(nd.sg[r] - U.dL[r])/d); const double dz = dzL_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zLs[r]/dz); }
+                    if (U.rU[r]) { if (d > 0) ap = fmin(ap, tau_*(U.dU[r] - nd.sg[r])/d); const double dz = dzU_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zUs[r]/dz); }
+                }
             }
         }
         double v[2] = {ap, ad};
         block_reduce<2>(v, OpMin(), c);
-        apr = v[0]; adu = v[1];
+        apr = uni(v[0]); adu = uni(v[1]);
+    }
+
+    /* the point x + alpha d */
+    __device__ __forceinline__ void trial_point(double alpha, double (&xt)[SPT][NV], double (&st)[SPT][NR]) const
+    {
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            Dir dd; load_dir(j, dd);
+#pragma unroll
+            for (int k = 0; k < NV; k++) xt[j][k] = n[j].x[k] + alpha*dd.dx[k];
+#pragma unroll
+            for (int r = 0; r < NR; r++) st[j][r] = n[j].sg[r] + (U.rowOn[r] ? alpha*n[j].dsg[r] : 0.0);
+        }
     }
 
     /* theta (1-norm of the scaled constraint rows), barrier objective and validity of the point x + alpha d */
-    __device__ __noinline__ void merit(double alpha, double mu_, double &theta, double &phi, bool &ok, Ev *evout, double (*xout)[NV], double (*sgout)[NR])
+    __device__ __forceinline__ void merit(double alpha, double mu_, double &theta, double &phi, bool &ok)
     {
-        double xt[NV], st[NR];
-#pragma unroll
-        for (int k = 0; k < NV; k++) xt[k] = n.x[k] + (n.on[k] ? alpha*n.dx[k] : 0.0);
-#pragma unroll
-        for (int r = 0; r < NR; r++) st[r] = n.sg[r] + (R.on[r] ? alpha*n.dsg[r] : 0.0);
+        double xt[SPT][NV], st[SPT][NR];
+        trial_point(alpha, xt, st);
         publish(xt);
-        double th = 0, bar = 0, bad = 0, obj = 0;
-        Ev et;
-        if (n.ival) {
-            eval_interval<false>(P, R, n, xt, c.xt[c.tid + 1], c.xb[c.tid + 1], et);
-            th = n.sct*fabs(et.c[0]) + n.scb*fabs(et.c[1]);
+        double th = 0, logs = 0, damp = 0, bad = 0, obj = 0;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                th += fabs(et.d[r] - st[r]);
-                if (R.hasL[r]) { double s = st[r] - R.dL[r]; if (s <= 0) bad = 1; else bar -= mu_*log(s); }
-                if (R.hasU[r]) { double s = R.dU[r] - st[r]; if (s <= 0) bad = 1; else bar -= mu_*log(s); }
-                if (R.hasL[r] && !R.hasU[r]) bar += K_D*mu_*(st[r] - R.dL[r]);
-                if (!R.hasL[r] && R.hasU[r]) bar += K_D*mu_*(R.dU[r] - st[r]);
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            double prod = 1.0;
+            if (nd.ival()) {
+                double cv[2], dv[NR]; Ev dummy;
+                eval_interval<false>(P, U, nd, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
+                th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    th += fabs(dv[r] - st[j][r]);
+                    if (U.rL[r]) { const double s = st[j][r] - U.dL[r]; if (s <= 0) bad = 1; else prod *= s; }
+                    if (U.rU[r]) { const double s = U.dU[r] - st[j][r]; if (s <= 0) bad = 1; else prod *= s; }
+                    if (U.rL[r] && !U.rU[r]) damp += st[j][r] - U.dL[r];
+                    if (!U.rL[r] && U.rU[r]) damp += U.dU[r] - st[j][r];
+                }
+            }
+            if (nd.node()) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    { const double s = xt[j][k] - lbv(k); if (s <= 0) bad = 1; else prod *= s; }
+                    if (hasU(k)) { const double s = ubv(j, k) - xt[j][k]; if (s <= 0) bad = 1; else prod *= s; }
+                    else damp += xt[j][k] - lbv(k);
+                }
+                obj += objective_term(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
+            }
+            logs += log(prod);
+        }
+        double v[5] = {th, logs, damp, obj, bad};
+        block_reduce<5>(v, OpSum(), c);
+        theta = uni(v[0]); phi = uni(v[3] - mu_*v[1] + K_D*mu_*v[2]);
+        ok = (uni(v[4]) == 0.0) && isfinite(theta) && isfinite(phi);
+    }
+
+    /* c and d - sigma at the trial point x + alpha d (needed by the second-order correction only) */
+    __device__ __forceinline__ void trial_residuals(double alpha, double (&tc)[SPT][2], double (&td)[SPT][NR])
+    {
+        double xt[SPT][NV], st[SPT][NR];
+        trial_point(alpha, xt, st);
+        publish(xt);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            tc[j][0] = tc[j][1] = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) td[j][r] = 0;
+            if (n[j].ival()) {
+                double dv[NR]; Ev dummy;
+                eval_interval<false>(P, U, n[j], xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
+#pragma unroll
+                for (int r = 0; r < NR; r++) td[j][r] = U.rowOn[r] ? dv[r] - st[j][r] : 0.0;
             }
         }
-        if (n.i <= P.N) {
+    }
+
+    /* evaluate the current point with derivatives; residuals of the Newton system into resc/resd */
+    __device__ __forceinline__ void evaluate_current(Ev (&e)[SPT])
+    {
+        publish_current();
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                if (!n.on[k]) continue;
-                if (n.hasL[k]) { double s = xt[k] - n.lb[k]; if (s <= 0) bad = 1; else bar -= mu_*log(s); }
-                if (n.hasU[k]) { double s = n.ub[k] - xt[k]; if (s <= 0) bad = 1; else bar -= mu_*log(s); }
-                if (n.hasL[k] && !n.hasU[k]) bar += K_D*mu_*(xt[k] - n.lb[k]);
-                if (!n.hasL[k] && n.hasU[k]) bar += K_D*mu_*(n.ub[k] - xt[k]);
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            resc[j][0] = resc[j][1] = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) resd[j][r] = 0;
+            if (n[j].ival()) {
+                double dv[NR];
+                eval_interval<true>(P, U, n[j], n[j].x, c.xt[n[j].i + 1], c.xb[n[j].i + 1], resc[j], dv, e[j]);
+#pragma unroll
+                for (int r = 0; r < NR; r++) resd[j][r] = U.rowOn[r] ? dv[r] - n[j].sg[r] : 0.0;
             }
-            obj = objective_term(P, n, xt, (n.i > 0) ? c.xf[c.tid - 1] : 0.0, sf);
-        }
-        double v[4] = {th, bar, obj, bad};
-        block_reduce<4>(v, OpSum(), c);
-        theta = v[0]; phi = v[2] + v[1];
-        ok = (v[3] == 0.0) && isfinite(theta) && isfinite(phi);
-        if (evout) *evout = et;
-        if (xout) {
-#pragma unroll
-            for (int k = 0; k < NV; k++) (*xout)[k] = xt[k];
-#pragma unroll
-            for (int r = 0; r < NR; r++) (*sgout)[r] = st[r];
         }
     }
 
@@ -750,250 +948,278 @@ struct Solver {
         return true;
     }
 
+    /* acceptance of a trial point by the filter line search (W&B section 2.3); th_ref/phi: current point */
+    __device__ __forceinline__ bool acceptable(bool okt, double th_t, double ph_t, double th_ref, double phi, double alpha_test, double gphid, bool ftype,
+                                              double theta_max, double theta_min, int nfilt) const
+    {
+        if (!okt || th_t > theta_max) return false;
+        bool acc;
+        if (ftype && th_ref <= theta_min) acc = cmp_le(ph_t - phi, ETA_PHI*alpha_test*gphid, phi);
+        else acc = cmp_le(th_t, (1 - G_THETA)*th_ref, th_ref) || cmp_le(ph_t - phi, -G_PHI*th_ref, phi);
+        return acc && filter_ok(nfilt, th_t, ph_t);
+    }
+
     /* ---------------------------------------------------------------------------------------- */
     __device__ __forceinline__ void run(const double *scen, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
     {
         const int N = P.N;
-        n.i = c.tid;
-        n.ival = n.i < N;
+        const unsigned long long cyc0 = __builtin_readcyclecounter();
+        if (c.tid == 0) { c.misc[1] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
+        c.tmark = cyc0;
         const double t0 = scen[MSD_SC_T0], tEnd = scen[MSD_SC_TEND], v0sq = scen[MSD_SC_V0SQ], vNsq = scen[MSD_SC_VNSQ];
 
-        /* ---- static data of the node: profile (coalesced reads), bounds (ocp.py:175-181, 247-272) ---- */
-        n.ds = n.ival ? P.ds[n.i] : 0.0;
-        n.G = n.ival ? track_resistance(P, P.grad[n.i], P.curv[n.i]) : 0.0;
+        /* ---- static data of the nodes: profile (coalesced reads), bounds (ocp.py:175-181, 247-272) ---- */
 #pragma unroll
-        for (int k = 0; k < NV; k++) { n.lb[k] = -INFINITY; n.ub[k] = INFINITY; n.on[k] = false; n.hasL[k] = n.hasU[k] = false; }
-        if (n.i <= N) {
-            n.on[VT] = n.on[VB] = true;
-            n.on[VF] = n.on[VS] = n.ival; n.on[VP] = n.ival && P.withPn;
-            n.lb[VF] = P.fmin; n.ub[VF] = P.fmax; n.lb[VP] = P.fminPn; n.ub[VP] = 0; n.lb[VS] = 0;
-            if (n.i == 0) { n.lb[VT] = n.ub[VT] = t0; n.lb[VB] = n.ub[VB] = v0sq; }
-            else if (n.i == N) { n.lb[VT] = t0; n.ub[VT] = tEnd; n.lb[VB] = n.ub[VB] = vNsq; }
-            else { n.lb[VT] = t0; n.ub[VT] = tEnd; n.lb[VB] = P.vminSq; n.ub[VB] = P.bmax[n.i]; }
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-                if (!n.on[k]) continue;
-                if (n.lb[k] == n.ub[k]) { n.on[k] = false; continue; }      /* fixed variables are parameters */
-                n.hasL[k] = isfinite(n.lb[k]); n.hasU[k] = isfinite(n.ub[k]);
-                if (n.hasL[k]) n.lb[k] -= K_BOUND_RELAX*fmax(1.0, fabs(n.lb[k]));
-                if (n.hasU[k]) n.ub[k] += K_BOUND_RELAX*fmax(1.0, fabs(n.ub[k]));
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) { R.on[r] = false; R.dL[r] = -INFINITY; R.dU[r] = INFINITY; R.rs[r] = 1.0; R.hasL[r] = R.hasU[r] = false; }
-        if (P.hasPower) { R.on[RPW0] = R.on[RPW1] = true; R.dL[RPW0] = R.dL[RPW1] = -fabs(P.pwL); R.dU[RPW0] = R.dU[RPW1] = fabs(P.pwU); }
-        R.on[RACC] = true; R.dL[RACC] = P.accMin; R.dU[RACC] = P.accMax;
-        if (P.energyOpt) { R.on[RLTR] = R.on[RLRG] = true; R.dL[RLTR] = R.dL[RLRG] = 0; }
-
-        /* ---- cold start (ocp.py:325-339) ---- */
-        {
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            Node &nd = n[j];
+            nd.i = c.tid + j*c.nt;
+            const bool ival = nd.i < N, node = nd.i <= N;
+            nd.ds = ival ? P.ds[nd.i] : 0.0;
+            nd.G = ival ? track_resistance(P, P.grad[nd.i], P.curv[nd.i]) : 0.0;
+            const double bm = (nd.i >= 1 && nd.i < N) ? P.bmax[nd.i] : INFINITY;
+            unsigned fl = (ival ? F_IVAL : 0u) | (node ? F_NODE : 0u);
+            /* fixed variables (lb == ub) are parameters of the NLP: x_0, b_N (fixed_variable_treatment = make_parameter) */
+            if (nd.i >= 1 && node && t0 != tEnd) fl |= F_ON_T;
+            if (nd.i >= 1 && nd.i < N && P.vminSq != bm) fl |= F_ON_B;
+            if (ival && P.fmin != P.fmax) fl |= F_ON_F;
+            if (ival && P.withPn && P.fminPn != 0.0) fl |= F_ON_P;
+            if (ival) fl |= F_ON_S;
+            nd.flags = fl;
+            nd.ubB = bm + K_BOUND_RELAX*fmax(1.0, fabs(bm));
+            /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
-            n.x[VT] = t0 + dt*n.i; n.x[VB] = vel0; n.x[VF] = 0.5; n.x[VP] = P.withPn ? -0.1 : 0.0; n.x[VS] = 1;
-            if (n.i == 0) { n.x[VT] = t0; n.x[VB] = v0sq; }
-            if (n.i == N) n.x[VB] = vNsq;
+            nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = P.withPn ? -0.1 : 0.0; nd.x[VS] = 1;
+            if (nd.i == 0) { nd.x[VT] = t0; nd.x[VB] = v0sq; }
+            if (nd.i == N) nd.x[VB] = vNsq;
+#pragma unroll
+            for (int k = 0; k < NV; k++) nd.zL[k] = nd.zU[k] = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { nd.sg[r] = nd.nu[r] = nd.zLs[r] = nd.zUs[r] = 0; nd.dsg[r] = 0; }
+            nd.lam[0] = nd.lam[1] = 0;
+            nd.sct = nd.scb = 1;
         }
+        U.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); U.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
+        U.blo = P.vminSq - K_BOUND_RELAX*fmax(1.0, fabs(P.vminSq));
+        U.flo = P.fmin - K_BOUND_RELAX*fmax(1.0, fabs(P.fmin)); U.fhi = P.fmax + K_BOUND_RELAX*fmax(1.0, fabs(P.fmax));
+        U.plo = P.fminPn - K_BOUND_RELAX*fmax(1.0, fabs(P.fminPn)); U.phi = K_BOUND_RELAX;
+        U.slo = -K_BOUND_RELAX;
 #pragma unroll
-        for (int k = 0; k < NV; k++) { n.zL[k] = n.zU[k] = 0; n.dx[k] = 0; }
-#pragma unroll
-        for (int r = 0; r < NR; r++) { n.sg[r] = n.nu[r] = n.zLs[r] = n.zUs[r] = 0; n.dsg[r] = n.dnu[r] = 0; resd[r] = 0; }
-        n.lam[0] = n.lam[1] = 0; n.dlam[0] = n.dlam[1] = 0; resc[0] = resc[1] = 0;
-        n.sct = n.scb = 1; sf = 1;
+        for (int r = 0; r < NR; r++) { U.rowOn[r] = false; U.dL[r] = -INFINITY; U.dU[r] = INFINITY; U.rs[r] = 1.0; U.rL[r] = U.rU[r] = false; }
+        if (P.hasPower) { U.rowOn[RPW0] = U.rowOn[RPW1] = true; U.dL[RPW0] = U.dL[RPW1] = -fabs(P.pwL); U.dU[RPW0] = U.dU[RPW1] = fabs(P.pwU); }
+        U.rowOn[RACC] = true; U.dL[RACC] = P.accMin; U.dU[RACC] = P.accMax;
+        if (P.energyOpt) { U.rowOn[RLTR] = U.rowOn[RLRG] = true; U.dL[RLTR] = U.dL[RLRG] = 0; }
+        U.sf = 1;
 
-        /* ---- gradient-based scaling at the starting point (max gradient 100) ---- */
-        publish(n.x);
+        /* ---- gradient-based scaling at the starting point (nlp_scaling_max_gradient = 100) ---- */
+        Ev e[SPT];
+        evaluate_current(e);
         {
             double gmax = 0, rmax[NR] = {0, 0, 0, 0, 0};
-            if (n.ival) {
-                eval_interval<true>(P, R, n, n.x, c.xt[c.tid + 1], c.xb[c.tid + 1], e);
-                double of, op, os, oq, off, opp;
-                obj_grads(nb_q(), of, op, os, oq, off, opp);
-                gmax = fmax(fabs(of), fmax(fabs(op), fabs(os)));
-                double mb = (n.i == N - 1) ? 0.0 : 1.0;
-                if (n.i > 0) mb = fmax(mb, fabs(e.Bb));
-                mb = fmax(mb, fabs(e.Bw));
-                n.scb = mb > 100 ? 100/mb : 1;
-                double mt = 1.0;
-                if (n.i > 0) mt = fmax(mt, fabs(e.tb));
-                mt = fmax(mt, fabs(e.tw));
-                n.sct = mt > 100 ? 100/mt : 1;
-                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                row_grads(n.x[VF], gb, gf, gp, gs, gb1);
 #pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    double m = fmax(fabs(gf[r]), fmax(fabs(gp[r]), fabs(gs[r])));
-                    if (n.i > 0) m = fmax(m, fabs(gb[r]));
-                    if (n.i < N - 1) m = fmax(m, fabs(gb1[r]));
-                    rmax[r] = m;
-                }
-            } else if (n.i == N && !P.energyOpt) gmax = 1.0/P.objDen;
+            for (int j = 0; j < SPT; j++) {
+                node_fence();
+                Node &nd = n[j];
+                if (nd.ival()) {
+                    double of, op, os, oq, off, opp;
+                    obj_grads(j, nb_q(j), of, op, os, oq, off, opp);
+                    gmax = fmax(gmax, fmax(fabs(of), fmax(fabs(op), fabs(os))));
+                    double mb = (nd.i == N - 1) ? 0.0 : 1.0;
+                    if (nd.i > 0) mb = fmax(mb, fabs(e[j].Bb));
+                    mb = fmax(mb, fabs(e[j].Bw));
+                    nd.scb = mb > 100 ? 100/mb : 1;
+                    double mt = 1.0;
+                    if (nd.i > 0) mt = fmax(mt, fabs(e[j].tb));
+                    mt = fmax(mt, fabs(e[j].tw));
+                    nd.sct = mt > 100 ? 100/mt : 1;
+                    double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
+                    row_grads(j, e[j], gb, gf, gp, gs, gb1);
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        double m = fmax(fabs(gf[r]), fmax(fabs(gp[r]), fabs(gs[r])));
+                        if (nd.i > 0) m = fmax(m, fabs(gb[r]));
+                        if (nd.i < N - 1) m = fmax(m, fabs(gb1[r]));
+                        rmax[r] = fmax(rmax[r], m);
+                    }
+                } else if (nd.i == N && !P.energyOpt) gmax = fmax(gmax, 1.0/P.objDen);
+            }
             double v[6] = {gmax, rmax[0], rmax[1], rmax[2], rmax[3], rmax[4]};
             block_reduce<6>(v, OpMax(), c);
-            if (v[0] > 100) sf = 100/v[0];
+            if (uni(v[0]) > 100) U.sf = uni(100/v[0]);
 #pragma unroll
-            for (int r = 0; r < NR; r++) if (R.on[r] && v[1 + r] > 100) R.rs[r] = 100/v[1 + r];
+            for (int r = 0; r < NR; r++) if (U.rowOn[r] && uni(v[1 + r]) > 100) U.rs[r] = uni(100/v[1 + r]);
         }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            if (!R.on[r]) continue;
-            R.dL[r] *= R.rs[r]; R.dU[r] *= R.rs[r];
-            R.hasL[r] = isfinite(R.dL[r]); R.hasU[r] = isfinite(R.dU[r]);
-            if (R.hasL[r]) R.dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(R.dL[r]));
-            if (R.hasU[r]) R.dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(R.dU[r]));
+            if (!U.rowOn[r]) continue;
+            U.dL[r] *= U.rs[r]; U.dU[r] *= U.rs[r];
+            U.rL[r] = isfinite(U.dL[r]); U.rU[r] = isfinite(U.dU[r]);
+            if (U.rL[r]) U.dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(U.dL[r]));
+            if (U.rU[r]) U.dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(U.dU[r]));
         }
 
         /* ---- push into the interior, slacks, bound multipliers ---- */
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            if (!n.on[k]) continue;
-            n.x[k] = push_in(n.x[k], n.lb[k], n.ub[k], n.hasL[k], n.hasU[k]);
-            n.zL[k] = n.hasL[k] ? 1.0 : 0.0; n.zU[k] = n.hasU[k] ? 1.0 : 0.0;
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if (!n[j].on(k)) continue;
+                n[j].x[k] = push_in(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k));
+                n[j].zL[k] = 1.0; n[j].zU[k] = hasU(k) ? 1.0 : 0.0;
+            }
         }
-        publish(n.x);
-        if (n.ival) {
-            eval_interval<true>(P, R, n, n.x, c.xt[c.tid + 1], c.xb[c.tid + 1], e);
+        evaluate_current(e);     /* resd = d(x) since the slacks are still zero */
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            if (!n[j].ival()) continue;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                if (!R.on[r]) continue;
-                n.sg[r] = push_in(e.d[r], R.dL[r], R.dU[r], R.hasL[r], R.hasU[r]);
-                n.zLs[r] = R.hasL[r] ? 1.0 : 0.0; n.zUs[r] = R.hasU[r] ? 1.0 : 0.0;
+                if (!U.rowOn[r]) continue;
+                n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], U.rL[r], U.rU[r]);
+                n[j].zLs[r] = U.rL[r] ? 1.0 : 0.0; n[j].zUs[r] = U.rU[r] ? 1.0 : 0.0;
+                resd[j][r] -= n[j].sg[r];
             }
         }
 
-        mu = K_MU_INIT; tau = fmax(K_TAU_MIN, 1 - mu);
+        double mu = K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
         {
-            bool ok = direction<MODE_LSQ>(0.0, 0.0);
+            const bool ok = direction(e, MODE_LSQ, 0.0, 0.0);
             double lmax = 0;
-            if (ok && n.ival) {
-                lmax = fmax(fabs(n.dlam[0])/n.sct, fabs(n.dlam[1])/n.scb);
+            Dir dd[SPT];
 #pragma unroll
-                for (int r = 0; r < NR; r++) if (R.on[r]) lmax = fmax(lmax, fabs(n.dnu[r]));
+            for (int j = 0; j < SPT; j++) {
+                load_dir(j, dd[j]);
+                if (ok && n[j].ival()) {
+                    lmax = fmax(lmax, fmax(fabs(dd[j].lt)/n[j].sct, fabs(dd[j].lb)/n[j].scb));
+#pragma unroll
+                    for (int r = 0; r < NR; r++) if (U.rowOn[r]) lmax = fmax(lmax, fabs(n[j].dsg[r]));
+                }
             }
             double v[1] = {lmax};
             block_reduce<1>(v, OpMax(), c);
-            const bool use = ok && v[0] <= LAM_INIT_MAX && isfinite(v[0]);
-            n.lam[0] = use ? n.dlam[0] : 0.0; n.lam[1] = use ? n.dlam[1] : 0.0;
+            const double lm = uni(v[0]);
+            const bool use = ok && lm <= LAM_INIT_MAX && isfinite(lm);
 #pragma unroll
-            for (int r = 0; r < NR; r++) n.nu[r] = (use && R.on[r] && n.ival) ? n.dnu[r] : 0.0;
+            for (int j = 0; j < SPT; j++) {
+                Node &nd = n[j];
+                const bool tk = use && nd.ival();
+                nd.lam[0] = tk ? dd[j].lt : 0.0; nd.lam[1] = tk ? dd[j].lb : 0.0;
 #pragma unroll
-            for (int k = 0; k < NV; k++) n.dx[k] = 0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) { n.dsg[r] = 0; n.dnu[r] = 0; }
-            n.dlam[0] = n.dlam[1] = 0;
+                for (int r = 0; r < NR; r++) { nd.nu[r] = (tk && U.rowOn[r]) ? nd.dsg[r] : 0.0; nd.dsg[r] = 0; }
+            }
         }
 
-        /* ---- filter ---- */
-        double theta, phi; bool okp;
-        merit(0.0, mu, theta, phi, okp, nullptr, nullptr, nullptr);
-        const double theta_max = 1e4*fmax(1.0, theta), theta_min = 1e-4*fmax(1.0, theta);
         int nfilt = 0;
-        double delta_last = 0;
-
+        double delta_last = 0, theta_max = 0, theta_min = 0;
         int status = MSD_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
         int n_reg = 0, n_soc = 0, n_back = 0;
-        Err E; E.dual = E.primal = E.primal_u = 0; E.cmax = E.cmin = 0; E.sd = E.sc = 1;
+        Err E;
         double alpha_pr = 0, alpha_du = 0, dnorm = 0, objv = 0;
         const double mu_floor = fmin(P.tol, 1e-4)/(K_EPS + 1.0);
 
         for (iter = 0;; iter++) {
-            publish(n.x);
-            if (n.ival) eval_interval<true>(P, R, n, n.x, c.xt[c.tid + 1], c.xb[c.tid + 1], e);
-            kkt_error(E);
-            {
-                double v[1] = {(n.i <= N) ? objective_term(P, n, n.x, nb_q(), sf) : 0.0};
-                block_reduce<1>(v, OpSum(), c);
-                objv = v[0]/sf;
-            }
+            c.mark(PH_OTHER); phase_fence();
+            if (iter > 0) evaluate_current(e);
+            c.mark(PH_EVAL); phase_fence();
+            kkt_pass(e, E);
+            c.mark(PH_KKT); phase_fence();
+            objv = E.obj/U.sf;
+            if (iter == 0) { theta_max = 1e4*fmax(1.0, E.theta); theta_min = 1e-4*fmax(1.0, E.theta); }
             if (hist && c.tid == 0 && iter < hist_cap) {
                 double *hh = hist + HIST_COLS*iter;
                 hh[0] = iter; hh[1] = objv; hh[2] = E.primal; hh[3] = E.dual; hh[4] = log10(mu); hh[5] = dnorm; hh[6] = alpha_du; hh[7] = alpha_pr;
             }
             const double E0 = total_err(E, 0.0);
-            const double dual_u = E.dual/sf, compl_u = compl_err(E, 0.0)/sf;
+            const double dual_u = E.dual/U.sf, compl_u = compl_err(E, 0.0)/U.sf;
             if (E0 <= P.tol && dual_u <= 1.0 && E.primal_u <= 1e-4 && compl_u <= 1e-4) { status = MSD_STATUS_SOLVED; break; }
             if (E0 <= ACC_TOL && dual_u <= 1e10 && E.primal_u <= 1e-2 && compl_u <= 1e-2) { if (++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
             else acc_count = 0;
             if (iter >= P.maxIter) { status = MSD_STATUS_MAXITER; break; }
             if (!isfinite(E0)) { status = MSD_STATUS_NUMERIC; break; }
 
-            /* barrier parameter (monotone, W&B eq. (7)); E_mu only differs from E_0 in the complementarity part */
+            /* barrier parameter (monotone, W&B eq. (7)); E_mu differs from E_0 only in the complementarity part */
             {
                 bool changed = false;
                 while (total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {
-                    double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, pow(mu, K_MU_SUP)));
+                    const double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, pow(mu, K_MU_SUP)));
                     if (nm >= mu) break;
                     mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = true;
                 }
                 if (changed) nfilt = 0;
             }
-            merit(0.0, mu, theta, phi, okp, nullptr, nullptr, nullptr);
+            const double theta = E.theta, phi = E.obj - mu*E.L + K_D*mu*E.D;
 
-            /* search direction with inertia correction (W&B Algorithm IC) */
-            resc[0] = n.ival ? e.c[0] : 0.0; resc[1] = n.ival ? e.c[1] : 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) resd[r] = (n.ival && R.on[r]) ? e.d[r] - n.sg[r] : 0.0;
+            /* search direction with inertia correction (W&B Algorithm IC); one call site */
             double dw = 0;
-            bool ok = direction<MODE_NEWTON>(mu, 0.0);
-            if (!ok) {
-                n_reg++;
-                dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last);
-                for (;;) {
-                    ok = direction<MODE_NEWTON>(mu, dw);
-                    if (ok) break;
-                    dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
-                    if (dw > DW_MAX) break;
-                }
-                if (!ok) { status = MSD_STATUS_REGULARIZATION; break; }
-                delta_last = dw;
+            bool ok;
+            for (bool first = true;; first = false) {
+                ok = direction(e, MODE_NEWTON, mu, dw);
+                if (ok) break;
+                if (first) { n_reg++; dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last); }
+                else dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
+                if (dw > DW_MAX) break;
             }
+            if (!ok) { status = MSD_STATUS_REGULARIZATION; break; }
+            if (dw > 0) delta_last = dw;
 
             /* directional derivative of the barrier function, step norms */
             double gphid, rel_step;
             {
                 double gd = 0, dn = 0, rel = 0;
-                double of = 0, op = 0, os = 0, oq = 0, off = 0, opp = 0;
-                if (n.i <= N) obj_grads(nb_q(), of, op, os, oq, off, opp);
-                /* d(obj)/dq of the next interval belongs to this node's f (barrier in uniform control flow) */
-                c.o1[c.tid] = oq;
+                double og[SPT][NV];
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    node_fence();
+                    double of = 0, op = 0, os = 0, oq = 0, off = 0, opp = 0;
+                    if (n[j].node()) obj_grads(j, nb_q(j), of, op, os, oq, off, opp);
+                    og[j][VT] = (n[j].i == N && !P.energyOpt) ? U.sf/P.objDen : 0.0; og[j][VB] = 0; og[j][VF] = of; og[j][VP] = op; og[j][VS] = os;
+                    /* d(obj)/dq of the next interval belongs to this node's f */
+                    c.o1[n[j].i] = oq;
+                }
                 __syncthreads();
-                if (n.i <= N) {
-                    double og[NV] = {(n.i == N && !P.energyOpt) ? sf/P.objDen : 0.0, 0.0, of, op, os};
-                    if (n.i + 1 < N) og[VF] += c.o1[c.tid + 1];
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    node_fence();
+                    const Node &nd = n[j];
+                    if (!nd.node()) continue;
+                    if (nd.i + 1 < N) og[j][VF] += c.o1[nd.i + 1];
+                    Dir dd; load_dir(j, dd);
 #pragma unroll
                     for (int k = 0; k < NV; k++) {
-                        if (!n.on[k]) continue;
-                        double Sg, gp; bar_terms(n.x[k], n.lb[k], n.ub[k], n.hasL[k], n.hasU[k], n.zL[k], n.zU[k], mu, Sg, gp);
-                        gd += (og[k] + gp)*n.dx[k];
-                        dn = fmax(dn, fabs(n.dx[k])); rel = fmax(rel, fabs(n.dx[k])/(1 + fabs(n.x[k])));
+                        if (!nd.on(k)) continue;
+                        double Sg, gp; var_terms(j, k, mu, Sg, gp);
+                        gd += (og[j][k] + gp)*dd.dx[k];
+                        dn = fmax(dn, fabs(dd.dx[k])); rel = fmax(rel, fabs(dd.dx[k])/(1 + fabs(nd.x[k])));
                     }
-                    if (n.ival) {
+                    if (nd.ival()) {
 #pragma unroll
                         for (int r = 0; r < NR; r++) {
-                            if (!R.on[r]) continue;
-                            double Sg, gp; bar_terms(n.sg[r], R.dL[r], R.dU[r], R.hasL[r], R.hasU[r], n.zLs[r], n.zUs[r], mu, Sg, gp);
-                            gd += gp*n.dsg[r];
-                            dn = fmax(dn, fabs(n.dsg[r])); rel = fmax(rel, fabs(n.dsg[r])/(1 + fabs(n.sg[r])));
+                            if (!U.rowOn[r]) continue;
+                            double Sg, gp; row_terms(j, r, mu, Sg, gp);
+                            gd += gp*nd.dsg[r];
+                            dn = fmax(dn, fabs(nd.dsg[r])); rel = fmax(rel, fabs(nd.dsg[r])/(1 + fabs(nd.sg[r])));
                         }
                     }
                 }
                 double v1[1] = {gd}; block_reduce<1>(v1, OpSum(), c);
                 double v2[2] = {dn, rel}; block_reduce<2>(v2, OpMax(), c);
-                gphid = v1[0]; dnorm = v2[0]; rel_step = v2[1];
+                gphid = uni(v1[0]); dnorm = uni(v2[0]); rel_step = uni(v2[1]);
             }
+            c.mark(PH_GPHID); phase_fence();
 
             double amax;
             step_lengths(mu, tau, amax, alpha_du);
+            c.mark(PH_STEPLEN); phase_fence();
 
             const bool tiny = rel_step < 10*DBL_EPSILON;
             double alpha = amax;
-            bool accepted = false, ftype_armijo = false, took_soc = false;
-            /* point to be accepted */
-            double xacc[NV], sacc[NR];
+            bool accepted = false, ftype_armijo = false;
             if (tiny) {
                 accepted = true;
-                double th_t, ph_t; bool okt;
-                merit(alpha, mu, th_t, ph_t, okt, nullptr, &xacc, &sacc);
                 if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { status = MSD_STATUS_TINY_STEP; break; }
             } else tiny_count = 0;
 
@@ -1004,51 +1230,37 @@ struct Solver {
             }
             amin *= ALPHA_MIN_FRAC;
 
-            /* saved Newton direction for the case a second-order correction replaces it */
             int ls = 0;
             while (!accepted) {
-                double th_t, ph_t; bool okt; Ev et;
-                merit(alpha, mu, th_t, ph_t, okt, &et, &xacc, &sacc);
+                double th_t, ph_t; bool okt;
+                merit(alpha, mu, th_t, ph_t, okt);
                 const bool ftype = (gphid < 0) && (alpha*pow(-gphid, S_PHI) > K_DELTA*pow(theta, S_THETA));
-                bool acc = false;
-                if (okt && th_t <= theta_max) {
-                    if (ftype && theta <= theta_min) acc = cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
-                    else acc = cmp_le(th_t, (1 - G_THETA)*theta, theta) || cmp_le(ph_t - phi, -G_PHI*theta, phi);
-                    if (acc) acc = filter_ok(nfilt, th_t, ph_t);
+                if (acceptable(okt, th_t, ph_t, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
+                    accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
+                    break;
                 }
-                if (acc) { accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi); break; }
-
-                /* second-order correction (W&B section 2.4) */
+                /* second-order correction (W&B section 2.4): rare, kept out of the hot path */
                 if (ls == 0 && okt && th_t >= theta) {
-                    const double th_old = theta; double th_prev = th_t; int nsoc = 0;
-                    /* keep the Newton step */
-                    double sdx[NV], sdsg[NR], sdlam[2], sdnu[NR], src[2], srd[NR];
-#pragma unroll
-                    for (int k = 0; k < NV; k++) sdx[k] = n.dx[k];
-#pragma unroll
-                    for (int r = 0; r < NR; r++) { sdsg[r] = n.dsg[r]; sdnu[r] = n.dnu[r]; srd[r] = resd[r]; }
-                    sdlam[0] = n.dlam[0]; sdlam[1] = n.dlam[1]; src[0] = resc[0]; src[1] = resc[1];
-                    double alpha_soc = alpha;
+                    double th_prev = th_t, alpha_soc = alpha; int nsoc = 0;
                     while (nsoc < P_MAX_SOC) {
                         /* c_soc = alpha_soc c_soc + c(trial) */
-                        resc[0] = alpha_soc*resc[0] + (n.ival ? et.c[0] : 0.0); resc[1] = alpha_soc*resc[1] + (n.ival ? et.c[1] : 0.0);
+                        double tc[SPT][2], td[SPT][NR];
+                        trial_residuals(alpha_soc, tc, td);
 #pragma unroll
-                        for (int r = 0; r < NR; r++) if (n.ival && R.on[r]) resd[r] = alpha_soc*resd[r] + (et.d[r] - sacc[r]);
-                        publish(n.x);          /* the neighbours' Fel in LDS are those of the trial point */
-                        if (!direction<MODE_NEWTON>(mu, dw)) break;
+                        for (int j = 0; j < SPT; j++) {
+                            resc[j][0] = alpha_soc*resc[j][0] + tc[j][0]; resc[j][1] = alpha_soc*resc[j][1] + tc[j][1];
+#pragma unroll
+                            for (int r = 0; r < NR; r++) resd[j][r] = alpha_soc*resd[j][r] + td[j][r];
+                        }
+                        publish_current();     /* the neighbours' Fel in LDS are those of the trial point */
+                        if (!direction(e, MODE_NEWTON, mu, dw)) break;
                         double adu_soc;
                         step_lengths(mu, tau, alpha_soc, adu_soc);
                         double th_s, ph_s; bool oks;
-                        merit(alpha_soc, mu, th_s, ph_s, oks, &et, &xacc, &sacc);
+                        merit(alpha_soc, mu, th_s, ph_s, oks);
                         nsoc++; n_soc++;
-                        bool accs = false;
-                        if (oks && th_s <= theta_max) {
-                            if (ftype && th_old <= theta_min) accs = cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
-                            else accs = cmp_le(th_s, (1 - G_THETA)*th_old, th_old) || cmp_le(ph_s - phi, -G_PHI*th_old, phi);
-                            if (accs) accs = filter_ok(nfilt, th_s, ph_s);
-                        }
-                        if (accs) {
-                            accepted = true; took_soc = true; ftype_armijo = ftype && cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
+                        if (acceptable(oks, th_s, ph_s, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
+                            accepted = true; ftype_armijo = ftype && cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
                             alpha = alpha_soc; alpha_du = adu_soc;
                             break;
                         }
@@ -1056,19 +1268,18 @@ struct Solver {
                         th_prev = th_s;
                     }
                     if (accepted) break;
-                    /* back to the Newton step */
-#pragma unroll
-                    for (int k = 0; k < NV; k++) n.dx[k] = sdx[k];
-#pragma unroll
-                    for (int r = 0; r < NR; r++) { n.dsg[r] = sdsg[r]; n.dnu[r] = sdnu[r]; resd[r] = srd[r]; }
-                    n.dlam[0] = sdlam[0]; n.dlam[1] = sdlam[1]; resc[0] = src[0]; resc[1] = src[1];
+                    /* back to the Newton step: recompute it */
+                    evaluate_current(e);
+                    direction(e, MODE_NEWTON, mu, dw);
+                    double apr_dummy;
+                    step_lengths(mu, tau, apr_dummy, alpha_du);
                 }
                 alpha *= 0.5; ls++; n_back++;
                 if (alpha < amin) break;
             }
             if (!accepted) { status = MSD_STATUS_LINESEARCH; break; }
             alpha_pr = alpha;
-            (void)took_soc;
+            c.mark(PH_MERIT); phase_fence();
 
             /* filter augmentation (W&B eq. (22)) */
             if (!tiny && !ftype_armijo && nfilt < FILT_CAP) {
@@ -1078,90 +1289,96 @@ struct Solver {
                 __syncthreads();
             }
 
-            /* accept the trial point; multipliers: equality with the primal step, bounds with alpha_du (of the accepted direction) */
-            if (n.i <= N) {
+            /* accept x + alpha d; multipliers: equalities with the primal step, bounds with alpha_du (of the accepted direction) */
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                node_fence();
+                Node &nd = n[j];
+                if (!nd.node()) continue;
+                Dir dd; load_dir(j, dd);
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    if (!n.on[k]) continue;
-                    const double dzl = n.hasL[k] ? dzL_var(k, mu) : 0.0, dzu = n.hasU[k] ? dzU_var(k, mu) : 0.0;
-                    n.x[k] = xacc[k];
-                    if (n.hasL[k]) n.zL[k] += alpha_du*dzl;
-                    if (n.hasU[k]) n.zU[k] += alpha_du*dzu;
+                    if (!nd.on(k)) continue;
+                    const double dzl = dzL_var(j, k, mu, dd.dx[k]), dzu = hasU(k) ? dzU_var(j, k, mu, dd.dx[k]) : 0.0;
+                    nd.x[k] += alpha_pr*dd.dx[k];
+                    nd.zL[k] += alpha_du*dzl;
+                    if (hasU(k)) nd.zU[k] += alpha_du*dzu;
+                    /* keep Sigma within [mu/(kappa_Sigma s), kappa_Sigma mu/s] (W&B eq. (16)) */
+                    { const double s = nd.x[k] - lbv(k); nd.zL[k] = fmax(fmin(nd.zL[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                    if (hasU(k)) { const double s = ubv(j, k) - nd.x[k]; nd.zU[k] = fmax(fmin(nd.zU[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
                 }
-                if (n.ival) {
+                if (nd.ival()) {
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        if (!R.on[r]) continue;
-                        const double dzl = R.hasL[r] ? dzL_row(r, mu) : 0.0, dzu = R.hasU[r] ? dzU_row(r, mu) : 0.0;
-                        n.sg[r] = sacc[r];
-                        n.nu[r] += alpha_pr*n.dnu[r];
-                        if (R.hasL[r]) n.zLs[r] += alpha_du*dzl;
-                        if (R.hasU[r]) n.zUs[r] += alpha_du*dzu;
+                        if (!U.rowOn[r]) continue;
+                        const double dzl = U.rL[r] ? dzL_row(j, r, mu) : 0.0, dzu = U.rU[r] ? dzU_row(j, r, mu) : 0.0;
+                        /* new inequality multiplier nu+ = (Sigma + delta_w) dsigma + grad phi_sigma, at the old point */
+                        double Sg, gphi; row_terms(j, r, mu, Sg, gphi);
+                        const double dnu = (Sg + dw)*nd.dsg[r] + gphi - nd.nu[r];
+                        nd.sg[r] += alpha_pr*nd.dsg[r];
+                        nd.nu[r] += alpha_pr*dnu;
+                        if (U.rL[r]) { nd.zLs[r] += alpha_du*dzl; const double s = nd.sg[r] - U.dL[r]; nd.zLs[r] = fmax(fmin(nd.zLs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                        if (U.rU[r]) { nd.zUs[r] += alpha_du*dzu; const double s = U.dU[r] - nd.sg[r]; nd.zUs[r] = fmax(fmin(nd.zUs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
                     }
-                    n.lam[0] += alpha_pr*n.dlam[0]; n.lam[1] += alpha_pr*n.dlam[1];
-                }
-                /* keep Sigma within [mu/(kappa_Sigma s), kappa_Sigma mu/s] (W&B eq. (16)) */
-#pragma unroll
-                for (int k = 0; k < NV; k++) {
-                    if (!n.on[k]) continue;
-                    if (n.hasL[k]) { double s = n.x[k] - n.lb[k]; n.zL[k] = fmax(fmin(n.zL[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                    if (n.hasU[k]) { double s = n.ub[k] - n.x[k]; n.zU[k] = fmax(fmin(n.zU[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                }
-                if (n.ival) {
-#pragma unroll
-                    for (int r = 0; r < NR; r++) {
-                        if (!R.on[r]) continue;
-                        if (R.hasL[r]) { double s = n.sg[r] - R.dL[r]; n.zLs[r] = fmax(fmin(n.zLs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                        if (R.hasU[r]) { double s = R.dU[r] - n.sg[r]; n.zUs[r] = fmax(fmin(n.zUs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                    }
+                    nd.lam[0] += alpha_pr*(dd.lt - nd.lam[0]); nd.lam[1] += alpha_pr*(dd.lb - nd.lam[1]);
                 }
             }
+            c.mark(PH_UPDATE); phase_fence();
         }
 
         /* ---- outputs: z in the reference's layout (ocp.py:166-272), multipliers in the reference's row order ---- */
         const int stp = 4 + P.withPn;
-        if (n.ival) {
-            double *zi = z_out + stp*n.i; int k = 0;
-            zi[k++] = n.x[VF]; if (P.withPn) zi[k++] = n.x[VP];
-            zi[k++] = n.x[VS]; zi[k++] = n.x[VT]; zi[k++] = n.x[VB];
-            if (lam_out) {
-                const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
-                double *l = lam_out + rpi*n.i; int m = 0;
-                if (P.hasPower) { l[m++] = n.nu[RPW0]*R.rs[RPW0]/sf; l[m++] = n.nu[RPW1]*R.rs[RPW1]/sf; }
-                l[m++] = n.nu[RACC]*R.rs[RACC]/sf;
-                l[m++] = n.lam[0]/sf; l[m++] = n.lam[1]/sf;
-                if (P.energyOpt) { l[m++] = n.nu[RLTR]*R.rs[RLTR]/sf; l[m++] = n.nu[RLRG]*R.rs[RLRG]/sf; }
-            }
-        } else if (n.i == N) { z_out[stp*N] = n.x[VT]; z_out[stp*N + 1] = n.x[VB]; }
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence();
+            const Node &nd = n[j];
+            if (nd.ival()) {
+                double *zi = z_out + stp*nd.i; int k = 0;
+                zi[k++] = nd.x[VF]; if (P.withPn) zi[k++] = nd.x[VP];
+                zi[k++] = nd.x[VS]; zi[k++] = nd.x[VT]; zi[k++] = nd.x[VB];
+                if (lam_out) {
+                    const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
+                    double *l = lam_out + rpi*nd.i; int m = 0;
+                    if (P.hasPower) { l[m++] = nd.nu[RPW0]*U.rs[RPW0]/U.sf; l[m++] = nd.nu[RPW1]*U.rs[RPW1]/U.sf; }
+                    l[m++] = nd.nu[RACC]*U.rs[RACC]/U.sf;
+                    l[m++] = nd.lam[0]/U.sf; l[m++] = nd.lam[1]/U.sf;
+                    if (P.energyOpt) { l[m++] = nd.nu[RLTR]*U.rs[RLTR]/U.sf; l[m++] = nd.nu[RLRG]*U.rs[RLRG]/U.sf; }
+                }
+            } else if (nd.i == N) { z_out[stp*N] = nd.x[VT]; z_out[stp*N + 1] = nd.x[VB]; }
+        }
         if (c.tid == 0) {
             stats[MSD_ST_STATUS] = status; stats[MSD_ST_ITERS] = iter; stats[MSD_ST_OBJ] = objv;
-            stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/sf;
-            stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/sf;
+            stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/U.sf;
+            stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/U.sf;
             stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back;
+            stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1];
+            /* phase telemetry of the logged scenario: the last two rows of the history buffer */
+            if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
         }
         __syncthreads();
     }
 };
 
 /*
- * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64, >= N + 1).
- * Dynamic LDS: lds_doubles(N, NT) * 8 bytes.
+ * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64), NT*SPT >= N + 1.
+ * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT>
-__global__ void __launch_bounds__(NT, 2) solve_kernel(DevProb P, int nscen, const double *scen, double *z_out, double *lam_out, double *stats,
-                                                   double *hist, int hist_cap)
+template <int NT, int SPT, int WPS>
+__global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, double *z_out, double *lam_out, double *stats,
+                                                       double *hist, int hist_cap)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    constexpr int NS = NT*SPT;     /* node slots */
     Ctx c;
-    c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.red_slot = 0;
+    c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.nt = NT; c.red_slot = 0;
     c.S = lds;
-    c.xt = c.S + S_STRIDE*(P.N + 1); c.xb = c.xt + NT; c.xf = c.xb + NT;
-    c.o1 = c.xf + NT; c.o2 = c.o1 + NT; c.o3 = c.o2 + NT;
-    c.filt = c.o3 + NT; c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
+    c.xt = c.S + S_STRIDE*(P.N + 1); c.xb = c.xt + NS; c.xf = c.xb + NS;
+    c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
+    c.filt = c.o3 + NS; c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
     const int nz = (4 + P.withPn)*P.N + 2;
     const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
     for (int sidx = blockIdx.x; sidx < nscen; sidx += gridDim.x) {
-        Solver s(P, c);
+        Solver<SPT> s(P, c);
         s.run(scen + (size_t)MSD_SC_COUNT*sidx, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
               stats + (size_t)MSD_ST_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
         __syncthreads();

@@ -12,10 +12,10 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'
+LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
 ABI_VERSION = 1
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, COUNT=11)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, COUNT=13)
 SC_COUNT = 4
 HIST_COLS = 8
 

@@ -5,6 +5,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -13,21 +15,21 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT>
+template <int NT, int SPT>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT));
+        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT*SPT));
         blk.shfl = shfl.data(); blk.lds = lds.data();
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT>(P, nscen, scen, z, lam, stats, hist, cap);
+                msd::solve_kernel<NT, SPT, 1>(P, nscen, scen, z, lam, stats, hist, cap);
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -42,14 +44,20 @@ extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const doubl
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax;
-    int NT = ((P.N + 1 + 63)/64)*64;
-    switch (NT) {
-    case 64: run_blocks<64>(P, nscen, scen, z, lam, stats, hist, cap); break;
-    case 128: run_blocks<128>(P, nscen, scen, z, lam, stats, hist, cap); break;
-    case 192: run_blocks<192>(P, nscen, scen, z, lam, stats, hist, cap); break;
-    case 256: run_blocks<256>(P, nscen, scen, z, lam, stats, hist, cap); break;
-    case 320: run_blocks<320>(P, nscen, scen, z, lam, stats, hist, cap); break;
-    default: return -3;
-    }
+    const int nodes = P.N + 1;
+    const char *force = getenv("EMU_GEOMETRY");     /* "NTxSPT" to test other geometries */
+    int NT = 0, SPT = 0;
+    if (force) sscanf(force, "%dx%d", &NT, &SPT);
+    else if (nodes <= 64) { NT = 64; SPT = 1; }
+    else if (nodes <= 128) { NT = 64; SPT = 2; }
+    else if (nodes <= 256) { NT = 128; SPT = 2; }
+    else { NT = 192; SPT = 2; }
+    if (NT*SPT < nodes) return -3;
+    if (NT == 64 && SPT == 1) run_blocks<64, 1>(P, nscen, scen, z, lam, stats, hist, cap);
+    else if (NT == 64 && SPT == 2) run_blocks<64, 2>(P, nscen, scen, z, lam, stats, hist, cap);
+    else if (NT == 128 && SPT == 1) run_blocks<128, 1>(P, nscen, scen, z, lam, stats, hist, cap);
+    else if (NT == 128 && SPT == 2) run_blocks<128, 2>(P, nscen, scen, z, lam, stats, hist, cap);
+    else if (NT == 192 && SPT == 2) run_blocks<192, 2>(P, nscen, scen, z, lam, stats, hist, cap);
+    else return -3;
     return 0;
 }

@@ -48,3 +48,14 @@ static inline double __shfl_xor(double v, int mask)
 }
 
 using std::isfinite;
+
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+
+/* scalarisation intrinsics: identity on the host */
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int __double2loint(double d) { unsigned long long u; std::memcpy(&u, &d, 8); return (int)(u & 0xffffffffu); }
+static inline int __double2hiint(double d) { unsigned long long u; std::memcpy(&u, &d, 8); return (int)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) { unsigned long long u = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double d; std::memcpy(&d, &u, 8); return d; }
+
+#include <x86intrin.h>
+#define __builtin_readcyclecounter() ((unsigned long long)__rdtsc())
