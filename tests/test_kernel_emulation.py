@@ -1,0 +1,47 @@
+"""
+The device header ms-eetc_amd/csrc/msd_kernel.hpp compiled for the host (tests/hip_emu: one OS thread per GPU thread,
+pthread barriers) and compared with the oracle.  This checks the kernel's arithmetic and control flow on CPU -- and is what
+the sanitizer build (SAN=1 tests/hip_emu/build.sh) runs -- but not wave-level behaviour: barrier placement in divergent code
+can only be seen on the GPU (tests/test_gpu_parity.py).  Emulation is test tooling; the product never uses it.
+"""
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+
+EMU = Path(__file__).resolve().parent / 'hip_emu'
+
+
+@pytest.fixture(scope='module')
+def emu():
+    subprocess.run([str(EMU / 'build.sh')], check=True)
+    lib = ctypes.CDLL(str(EMU / 'libmsd_emu.so'))
+    from mseetc._device import ProblemDesc
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.emu_solve_batch.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize('N,crop,T', [(30, 12000, 520.0), (70, 30000, 1100.0)])
+def test_emulated_kernel_matches_oracle(emu, N, crop, T):
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00(crop)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(prob, prob.scenario(T))
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
+    assert np.max(np.abs(lam[0] - ref['lam_g'])) < 1e-7
