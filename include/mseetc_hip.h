@@ -62,6 +62,17 @@ enum {
     MSD_SC_COUNT
 };
 
+/* optional per-scenario rolling-stock record (BASELINE config 3: perturbed mass / Davis coefficients): MSD_OV_COUNT doubles.
+ * It replaces the corresponding fields of msd_problem_desc for that scenario -- what constructing a new
+ * Train(config={...}) + casadiSolver would change in the reference (train.py:44-62, ocp.py:96-116, 278). */
+enum {
+    MSD_OV_SR0 = 0, MSD_OV_SR1, MSD_OV_SR2,
+    MSD_OV_F_MAX, MSD_OV_F_MIN, MSD_OV_F_MIN_PN,
+    MSD_OV_PW_UPPER, MSD_OV_PW_LOWER,
+    MSD_OV_OBJ_DEN,
+    MSD_OV_COUNT
+};
+
 /*
  * Problem description = everything casadiSolver.__init__ derives from (train, track, options)
  * (ocp.py:96-125, 134-284): specific force/power/acceleration bounds, the shooting grid and the
@@ -128,6 +139,10 @@ int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, 
  * enqueued on the handle's stream; msd_synchronize() waits.  Used to time throughput with inputs in HBM.
  */
 int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats);
+
+/* msd_solve_batch with per-scenario rolling-stock overrides: overrides[nscen][MSD_OV_COUNT] (host), NULL = none */
+int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats,
+                       float *kernel_ms);
 int msd_synchronize(msd_handle h);
 
 /* device scratch management for callers without their own allocator (ctypes): */

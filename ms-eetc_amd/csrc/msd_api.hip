@@ -28,7 +28,7 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(MSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
-using KernelFn = void (*)(msd::DevProb, int, const double *, double *, double *, double *, double *, int);
+using KernelFn = void (*)(msd::DevProb, int, const double *, const double *, double *, double *, double *, double *, int);
 
 /* launch geometry by horizon length: NT threads, SPT shooting nodes per thread (NT*SPT >= N + 1) */
 struct Geometry { int NT, SPT; KernelFn fn; };
@@ -61,7 +61,7 @@ struct msd_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr;
     /* grow-only scratch of the host-buffer entry point */
-    double *d_scen = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr;
+    double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr;
     int cap_scen = 0;
     double *h_hist = nullptr;
     int hist_cap = 0;
@@ -148,7 +148,7 @@ int msd_problem_destroy(msd_handle h)
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
     hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax);
-    hipFree(h->d_scen); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist);
+    hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -159,10 +159,10 @@ int msd_problem_destroy(msd_handle h)
 int msd_problem_nz(msd_handle h) { return h ? (4 + h->P.withPn)*h->P.N + 2 : 0; }
 int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 : 0) + 3 + (h->P.energyOpt ? 2 : 0) : 0; }
 
-static int launch(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap)
+static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap)
 {
     const int grid = nscen < h->max_grid ? nscen : h->max_grid;
-    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, h->P, nscen, d_scen, d_z, d_lam, d_stats, d_hist, hist_cap);
+    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, h->P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap);
     HIP_TRY(hipGetLastError());
     return MSD_OK;
 }
@@ -171,7 +171,7 @@ int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double
 {
     if (!h || nscen < 1 || !d_scen || !d_z || !d_stats) return fail(MSD_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    return launch(h, nscen, d_scen, d_z, d_lam, d_stats, nullptr, 0);
+    return launch(h, nscen, d_scen, nullptr, d_z, d_lam, d_stats, nullptr, 0);
 }
 
 int msd_synchronize(msd_handle h)
@@ -191,7 +191,18 @@ int msd_set_history(msd_handle h, double *host_hist, int cap)
 
 int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, double *lam_out, double *stats, float *kernel_ms)
 {
+    return msd_solve_batch_ex(h, nscen, scen, nullptr, z_out, lam_out, stats, kernel_ms);
+}
+
+int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
     if (!h || nscen < 1 || !scen || !z_out || !stats) return fail(MSD_E_INVALID, "bad argument");
+    if (overrides)
+        for (int k = 0; k < nscen; k++) {
+            const double *o = overrides + (size_t)MSD_OV_COUNT*k;
+            if (!(o[MSD_OV_OBJ_DEN] > 0) || !(o[MSD_OV_F_MAX] > o[MSD_OV_F_MIN]) || !(o[MSD_OV_SR0] >= 0) || !(o[MSD_OV_SR1] >= 0) || !(o[MSD_OV_SR2] >= 0))
+                return fail(MSD_E_INVALID, "invalid rolling-stock override");
+        }
     for (int k = 0; k < nscen; k++) {
         const double *s = scen + (size_t)MSD_SC_COUNT*k;
         if (!(s[MSD_SC_T0] >= 0)) return fail(MSD_E_INVALID, "Initial time must be a positive number!");
@@ -201,9 +212,10 @@ int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, 
     HIP_TRY(hipSetDevice(h->device));
     const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
     if (nscen > h->cap_scen) {
-        hipFree(h->d_scen); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats);
-        h->d_scen = h->d_z = h->d_lam = h->d_stats = nullptr; h->cap_scen = 0;
+        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats);
+        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = nullptr; h->cap_scen = 0;
         HIP_TRY(hipMalloc((void **)&h->d_scen, sizeof(double)*MSD_SC_COUNT*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_ovr, sizeof(double)*MSD_OV_COUNT*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_z, sizeof(double)*nz*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_lam, sizeof(double)*nl*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen));
@@ -217,8 +229,9 @@ int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, 
         d_hist = h->d_hist;
     }
     HIP_TRY(hipMemcpyAsync(h->d_scen, scen, sizeof(double)*MSD_SC_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
+    if (overrides) HIP_TRY(hipMemcpyAsync(h->d_ovr, overrides, sizeof(double)*MSD_OV_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    int rc = launch(h, nscen, h->d_scen, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap);
+    int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap);
     if (rc != MSD_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));

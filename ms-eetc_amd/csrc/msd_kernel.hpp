@@ -1364,8 +1364,8 @@ struct Solver {
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  WPS = minimum waves per SIMD the register budget is planned for.
  */
 template <int NT, int SPT, int WPS>
-__global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, double *z_out, double *lam_out, double *stats,
-                                                       double *hist, int hist_cap)
+__global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
+                                                       double *stats, double *hist, int hist_cap)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     constexpr int NS = NT*SPT;     /* node slots */
@@ -1378,7 +1378,15 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     const int nz = (4 + P.withPn)*P.N + 2;
     const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
     for (int sidx = blockIdx.x; sidx < nscen; sidx += gridDim.x) {
-        Solver<SPT> s(P, c);
+        /* per-scenario rolling stock (uniform over the workgroup) */
+        DevProb Ps = P;
+        if (overrides) {
+            const double *o = overrides + (size_t)MSD_OV_COUNT*sidx;
+            Ps.sr0 = o[MSD_OV_SR0]; Ps.sr1 = o[MSD_OV_SR1]; Ps.sr2 = o[MSD_OV_SR2];
+            Ps.fmax = o[MSD_OV_F_MAX]; Ps.fmin = o[MSD_OV_F_MIN]; Ps.fminPn = o[MSD_OV_F_MIN_PN];
+            Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
+        }
+        Solver<SPT> s(Ps, c);
         s.run(scen + (size_t)MSD_SC_COUNT*sidx, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
               stats + (size_t)MSD_ST_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
         __syncthreads();

@@ -17,6 +17,7 @@ LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent
 ABI_VERSION = 1
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, COUNT=13)
 SC_COUNT = 4
+OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, COUNT=9)
 HIST_COLS = 8
 
 STATUS_TEXT = {0: 'Solve_Succeeded', 1: 'Solved_To_Acceptable_Level', -1: 'Maximum_Iterations_Exceeded',
@@ -69,6 +70,7 @@ def lib():
         L.msd_problem_nz.argtypes = [vp]
         L.msd_problem_rows_per_interval.argtypes = [vp]
         L.msd_solve_batch.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
+        L.msd_solve_batch_ex.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
         L.msd_synchronize.argtypes = [vp]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
@@ -144,8 +146,8 @@ class DeviceProblem():
         except Exception:
             pass
 
-    def solve_batch(self, scen, want_multipliers=False, history=0):
-        "scen: (B,4) host array (t0, T, v0sq, vNsq) -> dict(z, stats, lam_g, kernel_ms[, hist])"
+    def solve_batch(self, scen, want_multipliers=False, history=0, overrides=None):
+        "scen: (B,4) host array (t0, T, v0sq, vNsq), overrides: optional (B, OV['COUNT']) -> dict(z, stats, lam_g, kernel_ms[, hist])"
 
         L = lib()
         scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
@@ -160,7 +162,11 @@ class DeviceProblem():
             hist = np.zeros((int(history), HIST_COLS))
             _check(L.msd_set_history(self._h, _d(hist), int(history)))
 
-        _check(L.msd_solve_batch(self._h, B, _d(scen), _d(z), _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+        if overrides is not None:
+            overrides = np.ascontiguousarray(overrides, dtype=np.float64).reshape(B, OV['COUNT'])
+
+        _check(L.msd_solve_batch_ex(self._h, B, _d(scen), _d(overrides) if overrides is not None else None, _d(z),
+                                    _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
 
         out = dict(z=z, stats=st, lam_g=lam, kernel_ms=float(ms.value))
 

@@ -195,16 +195,54 @@ class casadiSolver():
 
         return np.stack([t0, T, v0**2, vN**2], axis=1)
 
-    def solveBatch(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1, multipliers=False):
+    def _overrides(self, B, mass, r0, r1, r2):
         """
-        Solve many scenarios of this problem in one launch.  Arguments broadcast against each other.
+        Per-scenario rolling stock: what a new `Train(config={'mass': ..., 'rolling resistance r0': ...})` + `casadiSolver`
+        would change (train.py:44-62, ocp.py:96-116, 278).  Limits given in newtons / watts stay, specific ones follow the mass.
+        """
+
+        if mass is None and r0 is None and r1 is None and r2 is None:
+            return None
+
+        tr = self.train
+        full = lambda a, default: np.broadcast_to(np.asarray(default if a is None else a, dtype=float), (B,)).copy()
+        mass, r0, r1, r2 = full(mass, tr.mass), full(r0, tr.r0), full(r1, tr.r1), full(r2, tr.r2)
+
+        if np.any(mass <= 0) or np.any(r0 < 0) or np.any(r1 < 0) or np.any(r2 < 0):
+            raise ValueError("Train mass must be positive and rolling resistance coefficients non-negative!")
+
+        M = mass*tr.rho
+        d = self._desc
+        ratio = self.totalMass/M      # specific bounds scale with 1/M; accInf-defaulted bounds (no limit given) do not
+        OV = _device.OV
+        out = np.zeros((B, OV['COUNT']))
+        out[:, OV['SR0']], out[:, OV['SR1']], out[:, OV['SR2']] = r0/M, r1/M, r2/M
+        out[:, OV['F_MAX']] = d.f_max*ratio if tr.forceMax is not None else d.f_max
+        out[:, OV['F_MIN']] = d.f_min*ratio if tr.forceMin is not None else d.f_min
+        out[:, OV['F_MIN_PN']] = d.f_min_pn*ratio if tr.forceMinPn is not None else d.f_min_pn
+        # power rows: P/M when a power limit is set, else force*vmax (ocp.py:186-187)
+        out[:, OV['PW_UPPER']] = d.pw_upper*ratio if (tr.powerMax is not None or tr.forceMax is not None) else d.pw_upper
+        out[:, OV['PW_LOWER']] = d.pw_lower*ratio if (tr.powerMin is not None or tr.forceMin is not None) else d.pw_lower
+        out[:, OV['OBJ_DEN']] = 3.6/(1e-6*M) if self.energyOptimal else d.obj_den
+
+        return out
+
+    def solveBatch(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1, multipliers=False,
+                   mass=None, r0=None, r1=None, r2=None):
+        """
+        Solve many scenarios of this problem in one launch.  Arguments broadcast against each other; `mass`, `r0`, `r1`, `r2`
+        (SI units, scalars or one value per scenario) perturb the rolling stock per scenario.
         Returns dict: 'z' (B, nz) in the reference's variable layout, 'status' (B,), 'iterations' (B,), 'cost' (B,)
         [kWh or s], 'stats' (raw records), 'kernel_ms', optionally 'lam_g'.
         """
 
         scen = self._scenarios(terminalTime, initialTime, terminalVelocity, initialVelocity)
 
-        out = self.problem.solve_batch(scen, want_multipliers=multipliers)
+        B = max([scen.shape[0]] + [np.size(a) for a in (mass, r0, r1, r2) if a is not None])
+        if scen.shape[0] != B:
+            scen = np.broadcast_to(scen, (B, scen.shape[1])).copy()
+
+        out = self.problem.solve_batch(scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2))
 
         st = out['stats']
         ST = _device.ST

@@ -16,7 +16,7 @@ thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
 template <int NT, int SPT>
-static void run_blocks(msd::DevProb P, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
+static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
         emu_block blk;
@@ -29,14 +29,19 @@ static void run_blocks(msd::DevProb P, int nscen, const double *scen, double *z,
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1>(P, nscen, scen, z, lam, stats, hist, cap);
+                msd::solve_kernel<NT, SPT, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
     }
 }
 
+extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap);
 extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
+{
+    return emu_solve_batch_ex(d, nscen, scen, nullptr, z, lam, stats, hist, cap);
+}
+extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
     P.N = d->num_intervals; P.withPn = d->with_pn_brake; P.hasPower = d->has_power_rows; P.energyOpt = d->energy_optimal;
@@ -53,11 +58,11 @@ extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const doubl
     else if (nodes <= 256) { NT = 128; SPT = 2; }
     else { NT = 192; SPT = 2; }
     if (NT*SPT < nodes) return -3;
-    if (NT == 64 && SPT == 1) run_blocks<64, 1>(P, nscen, scen, z, lam, stats, hist, cap);
-    else if (NT == 64 && SPT == 2) run_blocks<64, 2>(P, nscen, scen, z, lam, stats, hist, cap);
-    else if (NT == 128 && SPT == 1) run_blocks<128, 1>(P, nscen, scen, z, lam, stats, hist, cap);
-    else if (NT == 128 && SPT == 2) run_blocks<128, 2>(P, nscen, scen, z, lam, stats, hist, cap);
-    else if (NT == 192 && SPT == 2) run_blocks<192, 2>(P, nscen, scen, z, lam, stats, hist, cap);
+    if (NT == 64 && SPT == 1) run_blocks<64, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+    else if (NT == 64 && SPT == 2) run_blocks<64, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+    else if (NT == 128 && SPT == 1) run_blocks<128, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+    else if (NT == 128 && SPT == 2) run_blocks<128, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+    else if (NT == 192 && SPT == 2) run_blocks<192, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
     else return -3;
     return 0;
 }

@@ -152,3 +152,29 @@ def test_dataframe_surface():
     # infeasible running time -> failure is reported, not raised (ocp.py:364-370)
     df2, st2 = solver.solve(900)
     assert df2 is None and st2['Solver status'] != 'Solve_Succeeded'
+
+
+def test_config3_rolling_stock_perturbations_vs_oracle():
+    # BASELINE config 3: +-5 % (clipped at 2 sigma) perturbation of mass, r0, r1, r2 per scenario.  Reference mechanism:
+    # a new Train(config={...}) per scenario (train.py:44-62); here one launch with per-scenario overrides.
+    from oracle import oracle
+    from mseetc.train import Train
+    rng = np.random.default_rng(20260614)
+    B = 6
+    T = 1541*(1 + 0.15*rng.random(B))
+    pert = 1 + 0.05*np.clip(rng.standard_normal((B, 4)), -2, 2)
+    base = cases.train_default()
+    solver = _solver(base, cases.track_00(), 100)
+    res = solver.solveBatch(T, mass=base.mass*pert[:, 0], r0=base.r0*pert[:, 1], r1=base.r1*pert[:, 2], r2=base.r2*pert[:, 3])
+    assert np.all(res['status'] == 0)
+    for k in range(B):
+        tr = Train(config={'id': 'NL_Intercity_VIRM6',
+                           'mass': {'unit': 'kg', 'value': base.mass*pert[k, 0]},
+                           'rolling resistance r0': {'unit': 'N', 'value': base.r0*pert[k, 1]},
+                           'rolling resistance r1': {'unit': 'N/(m/s)', 'value': base.r1*pert[k, 2]},
+                           'rolling resistance r2': {'unit': 'N/(m/s)^2', 'value': base.r2*pert[k, 3]}})
+        prob = cases.oracle_problem(tr, cases.track_00(), 100)
+        ref = oracle.solve(prob, prob.scenario(float(T[k])))
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= Z_RTOL
