@@ -180,3 +180,35 @@ def test_config3_rolling_stock_perturbations_vs_oracle():
         # the two sides compute r/M with different roundings; the energy agrees to 1e-8 but weakly determined variables
         # (how the last braking metres are split between the two brakes) move by ~1e-5 -> the north_star tolerance is used here
         assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4
+
+
+def test_config4_shrinking_horizon_vs_oracle():
+    # BASELINE config 4 in miniature: 4 re-solves, stride 2, 1 % measurement noise, 6 scenarios; the same driver is run
+    # with the device solver and with the oracle standing in for it -- same noise stream, so the logs must agree.
+    from mseetc.mpc import shrinkingHorizon
+    from oracle import oracle
+
+    class OracleSolver():
+        "casadiSolver look-alike backed by the oracle (checker only)"
+        def __init__(self, train, track, opts):
+            from mseetc.ocp import casadiSolver
+            self._front = casadiSolver(train, track, opts)     # host-side packing only; never touches the device
+            self.points, self.withPnBrake = self._front.points, self._front.withPnBrake
+            io = opts.get('integrationOptions', {})
+            self._prob = cases.oracle_problem(train, track, opts['numIntervals'], numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0))
+        def solveBatch(self, T, initialTime=0, terminalVelocity=1, initialVelocity=1):
+            scen = self._front._scenarios(T, initialTime, terminalVelocity, initialVelocity)
+            z, st, nfail = oracle.solve_batch(self._prob, scen, nthreads=4)
+            return dict(z=z, status=st[:, 0].astype(int), iterations=st[:, 1].astype(int), cost=st[:, 2])
+
+    train, track = cases.train_default(), cases.track_00(crop=20000)
+    opts = dict(numIntervals=40, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+    T = np.linspace(800.0, 950.0, 6)
+    gpu = shrinkingHorizon(train, track, opts, T, numResolves=4, noise=0.01, seed=3)
+    ref = shrinkingHorizon(train, track, opts, T, numResolves=4, noise=0.01, seed=3, solverFactory=lambda a, b, c: OracleSolver(a, b, c))
+    assert len(gpu) == len(ref) == 4
+    for g, r in zip(gpu, ref):
+        assert g['numIntervals'] == r['numIntervals'] and g['position'] == r['position']
+        assert np.array_equal(g['status'], r['status']) and np.all(g['status'] == 0)
+        assert np.allclose(g['t0'], r['t0'], rtol=1e-7) and np.allclose(g['v0'], r['v0'], rtol=1e-7)
+        assert np.allclose(g['cost'], r['cost'], rtol=1e-7)
