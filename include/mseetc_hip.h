@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 1
+#define MSD_ABI_VERSION 2
 
 /* error codes */
 #define MSD_OK 0
@@ -87,7 +87,7 @@ typedef struct msd_problem_desc {
     int energy_optimal;      /* ocp.py:20                                                     */
     int num_steps;           /* OptionsRK.numSteps (train.py:463)                             */
     int num_approx_steps;    /* OptionsRK.numApproxSteps (train.py:465)                       */
-    int loss_kind;           /* 0 none, 1 static efficiencies (train.py:199-212)              */
+    int loss_kind;           /* 0 none, 1 static efficiencies (train.py:199-212), 2 dynamic table (efficiency.py) */
     int max_iterations;      /* ocp.py:18,290                                                 */
     int reserved_i[7];
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
@@ -105,6 +105,12 @@ typedef struct msd_problem_desc {
     const double *grad;      /* [N]   gradient, permil/1000 (ocp.py:195)                      */
     const double *curv;      /* [N]   curvature 1/m (ocp.py:196)                              */
     const double *bmax;      /* [N+1] upper bound of b at interior nodes (ocp.py:266-269)     */
+    /* loss_kind 2: parameter block of the dynamic loss model (efficiency.py:7-141): forceMax, powerMax, vTurn, vMin, vMax,
+     * auxiliaries, (1-etaGear)/etaGear, 1-etaGear, R, V, totalMass, nx, ny, xb[nx+1], yb[ny+1], coef[nx][ny][4][4]
+     * (bicubic patches about the cell centres of the not-a-knot spline of the measured motor + converter losses) */
+    const double *loss_table;
+    int loss_table_len;
+    int reserved_tail;
 } msd_problem_desc;
 
 typedef struct msd_problem *msd_handle;

@@ -15,6 +15,7 @@
 #include <string>
 
 #include "msd_kernel.hpp"
+#include "msd_geometry.hpp"
 
 namespace {
 
@@ -28,26 +29,6 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(MSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
-using KernelFn = void (*)(msd::DevProb, int, const double *, const double *, double *, double *, double *, double *, int);
-
-/* launch geometry by horizon length: NT threads, SPT shooting nodes per thread (NT*SPT >= N + 1) */
-struct Geometry { int NT, SPT; KernelFn fn; };
-
-Geometry pick_geometry(int N)
-{
-    const int nodes = N + 1;
-    /* MSD_GEOMETRY=128x1 selects the one-node-per-thread variant (tuning experiments only) */
-    const char *g = getenv("MSD_GEOMETRY");
-    if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, msd::solve_kernel<128, 1, 2>};
-    if (nodes <= 64) return {64, 1, msd::solve_kernel<64, 1, 1>};
-    if (nodes <= 128) return {64, 2, msd::solve_kernel<64, 2, 1>};     /* one wave per scenario, one wave per SIMD */
-    if (nodes <= 256) return {128, 2, msd::solve_kernel<128, 2, 1>};
-    if (nodes <= 384) return {192, 2, msd::solve_kernel<192, 2, 1>};
-    if (nodes <= 512) return {256, 2, msd::solve_kernel<256, 2, 1>};
-    if (nodes <= 640) return {320, 2, msd::solve_kernel<320, 2, 2>};
-    return {0, 0, nullptr};
-}
-
 }  // namespace
 
 struct msd_problem {
@@ -56,10 +37,10 @@ struct msd_problem {
     int NT = 0;
     size_t lds_bytes = 0;
     int max_grid = 0;
-    KernelFn kernel = nullptr;
+    msd::KernelFn kernel = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr;
+    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr, *d_loss = nullptr;
     /* grow-only scratch of the host-buffer entry point */
     double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr;
     int cap_scen = 0;
@@ -87,7 +68,12 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     if (d->num_steps < 1 || d->num_approx_steps < 0) return fail(MSD_E_INVALID, "bad integrator options");
     if (!d->ds || !d->grad || !d->curv || !d->bmax) return fail(MSD_E_INVALID, "null profile array");
     if (!(d->vmin_sq > 0) || !(d->obj_den > 0) || !(d->tol > 0)) return fail(MSD_E_INVALID, "vmin_sq, obj_den and tol must be positive");
-    if (d->loss_kind != 0 && d->loss_kind != 1) return fail(MSD_E_UNSUPPORTED, "loss model not available on the device");
+    if (d->loss_kind < 0 || d->loss_kind > 2) return fail(MSD_E_UNSUPPORTED, "loss model not available on the device");
+    if (d->loss_kind == 2) {
+        if (!d->loss_table || d->loss_table_len < 13) return fail(MSD_E_INVALID, "dynamic loss model without its table");
+        const int nx = (int)d->loss_table[11], ny = (int)d->loss_table[12];
+        if (nx < 1 || ny < 1 || d->loss_table_len != 13 + (nx + 1) + (ny + 1) + 16*nx*ny) return fail(MSD_E_INVALID, "inconsistent loss table");
+    }
     for (int i = 0; i < d->num_intervals; i++)
         if (!(d->ds[i] > 0)) return fail(MSD_E_INVALID, "interval lengths must be positive");
 
@@ -97,11 +83,11 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     HIP_TRY(hipSetDevice(device));
 
     const int N = d->num_intervals;
-    const Geometry geo = pick_geometry(N);
-    KernelFn k = geo.fn;
+    const msd::Geometry geo = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
+    msd::KernelFn k = geo.fn;
     if (!k) return fail(MSD_E_UNSUPPORTED, "numIntervals > 639 is not supported by the LDS-resident kernel");
     const int NT = geo.NT;
-    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT);
+    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (lds > 160*1024)
@@ -125,8 +111,9 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
         }                                                                                      \
     } while (0)
     UPLOAD(h->d_ds, d->ds, N); UPLOAD(h->d_grad, d->grad, N); UPLOAD(h->d_curv, d->curv, N); UPLOAD(h->d_bmax, d->bmax, N + 1);
+    if (d->loss_kind == 2) UPLOAD(h->d_loss, d->loss_table, d->loss_table_len);
 #undef UPLOAD
-    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax;
+    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax; P.loss = h->d_loss;
 
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         msd_problem_destroy(h);
@@ -147,7 +134,7 @@ int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax);
+    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax); hipFree(h->d_loss);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -299,7 +286,7 @@ int msd_stage_eval(msd_handle h, int n, const double *b, const double *w, const 
     if (hipMalloc((void **)&d_out, sizeof(double)*12*n) != hipSuccess) { hipFree(d_in); return fail(MSD_E_HIP, "hipMalloc failed"); }
     const double *src[5] = {b, w, ds, grad, curv};
     for (int k = 0; k < 5; k++) hipMemcpyAsync(d_in + (size_t)k*n, src[k], sizeof(double)*n, hipMemcpyHostToDevice, h->stream);
-    hipLaunchKernelGGL(msd::stage_eval_kernel, dim3((n + 255)/256), dim3(256), 0, h->stream, h->P, n, d_in, d_in + n, d_in + 2*(size_t)n, d_in + 3*(size_t)n,
+    hipLaunchKernelGGL(msd::stage_eval_kernel<0>, dim3((n + 255)/256), dim3(256), 0, h->stream, h->P, n, d_in, d_in + n, d_in + 2*(size_t)n, d_in + 3*(size_t)n,
                        d_in + 4*(size_t)n, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out12, d_out, sizeof(double)*12*n, hipMemcpyDeviceToHost, h->stream);

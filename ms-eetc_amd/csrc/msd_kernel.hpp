@@ -54,6 +54,7 @@ struct DevProb {
     int N, withPn, hasPower, energyOpt, numSteps, numApprox, lossKind, maxIter;
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     const double *ds, *grad, *curv, *bmax;
+    const double *loss;      /* parameter block of the dynamic loss model (lossKind == 2), see DynLoss */
 };
 
 /* IPOPT default option values */
@@ -74,7 +75,9 @@ constexpr int VT = 0, VB = 1, VF = 2, VP = 3, VS = 4, NV = 5;
 constexpr int RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5;
 
 /* LDS layout (in doubles) */
-constexpr int S_STRIDE = 27;    /* stage block: odd stride -> the per-thread writes spread over the banks */
+/* stage block stride: odd -> the per-thread writes spread over the banks; the dynamic loss model needs three more entries */
+constexpr int S_STRIDE_STATIC = 27, S_STRIDE_DYN = 31;
+__host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE_DYN : S_STRIDE_STATIC; }
 constexpr int FILT_CAP = 64;
 constexpr int RED_K = 8, RED_SLOTS = 4, MAX_WAVES = 16;
 constexpr int HIST_COLS = 8;
@@ -85,10 +88,12 @@ constexpr int S_HTT = 6, S_HBB = 7, S_HBQ = 8, S_HBF = 9, S_HBP = 10, S_HQQ = 11
               S_HPP = 16, S_HSS = 17, S_HT = 18, S_HB = 19, S_HQ = 20, S_HF = 21, S_HP = 22, S_HS = 23;
 constexpr int S_K = 6 /* 9 */, S_KV = 15 /* 3 */, S_PN = 18 /* 6 */, S_PV = 24 /* 3 */;
 constexpr int S_DT = 6, S_DB = 7, S_DF = 8, S_DP = 9, S_DS = 10, S_LT = 11, S_LB = 12;
+/* dynamic loss model only: (b,s) entry and the couplings of (b_i, s_i) with b_{i+1}; never overwritten by the sweeps */
+constexpr int S_HBS = 27, S_EB = 28, S_ES = 29;
 
-__host__ __device__ __forceinline__ int lds_doubles(int N, int NT)
+__host__ __device__ __forceinline__ int lds_doubles(int N, int NT, bool dyn)
 {
-    return S_STRIDE*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32;
+    return stage_stride(dyn)*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -100,6 +105,11 @@ __device__ __forceinline__ Jet operator+(Jet a, Jet b) { return {a.v + b.v, a.g0
 __device__ __forceinline__ Jet operator-(Jet a, Jet b) { return {a.v - b.v, a.g0 - b.g0, a.g1 - b.g1, a.h00 - b.h00, a.h01 - b.h01, a.h11 - b.h11}; }
 __device__ __forceinline__ Jet operator*(Jet a, double s) { return {a.v*s, a.g0*s, a.g1*s, a.h00*s, a.h01*s, a.h11*s}; }
 __device__ __forceinline__ Jet operator*(double s, Jet a) { return a*s; }
+__device__ __forceinline__ Jet operator*(Jet a, Jet b)
+{
+    return {a.v*b.v, a.v*b.g0 + b.v*a.g0, a.v*b.g1 + b.v*a.g1, a.v*b.h00 + 2*a.g0*b.g0 + b.v*a.h00,
+            a.v*b.h01 + a.g0*b.g1 + a.g1*b.g0 + b.v*a.h01, a.v*b.h11 + 2*a.g1*b.g1 + b.v*a.h11};
+}
 __device__ __forceinline__ Jet operator+(Jet a, double c) { a.v += c; return a; }
 __device__ __forceinline__ Jet operator+(double c, Jet a) { a.v += c; return a; }
 __device__ __forceinline__ Jet operator-(Jet a, double c) { a.v -= c; return a; }
@@ -166,6 +176,103 @@ template <class T> __device__ __forceinline__ void interval_map(const DevProb &P
         prev = cur;
     }
     tau = acc; bplus = prev;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic loss model (reference: mseetc/efficiency.py:7-141 with utils.py:197-220 and train.py:214-217).
+ * Parameter block: forceMax, powerMax, vTurn, vMin, vMax, auxiliaries, cgT, cgB, R, V, totalMass, nx, ny, xb[nx+1], yb[ny+1],
+ * coef[nx][ny][4][4] -- bicubic patches (about the cell centres) of the not-a-knot spline of the measured motor+converter losses.
+ * ---------------------------------------------------------------------------------------- */
+struct DynLoss {
+    double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
+    int nx, ny;
+    const double *xb, *yb, *coef;
+    __device__ __forceinline__ explicit DynLoss(const double *b)
+        : Fmax(b[0]), Pmax(b[1]), vTurn(b[2]), vMin(b[3]), vMax(b[4]), aux(b[5]), cgT(b[6]), cgB(b[7]), R(b[8]), V(b[9]), M(b[10]),
+          nx((int)b[11]), ny((int)b[12]), xb(b + 13), yb(b + 13 + (int)b[11] + 1), coef(b + 13 + (int)b[11] + 1 + (int)b[12] + 1) {}
+};
+
+/* value and derivatives up to second order of the table at (x, y): t = {p, px, py, pxx, pxy, pyy}; zero outside the x range */
+__device__ __forceinline__ void table_eval(const DynLoss &D, double x, double y, double (&t)[6])
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) t[k] = 0;
+    if (x < D.xb[0] || x > D.xb[D.nx]) return;
+    int ix = 0, iy = 0;
+    while (ix + 1 < D.nx && x >= D.xb[ix + 1]) ix++;
+    while (iy + 1 < D.ny && y >= D.yb[iy + 1]) iy++;
+    const double dx = x - 0.5*(D.xb[ix] + D.xb[ix + 1]), dy = y - 0.5*(D.yb[iy] + D.yb[iy + 1]);
+    const double *c = D.coef + 16*(ix*D.ny + iy);
+    const double X[4] = {1, dx, dx*dx, dx*dx*dx}, X1[4] = {0, 1, 2*dx, 3*dx*dx}, X2[4] = {0, 0, 2, 6*dx};
+    const double Y[4] = {1, dy, dy*dy, dy*dy*dy}, Y1[4] = {0, 1, 2*dy, 3*dy*dy}, Y2[4] = {0, 0, 2, 6*dy};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double cc = c[4*p + q];
+            t[0] += cc*X[p]*Y[q]; t[1] += cc*X1[p]*Y[q]; t[2] += cc*X[p]*Y1[q];
+            t[3] += cc*X2[p]*Y[q]; t[4] += cc*X1[p]*Y1[q]; t[5] += cc*X[p]*Y2[q];
+        }
+    }
+}
+
+/* specific total losses [W/kg] of the traction (f >= 0) or braking (f < 0) branch as a jet in (f, v) */
+__device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, double f, double v)
+{
+    const Jet F = Jet{f, 1, 0, 0, 0, 0}*D.M, vv = Jet{v, 0, 1, 0, 0, 0};
+    const bool inside = (v >= D.vMin && v <= D.vMax);
+    const Jet vc = inside ? vv : Jet{v < D.vMin ? D.vMin : D.vMax, 0, 0, 0, 0, 0};                       /* efficiency.py:40 */
+    const Jet absF = traction ? F : F*(-1.0);
+    const Jet load = (vc.v <= D.vTurn) ? absF*(100/D.Fmax) : (absF*vc)*(100/D.Pmax);                      /* efficiency.py:7-12 */
+    double t[6];
+    table_eval(D, load.v, vc.v, t);
+    if (!(t[0] > 0)) return Jet{0, 0, 0, 0, 0, 0};                                                        /* efficiency.py:137 */
+    Jet motor;
+    motor.v = t[0];
+    motor.g0 = t[1]*load.g0 + t[2]*vc.g0;
+    motor.g1 = t[1]*load.g1 + t[2]*vc.g1;
+    motor.h00 = t[1]*load.h00 + t[2]*vc.h00 + t[3]*load.g0*load.g0 + 2*t[4]*load.g0*vc.g0 + t[5]*vc.g0*vc.g0;
+    motor.h01 = t[1]*load.h01 + t[2]*vc.h01 + t[3]*load.g0*load.g1 + t[4]*(load.g0*vc.g1 + load.g1*vc.g0) + t[5]*vc.g0*vc.g1;
+    motor.h11 = t[1]*load.h11 + t[2]*vc.h11 + t[3]*load.g1*load.g1 + 2*t[4]*load.g1*vc.g1 + t[5]*vc.g1*vc.g1;
+    const Jet pW = traction ? F*vv : (F*vv)*(-1.0);                                                        /* efficiency.py:108-109 */
+    const Jet gear = pW*(traction ? D.cgT : D.cgB);                                                        /* efficiency.py:112-116 */
+    const Jet Pm = traction ? (pW + gear) + (motor + D.aux) : (pW - gear) - (motor + D.aux);
+    const Jet inner = traction ? (Pm*(-4*D.R)) + D.V*D.V : (Pm*(4*D.R)) + D.V*D.V;
+    const Jet dif = (xsqrt(inner)*(-1.0)) + D.V;
+    const Jet trafo = (dif*dif)*(1/(4*D.R));                                                               /* efficiency.py:127-130 */
+    return ((gear + motor) + (trafo + D.aux))*(1/D.M);                                                     /* train.py:216 */
+}
+
+/*
+ * The loss rows of ocp.py:225-226 as functions of (f, vbar): g = L(f, v)/v of the traction part (row 0) and of the
+ * regenerative-brake part (row 1), each extended linearly through f = 0 (utils.py:197-220).  lr[row] = {g, g_f, g_v, g_ff, g_fv, g_vv}.
+ * In the linear-extension branch the third derivative that g_vv would need is dropped: that branch is not active at a solution
+ * and only Newton's curvature is affected, not the NLP (same convention as the oracle).
+ */
+__device__ __forceinline__ void loss_rows(const DynLoss &D, double f, double v, double (&lr)[2][6])
+{
+    const double tol = 1e-10;
+    const Jet beta = spec_losses(D, true, 0.0, v);
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const bool traction = (row == 0);
+        const bool truth = traction ? (f >= 0) : (f < 0);
+        double L, Lf, Lv, Lff, Lfv, Lvv;
+        if (truth) {
+            const Jet s = spec_losses(D, traction, f, v);
+            L = s.v; Lf = s.g0; Lv = s.g1; Lff = s.h00; Lfv = s.h01; Lvv = s.h11;
+        } else {
+            const Jet a = spec_losses(D, traction, traction ? tol : -tol, v);
+            L = a.g0*f + beta.v; Lf = a.g0; Lv = a.h01*f + beta.g1; Lff = 0; Lfv = a.h01; Lvv = beta.h11;
+        }
+        const double iv = 1/v;
+        lr[row][0] = L*iv;
+        lr[row][1] = Lf*iv;
+        lr[row][2] = Lv*iv - L*iv*iv;
+        lr[row][3] = Lff*iv;
+        lr[row][4] = Lfv*iv - Lf*iv*iv;
+        lr[row][5] = Lvv*iv - 2*Lv*iv*iv + 2*L*iv*iv*iv;
+    }
 }
 
 __device__ __forceinline__ double track_resistance(const DevProb &P, double grad, double curv)
@@ -293,6 +400,7 @@ __device__ __forceinline__ double uni(double v)
 struct Ev {
     double sb, sb1, b1;
     double tb, tw, tbb, tbw, tww, Bb, Bw, Bbb, Bbw, Bww;
+    double lg[2][5];     /* dynamic loss rows: g_f, g_v, g_ff, g_fv, g_vv of the traction / brake row at (f, vbar) */
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
@@ -317,8 +425,22 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
     dv[RPW0] = U.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
     dv[RPW1] = U.rs[RPW1]*f*sb1;
     dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - n.G);     /* ocp.py:199 */
-    dv[RLTR] = U.rs[RLTR]*(s - P.ct*f);                                     /* ocp.py:225 */
-    dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);                                     /* ocp.py:226 */
+    if (P.lossKind == 2) {
+        const DynLoss D(P.loss);
+        double lr[2][6];
+        loss_rows(D, f, 0.5*(sb + sb1), lr);                                 /* ocp.py:221: mid-point speed of the interval */
+        dv[RLTR] = U.rs[RLTR]*(s - lr[0][0]);
+        dv[RLRG] = U.rs[RLRG]*(s - lr[1][0]);
+        if (DERIV) {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int m = 0; m < 5; m++) e.lg[k][m] = lr[k][1 + m];
+        }
+    } else {
+        dv[RLTR] = U.rs[RLTR]*(s - P.ct*f);                                 /* ocp.py:225 */
+        dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);                                 /* ocp.py:226 */
+    }
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
@@ -343,8 +465,10 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const Node &n
  * The last interval eliminates df through db_N = 0 (b_N is a parameter of the NLP).
  * Returns false when a pivot is not positive (wrong inertia of the KKT matrix).
  * ---------------------------------------------------------------------------------------- */
+template <bool DYN>
 __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
 {
+    constexpr int S_STRIDE = stage_stride(DYN);
     const int N = P.N;
     const bool pn = P.withPn != 0;
     /* terminal value function: only t_N is a free variable of the NLP */
@@ -359,6 +483,9 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
                      Hff = s[S_HFF], Hfp = s[S_HFP], Hfs = s[S_HFS], Hpp = s[S_HPP], Hss = s[S_HSS];
         const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP], hs = s[S_HS];
+        /* dynamic loss rows: (b,s) entry and couplings e_b db_i db_{i+1} + e_s ds_i db_{i+1}; b_N is a parameter, so none in the last interval */
+        const double Hbs = DYN ? s[S_HBS] : 0.0;
+        const double ceb = (DYN && i < N - 1) ? s[S_EB] : 0.0, ces = (DYN && i < N - 1) ? s[S_ES] : 0.0;
         /* stash the value function of stage i+1 for the forward sweep */
         s[S_PN + 0] = Ptt; s[S_PN + 1] = Ptb; s[S_PN + 2] = Ptq; s[S_PN + 3] = Pbb; s[S_PN + 4] = Pbq; s[S_PN + 5] = Pqq;
         s[S_PV + 0] = pt; s[S_PV + 1] = pb; s[S_PV + 2] = pq;
@@ -377,7 +504,13 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         double Gpp = Hpp + Tw*Mpt + Bw*Mpb, Gss = Hss;
         double gt = ht + Prt, gb = hb + Tb*Prt + Bb*Prb, gq = hq;
         double gf = hf + Tw*Prt + Bw*Prb + Prq, gp = hp + Tw*Prt + Bw*Prb, gs = hs;
-        if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; }
+        double Gbs = 0, Gps = 0;
+        if (DYN) {
+            /* substitute db+ = Bb db + Bw (df + dp) + rb into the coupling terms */
+            Gbb += 2*ceb*Bb; Gbf += ceb*Bw; Gbp += ceb*Bw; gb += ceb*rb;
+            Gbs = Hbs + ces*Bb; Gfs += ces*Bw; Gps = ces*Bw; gs += ces*rb;
+        }
+        if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; Gps = 0; }
 
         double Kft, Kfb, Kfq, Kpt, Kpb, Kpq, Kst, Ksb, Ksq, kf, kp, ks;
         double nPtt, nPtb, nPtq, nPbb, nPbq, nPqq, npt, npb, npq;
@@ -390,7 +523,7 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
             /* reduced blocks over (t, b, q | p, s) */
             double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs, Hss2 = Gss;
             double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
-            double Hsb = Gfs*eb;
+            double Hsb = Gfs*eb + Gbs;
             double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
             double Xtt = Gtt, Xtb = Gtb + Gtf*eb, Xbb = Gbb + 2*eb*Gbf + eb*eb*Gff, Xbq = Gbq + eb*Gqf, Xqq = Gqq;
             double xt = gt + Gtf*e0, xb = gb + Gbf*e0 + eb*gfe, xq = gq + Gqf*e0;
@@ -417,6 +550,31 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
             Kpt = Kp2t; Kpb = Kp2b; Kpq = Kp2q; kp = kp2;
             Kst = Ks2t; Ksb = Ks2b; Ksq = Ks2q; ks = ks2;
             Kft = -Kp2t; Kfb = eb - Kp2b; Kfq = -Kp2q; kf = e0 - kp2;
+        } else if (DYN) {
+            /* full 3x3 LDL^T of Guu in the order s, p, f */
+            if (!(Gss > 0)) return false;
+            const double is = 1.0/Gss, lps = Gps*is, lfs = Gfs*is;
+            const double Gpp1 = Gpp - Gps*lps, Gfp1 = Gfp - Gfs*lps, Gff1 = Gff - Gfs*lfs;
+            if (!(Gpp1 > 0)) return false;
+            const double ip = 1.0/Gpp1, lfp = Gfp1*ip;
+            const double df_ = Gff1 - Gfp1*lfp;
+            if (!(df_ > 0)) return false;
+            const double iff = 1.0/df_;
+            auto solve = [&](double Rf, double Rp, double Rs, double &xf, double &xp, double &xs) {
+                const double yp = Rp - lps*Rs, yf = Rf - lfs*Rs - lfp*yp;
+                xf = yf*iff; xp = yp*ip - lfp*xf; xs = Rs*is - lps*xp - lfs*xf;
+            };
+            solve(-Gtf, -Gtp, 0.0, Kft, Kpt, Kst);
+            solve(-Gbf, -Gbp, -Gbs, Kfb, Kpb, Ksb);
+            solve(-Gqf, 0.0, 0.0, Kfq, Kpq, Ksq);
+            solve(-gf, -gp, -gs, kf, kp, ks);
+            nPtt = Gtt + Gtf*Kft + Gtp*Kpt;
+            nPtb = Gtb + Gtf*Kfb + Gtp*Kpb;
+            nPtq = Gtf*Kfq + Gtp*Kpq;
+            nPbb = Gbb + Gbf*Kfb + Gbp*Kpb + Gbs*Ksb;
+            nPbq = Gbq + Gbf*Kfq + Gbp*Kpq + Gbs*Ksq;
+            nPqq = Gqq + Gqf*Kfq;
+            npt = gt + Gtf*kf + Gtp*kp; npb = gb + Gbf*kf + Gbp*kp + Gbs*ks; npq = gq + Gqf*kf;
         } else {
             /* pivots of Guu in the order s, p, f (s and p couple only with f) */
             if (!(Gss > 0) || !(Gpp > 0)) return false;
@@ -459,6 +617,7 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         const double *Pn = s + S_PN, *pv = s + S_PV;
         double lt = -(Pn[0]*nt + Pn[1]*nb + Pn[2]*nq + pv[0]);
         double lb = -(Pn[1]*nt + Pn[3]*nb + Pn[4]*nq + pv[1]);
+        if (DYN && i < N - 1) lb -= s[S_EB]*db + s[S_ES]*dsl;      /* coupling terms of the dynamic loss rows */
         if (i == N - 1) lb = (LGtf*dt + LGbf*db + LGqf*dq + LGff*df + LGfp*dp + LGfs*dsl + Lgf)/Bw;
         s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp; s[S_DS] = dsl; s[S_LT] = lt; s[S_LB] = lb;
         dt = nt; db = nb; dq = nq;
@@ -475,8 +634,9 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int SPT>
+template <int SPT, bool DYN>
 struct Solver {
+    static constexpr int S_STRIDE = stage_stride(DYN);
     const DevProb &P;
     Ctx &c;
     Node n[SPT];
@@ -542,8 +702,15 @@ struct Solver {
         gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
         gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
         gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
-        gs[RLTR] = 1; gf[RLTR] = -P.ct;
-        gs[RLRG] = 1; gf[RLRG] = P.cr;
+        if (P.lossKind == 2) {
+            /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
+            const double vb = 0.25/ev.sb, vb1 = 0.25/ev.sb1;
+            gs[RLTR] = 1; gf[RLTR] = -ev.lg[0][0]; gb[RLTR] = -ev.lg[0][1]*vb; gb1[RLTR] = -ev.lg[0][1]*vb1;
+            gs[RLRG] = 1; gf[RLRG] = -ev.lg[1][0]; gb[RLRG] = -ev.lg[1][1]*vb; gb1[RLRG] = -ev.lg[1][1]*vb1;
+        } else {
+            gs[RLTR] = 1; gf[RLTR] = -P.ct;
+            gs[RLRG] = 1; gf[RLRG] = P.cr;
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++) { gb[r] *= U.rs[r]; gf[r] *= U.rs[r]; gp[r] *= U.rs[r]; gs[r] *= U.rs[r]; gb1[r] *= U.rs[r]; }
     }
@@ -695,6 +862,7 @@ struct Solver {
             double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
             double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
             double nHbb = 0, nHbq = 0, nhb = 0;
+            double Hbs = 0, Eb = 0, Es = 0;     /* only the dynamic loss rows fill these */
             if (nd.ival()) {
                 const double f = nd.x[VF];
                 double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
@@ -715,6 +883,18 @@ struct Solver {
                     if (U.rowOn[RPW0]) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
                     if (U.rowOn[RPW1]) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
                     if (U.rowOn[RACC]) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
+                    if (DYN && U.rowOn[RLTR]) {
+                        /* rows s - g(f, vbar(b, b1)): nu * hess = -nu * hess(g) */
+                        const double vb = 0.25/e[j].sb, vb1 = 0.25/e[j].sb1, vbb = -0.125/(b*e[j].sb), vb1b1 = -0.125/(e[j].b1*e[j].sb1);
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int r = (k == 0) ? RLTR : RLRG;
+                            const double w = -nd.nu[r]*U.rs[r];
+                            const double gv = e[j].lg[k][1], gff = e[j].lg[k][2], gfv = e[j].lg[k][3], gvv = e[j].lg[k][4];
+                            Hff += w*gff; Hbf += w*gfv*vb; nHbq += w*gfv*vb1;
+                            Hbb += w*(gvv*vb*vb + gv*vbb); nHbb += w*(gvv*vb1*vb1 + gv*vb1b1); Eb += w*gvv*vb*vb1;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
@@ -727,6 +907,7 @@ struct Solver {
                     Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
                     Hpp += Sg*gp[r]*gp[r]; Hss += Sg*gs[r]*gs[r];
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
+                    if (DYN) { Hbs += Sg*gb[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
             } else if (nd.i == P.N && !P.energyOpt) ht = U.sf/P.objDen;
             /* bounds of the node's own variables + regularisation */
@@ -748,6 +929,7 @@ struct Solver {
                 s[S_HTT] = Htt; s[S_HBB] = Hbb; s[S_HBQ] = Hbq; s[S_HBF] = Hbf; s[S_HBP] = Hbp; s[S_HQQ] = Hqq; s[S_HQF] = Hqf;
                 s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HFS] = Hfs; s[S_HPP] = Hpp; s[S_HSS] = Hss;
                 s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp; s[S_HS] = hs;
+                if (DYN) { s[S_HBS] = Hbs; s[S_EB] = Eb; s[S_ES] = Es; }
             }
             /* the end-of-interval power row lives in the next stage's (b, q) block */
             c.o1[nd.i] = nHbb; c.o2[nd.i] = nHbq; c.o3[nd.i] = nhb;
@@ -773,7 +955,7 @@ struct Solver {
         c.mark(PH_ASSEMBLE); phase_fence();
         if (c.tid == 0) {
             const unsigned long long t0 = __builtin_readcyclecounter();
-            c.misc[0] = riccati_solve(P, c.S) ? 1.0 : 0.0;
+            c.misc[0] = riccati_solve<DYN>(P, c.S) ? 1.0 : 0.0;
             c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
         }
         __syncthreads();
@@ -1363,7 +1545,7 @@ struct Solver {
  * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64), NT*SPT >= N + 1.
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT, int SPT, int WPS>
+template <int NT, int SPT, int WPS, bool DYN>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap)
 {
@@ -1372,7 +1554,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     Ctx c;
     c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.nt = NT; c.red_slot = 0;
     c.S = lds;
-    c.xt = c.S + S_STRIDE*(P.N + 1); c.xb = c.xt + NS; c.xf = c.xb + NS;
+    c.xt = c.S + stage_stride(DYN)*(P.N + 1); c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
     c.filt = c.o3 + NS; c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
     const int nz = (4 + P.withPn)*P.N + 2;
@@ -1386,7 +1568,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             Ps.fmax = o[MSD_OV_F_MAX]; Ps.fmin = o[MSD_OV_F_MIN]; Ps.fminPn = o[MSD_OV_F_MIN_PN];
             Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
         }
-        Solver<SPT> s(Ps, c);
+        Solver<SPT, DYN> s(Ps, c);
         s.run(scen + (size_t)MSD_SC_COUNT*sidx, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
               stats + (size_t)MSD_ST_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
         __syncthreads();
@@ -1394,6 +1576,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
 }
 
 /* one thread per interval: TrainIntegrator.solve (train.py:347-364) with sensitivities */
+template <int UNUSED>
 __global__ void stage_eval_kernel(DevProb P, int n, const double *b, const double *w, const double *ds, const double *grad, const double *curv, double *out)
 {
     int k = blockIdx.x*blockDim.x + threadIdx.x;

@@ -14,7 +14,7 @@ import numpy as np
 
 LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, COUNT=13)
 SC_COUNT = 4
 OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, COUNT=9)
@@ -39,7 +39,8 @@ class ProblemDesc(ctypes.Structure):
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
                 ('loss_ct', ctypes.c_double), ('loss_cr', ctypes.c_double), ('vmin_sq', ctypes.c_double), ('obj_den', ctypes.c_double),
                 ('tol', ctypes.c_double), ('reserved_d', ctypes.c_double*7),
-                ('ds', _dptr), ('grad', _dptr), ('curv', _dptr), ('bmax', _dptr)]
+                ('ds', _dptr), ('grad', _dptr), ('curv', _dptr), ('bmax', _dptr),
+                ('loss_table', _dptr), ('loss_table_len', ctypes.c_int), ('reserved_tail', ctypes.c_int)]
 
 
 class DeviceError(RuntimeError):
@@ -101,7 +102,7 @@ def _d(a):
 
 
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
-              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax):
+              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None):
     "Fill a ProblemDesc; the numpy arrays are kept alive on the returned object."
 
     d = ProblemDesc()
@@ -115,6 +116,9 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
     d.loss_ct, d.loss_cr, d.vmin_sq, d.obj_den, d.tol = ct, cr, vminSq, objDen, tol
     keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (ds, grad, curv, bmax)]
     d.ds, d.grad, d.curv, d.bmax = [_d(a) for a in keep]
+    if lossTable is not None:
+        keep.append(np.ascontiguousarray(lossTable, dtype=np.float64))
+        d.loss_table, d.loss_table_len = _d(keep[-1]), len(keep[-1])
     d._keep = keep
 
     return d

@@ -15,7 +15,7 @@ import pandas as pd
 
 from .train import OptionsRK, OptionsIRK, OptionsCVODES
 from .track import computeDiscretizationPoints
-from .utils import Options, classifyLosses, postProcessDataFrame, LOSS_NONE
+from .utils import Options, classifyLosses, postProcessDataFrame, LOSS_NONE, LOSS_DYNAMIC
 from . import _device
 
 
@@ -143,7 +143,8 @@ class casadiSolver():
             N, withPnBrake, hasPower, opts.energyOptimal, io.numSteps, io.numApproxSteps, lossKind, int(opts.maxIterations),
             (model.sr0, model.sr1, model.sr2), train.g, rho, forceMax, forceMin if withRgBrake else 0.0, forceMinPn,
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
-            self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax)
+            self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
+            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU
@@ -203,6 +204,9 @@ class casadiSolver():
 
         if mass is None and r0 is None and r1 is None and r2 is None:
             return None
+
+        if self._desc.loss_kind == LOSS_DYNAMIC:
+            raise NotImplementedError("Per-scenario rolling stock is not available together with the dynamic loss model.")
 
         tr = self.train
         full = lambda a, default: np.broadcast_to(np.asarray(default if a is None else a, dtype=float), (B,)).copy()

@@ -145,6 +145,7 @@ class Options():
 
 LOSS_NONE = 0     # perfect efficiency, L(f,v) = 0
 LOSS_STATIC = 1   # constant efficiencies: L = f v (1-eta_t)/eta_t (f>0), -(1-eta_r) f v (f<0)
+LOSS_DYNAMIC = 2  # measured motor/converter table + gear + auxiliaries + transformer (efficiency.py)
 
 
 class StaticLosses():
@@ -178,6 +179,9 @@ def classifyLosses(fun):
     if isinstance(fun, StaticLosses):
         ct, cr = fun.slopes()
         return LOSS_STATIC, ct, cr
+
+    if getattr(fun, 'KIND', None) == LOSS_DYNAMIC:      # efficiency.DynamicLosses
+        return LOSS_DYNAMIC, 0.0, 0.0
 
     fs = np.array([-3e5, -1.1e5, -2.5e4, -1.0, 1.0, 3.3e4, 1.2e5, 2.9e5])
     vs = np.array([0.7, 3.0, 11.0, 27.0, 44.0])

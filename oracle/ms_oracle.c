@@ -47,6 +47,128 @@ static jet j_chain(jet a, double F, double f1, double f2)
 static jet j_sqrt(jet a) { double s = sqrt(a.v); return j_chain(a, s, 0.5/s, -0.25/(a.v*s)); }
 static jet j_recip(jet a) { double r = 1.0/a.v; return j_chain(a, r, -r*r, 2*r*r*r); }
 
+static jet j_mul(jet a, jet b)
+{
+    jet r;
+    r.v = a.v*b.v;
+    r.g0 = a.v*b.g0 + b.v*a.g0;
+    r.g1 = a.v*b.g1 + b.v*a.g1;
+    r.h00 = a.v*b.h00 + 2*a.g0*b.g0 + b.v*a.h00;
+    r.h01 = a.v*b.h01 + a.g0*b.g1 + a.g1*b.g0 + b.v*a.h01;
+    r.h11 = a.v*b.h11 + 2*a.g1*b.g1 + b.v*a.h11;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic loss model (reference: mseetc/efficiency.py:7-141, utils.py:197-220, train.py:214-217).
+ * Parameter block (doubles): forceMax, powerMax, vTurn, vMin, vMax, auxiliaries, cgT = (1-etaG)/etaG, cgB = 1-etaG, R, V,
+ * totalMass, nx, ny, xb[nx+1], yb[ny+1], coef[nx][ny][4][4] (bicubic patches about the cell centres, ascending powers).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
+    int nx, ny;
+    const double *xb, *yb, *coef;
+} DynLoss;
+
+static const double *g_loss_block = NULL;
+void oracle_set_loss_table(const double *block) { g_loss_block = block; }
+
+static void dyn_init(DynLoss *D, const double *b)
+{
+    D->Fmax = b[0]; D->Pmax = b[1]; D->vTurn = b[2]; D->vMin = b[3]; D->vMax = b[4]; D->aux = b[5]; D->cgT = b[6]; D->cgB = b[7];
+    D->R = b[8]; D->V = b[9]; D->M = b[10]; D->nx = (int)b[11]; D->ny = (int)b[12];
+    D->xb = b + 13; D->yb = D->xb + D->nx + 1; D->coef = D->yb + D->ny + 1;
+}
+
+/* bicubic table: value and derivatives up to second order wrt (x, y); all zero outside the x range (efficiency.py:137) */
+static void table_eval(const DynLoss *D, double x, double y, double out[6])
+{
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    if (x < D->xb[0] || x > D->xb[D->nx]) return;
+    int ix = 0, iy = 0;
+    while (ix + 1 < D->nx && x >= D->xb[ix + 1]) ix++;
+    while (iy + 1 < D->ny && y >= D->yb[iy + 1]) iy++;
+    const double dx = x - 0.5*(D->xb[ix] + D->xb[ix + 1]), dy = y - 0.5*(D->yb[iy] + D->yb[iy + 1]);
+    const double *c = D->coef + 16*(ix*D->ny + iy);
+    const double X[4] = {1, dx, dx*dx, dx*dx*dx}, X1[4] = {0, 1, 2*dx, 3*dx*dx}, X2[4] = {0, 0, 2, 6*dx};
+    const double Y[4] = {1, dy, dy*dy, dy*dy*dy}, Y1[4] = {0, 1, 2*dy, 3*dy*dy}, Y2[4] = {0, 0, 2, 6*dy};
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) {
+            const double cc = c[4*p + q];
+            out[0] += cc*X[p]*Y[q]; out[1] += cc*X1[p]*Y[q]; out[2] += cc*X[p]*Y1[q];
+            out[3] += cc*X2[p]*Y[q]; out[4] += cc*X1[p]*Y1[q]; out[5] += cc*X[p]*Y2[q];
+        }
+}
+
+/* specific total losses [W/kg] of one branch as a jet in (f, v): traction branch for f >= 0, braking branch for f < 0 */
+static jet spec_losses(const DynLoss *D, int traction, double f, double v)
+{
+    jet F = j_scale(j_var(f, 0), D->M), vv = j_var(v, 1);
+    jet vc = (v >= D->vMin && v <= D->vMax) ? vv : j_const(v < D->vMin ? D->vMin : D->vMax);   /* efficiency.py:40 */
+    jet absF = traction ? F : j_scale(F, -1);
+    jet load = (vc.v <= D->vTurn) ? j_scale(absF, 100/D->Fmax) : j_scale(j_mul(absF, vc), 100/D->Pmax);   /* efficiency.py:7-12 */
+    double t[6];
+    table_eval(D, load.v, vc.v, t);
+    jet motor;
+    motor.v = t[0];
+    motor.g0 = t[1]*load.g0 + t[2]*vc.g0;
+    motor.g1 = t[1]*load.g1 + t[2]*vc.g1;
+    motor.h00 = t[1]*load.h00 + t[2]*vc.h00 + t[3]*load.g0*load.g0 + 2*t[4]*load.g0*vc.g0 + t[5]*vc.g0*vc.g0;
+    motor.h01 = t[1]*load.h01 + t[2]*vc.h01 + t[3]*load.g0*load.g1 + t[4]*(load.g0*vc.g1 + load.g1*vc.g0) + t[5]*vc.g0*vc.g1;
+    motor.h11 = t[1]*load.h11 + t[2]*vc.h11 + t[3]*load.g1*load.g1 + 2*t[4]*load.g1*vc.g1 + t[5]*vc.g1*vc.g1;
+    if (!(motor.v > 0)) return j_const(0);                                       /* efficiency.py:137 */
+    jet pW = traction ? j_mul(F, vv) : j_scale(j_mul(F, vv), -1);               /* efficiency.py:108-109 */
+    jet gear = j_scale(pW, traction ? D->cgT : D->cgB);                          /* efficiency.py:112-116 */
+    jet Pm, inner;
+    if (traction) { Pm = j_add(j_add(pW, gear), j_add(motor, j_const(D->aux))); inner = j_sub(j_const(D->V*D->V), j_scale(Pm, 4*D->R)); }
+    else { Pm = j_sub(j_sub(pW, gear), j_add(motor, j_const(D->aux))); inner = j_add(j_const(D->V*D->V), j_scale(Pm, 4*D->R)); }
+    jet dif = j_sub(j_const(D->V), j_sqrt(inner));
+    jet trafo = j_scale(j_mul(dif, dif), 1/(4*D->R));                            /* efficiency.py:127-130 */
+    jet total = j_add(j_add(gear, motor), j_add(j_const(D->aux), trafo));
+    return j_scale(total, 1/D->M);                                               /* train.py:216 */
+}
+
+/*
+ * The two loss rows of ocp.py:225-226 as functions of (f, vbar): g = L(f, v)/v for the traction part (row 0) and the
+ * regenerative-brake part (row 1), each extended linearly through f = 0 (utils.py:197-220: slope = dL/df at +-1e-10,
+ * intercept = L(0, v)).  out[row] = {g, g_f, g_v, g_ff, g_fv, g_vv}.  In the linear-extension branch the third
+ * derivative d3L/df dv2 that g_vv would need is dropped (the branch is never active at a solution; only the
+ * curvature used by Newton's method is affected, not the NLP).
+ */
+static void loss_rows(const DynLoss *D, double f, double v, double out[2][6])
+{
+    const double tol = 1e-10;
+    jet beta = spec_losses(D, 1, 0.0, v);
+    for (int row = 0; row < 2; row++) {
+        const int traction = (row == 0);
+        const int truth = traction ? (f >= 0) : (f < 0);
+        double L, Lf, Lv, Lff, Lfv, Lvv;
+        if (truth) {
+            jet s = spec_losses(D, traction, f, v);
+            L = s.v; Lf = s.g0; Lv = s.g1; Lff = s.h00; Lfv = s.h01; Lvv = s.h11;
+        } else {
+            jet a = spec_losses(D, traction, traction ? tol : -tol, v);    /* slope alpha(v) = a.g0, alpha'(v) = a.h01 */
+            L = a.g0*f + beta.v; Lf = a.g0; Lv = a.h01*f + beta.g1; Lff = 0; Lfv = a.h01; Lvv = beta.h11;
+        }
+        const double iv = 1/v;
+        out[row][0] = L*iv;
+        out[row][1] = Lf*iv;
+        out[row][2] = Lv*iv - L*iv*iv;
+        out[row][3] = Lff*iv;
+        out[row][4] = Lfv*iv - Lf*iv*iv;
+        out[row][5] = Lvv*iv - 2*Lv*iv*iv + 2*L*iv*iv*iv;
+    }
+}
+
+/* test hook: the two loss rows and their derivatives at (f, v) for a parameter block */
+void oracle_loss_rows(const double *block, double f, double v, double *out12)
+{
+    DynLoss D; dyn_init(&D, block);
+    double lr[2][6];
+    loss_rows(&D, f, v, lr);
+    for (int k = 0; k < 6; k++) { out12[k] = lr[0][k]; out12[6 + k] = lr[1][k]; }
+}
+
 /* ------------------------------------------------------------------------------------------
  * problem data
  * ---------------------------------------------------------------------------------------- */
@@ -61,6 +183,7 @@ typedef struct {
     const double *ds, *grad, *curv, *bmax;
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     double t0, tEnd, v0sq, vNsq;
+    DynLoss dyn;
 } Prob;
 
 static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds, const double *grad, const double *curv, const double *bmax)
@@ -73,6 +196,7 @@ static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds
     P->pwU = dp[OR_DP_PW_UPPER]; P->pwL = dp[OR_DP_PW_LOWER]; P->accMin = dp[OR_DP_ACC_MIN]; P->accMax = dp[OR_DP_ACC_MAX];
     P->ct = dp[OR_DP_LOSS_CT]; P->cr = dp[OR_DP_LOSS_CR]; P->vminSq = dp[OR_DP_VMIN_SQ]; P->objDen = dp[OR_DP_OBJ_DEN]; P->tol = dp[OR_DP_TOL];
     P->t0 = dp[OR_DP_T0]; P->tEnd = dp[OR_DP_TEND]; P->v0sq = dp[OR_DP_V0SQ]; P->vNsq = dp[OR_DP_VNSQ];
+    if (P->lossKind == 2 && g_loss_block) dyn_init(&P->dyn, g_loss_block);
 }
 
 /* velocity-independent specific resistance of interval i: g*grad/rho + cr(curv)/rho (train.py:252-254) */
@@ -185,7 +309,13 @@ void oracle_nlp_eval(const int *ip, const double *dp, const double *ds, const do
             g[r++] = f + p - (P.sr0 + P.sr1*sqrt(b) + P.sr2*b) - G;
             g[r++] = t1 - (t + tau.v);
             g[r++] = b1 - bp.v;
-            if (P.energyOpt) { g[r++] = s - P.ct*f; g[r++] = s + P.cr*f; }
+            if (P.energyOpt) {
+                if (P.lossKind == 2) {
+                    double lr[2][6];
+                    loss_rows(&P.dyn, f, 0.5*(sqrt(b) + sqrt(b1)), lr);      /* ocp.py:221 mid-point speed */
+                    g[r++] = s - lr[0][0]; g[r++] = s - lr[1][0];
+                } else { g[r++] = s - P.ct*f; g[r++] = s + P.cr*f; }
+            }
         }
         if (P.energyOpt) {
             J += ds[i]*(f + s);
@@ -344,8 +474,15 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     e->d[RPW0] = W->rs[RPW0]*f*sb;
     e->d[RPW1] = W->rs[RPW1]*f*sb1;
     e->d[RACC] = W->rs[RACC]*(f + p - (P->sr0 + P->sr1*sb + P->sr2*b) - W->G[i]);
-    e->d[RLTR] = W->rs[RLTR]*(s - P->ct*f);
-    e->d[RLRG] = W->rs[RLRG]*(s + P->cr*f);
+    double lr[2][6];
+    if (P->lossKind == 2) {
+        loss_rows(&P->dyn, f, 0.5*(sb + sb1), lr);
+        e->d[RLTR] = W->rs[RLTR]*(s - lr[0][0]);
+        e->d[RLRG] = W->rs[RLRG]*(s - lr[1][0]);
+    } else {
+        e->d[RLTR] = W->rs[RLTR]*(s - P->ct*f);
+        e->d[RLRG] = W->rs[RLRG]*(s + P->cr*f);
+    }
     if (order == 0) return;
 
     e->tg[0] = tau.g0; e->tg[1] = tau.g1; e->th[0] = tau.h00; e->th[1] = tau.h01; e->th[2] = tau.h11;
@@ -363,8 +500,24 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     e->gr[RACC][LF] = 1; e->gr[RACC][LP] = P->withPn ? 1 : 0; e->gr[RACC][LB] = -(0.5*P->sr1/sb + P->sr2);
     e->hr[RACC][LB][LB] = 0.25*P->sr1/(b*sb);
     /* static loss rows (ocp.py:225-226 with train.py:203 / utils.py:197-220) */
-    e->gr[RLTR][LS] = 1; e->gr[RLTR][LF] = -P->ct;
-    e->gr[RLRG][LS] = 1; e->gr[RLRG][LF] = P->cr;
+    if (P->lossKind == 2) {
+        /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
+        const double vb = 0.25/sb, vb1 = 0.25/sb1, vbb = -0.125/(b*sb), vb1b1 = -0.125/(x1[VB]*sb1);
+        for (int k = 0; k < 2; k++) {
+            const int r = k == 0 ? RLTR : RLRG;
+            const double gf = lr[k][1], gv = lr[k][2], gff = lr[k][3], gfv = lr[k][4], gvv = lr[k][5];
+            e->gr[r][LS] = 1; e->gr[r][LF] = -gf; e->gr[r][LB] = -gv*vb; e->gr[r][LB1] = -gv*vb1;
+            e->hr[r][LF][LF] = -gff;
+            e->hr[r][LF][LB] = e->hr[r][LB][LF] = -gfv*vb;
+            e->hr[r][LF][LB1] = e->hr[r][LB1][LF] = -gfv*vb1;
+            e->hr[r][LB][LB] = -(gvv*vb*vb + gv*vbb);
+            e->hr[r][LB1][LB1] = -(gvv*vb1*vb1 + gv*vb1b1);
+            e->hr[r][LB][LB1] = e->hr[r][LB1][LB] = -gvv*vb*vb1;
+        }
+    } else {
+        e->gr[RLTR][LS] = 1; e->gr[RLTR][LF] = -P->ct;
+        e->gr[RLRG][LS] = 1; e->gr[RLRG][LF] = P->cr;
+    }
     for (int r = 0; r < NR; r++)
         if (W->rs[r] != 1.0)
             for (int a = 0; a < NL; a++) { e->gr[r][a] *= W->rs[r]; for (int c = 0; c < NL; c++) e->hr[r][a][c] *= W->rs[r]; }

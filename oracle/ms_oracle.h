@@ -42,7 +42,7 @@ enum {
     OR_IP_ENERGY_OPT,     /* 1: energy optimal, 0: time optimal                              */
     OR_IP_NUM_STEPS,      /* RK4 steps per interval                                          */
     OR_IP_NUM_APPROX,     /* trapezoidal time sub-intervals (0: integrate time with RK4)     */
-    OR_IP_LOSS_KIND,      /* 0 none, 1 static efficiencies                                   */
+    OR_IP_LOSS_KIND,      /* 0 none, 1 static efficiencies, 2 dynamic table (oracle_set_loss_table)   */
     OR_IP_MAX_ITER,
     OR_IP_COUNT
 };
@@ -108,6 +108,10 @@ int oracle_solve_batch(const int *ip, const double *dp, const double *ds, const 
  * d2tau/dbdb, d2tau/dbdw, d2tau/dwdw, d2bplus/dbdb, d2bplus/dbdw, d2bplus/dwdw} where tau = t+ - t and w = Fel+Fpb.
  */
 void oracle_stage_eval(const int *ip, const double *dp, double b, double w, double ds, double grad, double curv, double *out12);
+
+/* parameter block of the dynamic loss model (efficiency.py), see ms_oracle.c; the pointer must stay valid */
+void oracle_set_loss_table(const double *block);
+void oracle_loss_rows(const double *block, double f, double v, double *out12);
 
 /* NLP functions at z (reference layout): objective and the constraint rows in the reference's order. */
 void oracle_nlp_eval(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,

@@ -60,6 +60,10 @@ def lib():
         _lib.oracle_solve_batch.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
         _lib.oracle_stage_eval.restype = None
         _lib.oracle_stage_eval.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
+        _lib.oracle_set_loss_table.restype = None
+        _lib.oracle_set_loss_table.argtypes = [dptr]
+        _lib.oracle_loss_rows.restype = None
+        _lib.oracle_loss_rows.argtypes = [dptr, ctypes.c_double, ctypes.c_double, dptr]
         _lib.oracle_nlp_eval.restype = None
         _lib.oracle_nlp_eval.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr]
 
@@ -72,6 +76,26 @@ def _d(a):
 
 def _i(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+_loss_keepalive = None
+
+
+def set_loss_table(block):
+    "Install the parameter block of the dynamic loss model (kept alive here; one model at a time)."
+
+    global _loss_keepalive
+    _loss_keepalive = np.ascontiguousarray(block, dtype=np.float64)
+    lib().oracle_set_loss_table(_d(_loss_keepalive))
+
+
+def loss_rows(block, f, v):
+    "(2, 6): g, g_f, g_v, g_ff, g_fv, g_vv of the traction and the regenerative-brake loss row at (f [N/kg], v [m/s])"
+
+    block = np.ascontiguousarray(block, dtype=np.float64)
+    out = np.zeros(12)
+    lib().oracle_loss_rows(_d(block), float(f), float(v), _d(out))
+    return out.reshape(2, 6)
 
 
 class Problem():

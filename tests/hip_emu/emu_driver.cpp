@@ -15,21 +15,21 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT, int SPT>
+template <int NT, int SPT, bool DYN>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT*SPT));
+        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT*SPT, DYN));
         blk.shfl = shfl.data(); blk.lds = lds.data();
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+                msd::solve_kernel<NT, SPT, 1, DYN>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -48,7 +48,8 @@ extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const do
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
-    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax;
+    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax; P.loss = d->loss_table;
+    const bool dyn = d->loss_kind == 2;
     const int nodes = P.N + 1;
     const char *force = getenv("EMU_GEOMETRY");     /* "NTxSPT" to test other geometries */
     int NT = 0, SPT = 0;
@@ -58,11 +59,11 @@ extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const do
     else if (nodes <= 256) { NT = 128; SPT = 2; }
     else { NT = 192; SPT = 2; }
     if (NT*SPT < nodes) return -3;
-    if (NT == 64 && SPT == 1) run_blocks<64, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-    else if (NT == 64 && SPT == 2) run_blocks<64, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-    else if (NT == 128 && SPT == 1) run_blocks<128, 1>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-    else if (NT == 128 && SPT == 2) run_blocks<128, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-    else if (NT == 192 && SPT == 2) run_blocks<192, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+    if (NT == 64 && SPT == 1) { if (dyn) run_blocks<64, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
+    else if (NT == 64 && SPT == 2) { if (dyn) run_blocks<64, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
+    else if (NT == 128 && SPT == 1) { if (dyn) run_blocks<128, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<128, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
+    else if (NT == 128 && SPT == 2) { if (dyn) run_blocks<128, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<128, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
+    else if (NT == 192 && SPT == 2) { if (dyn) run_blocks<192, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<192, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
     else return -3;
     return 0;
 }

@@ -32,9 +32,11 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_desc_struct_matches_header(built):
-    # size of msd_problem_desc as laid out by ctypes == 16 ints + 24 doubles + 4 pointers
-    from mseetc._device import ProblemDesc
-    assert ctypes.sizeof(ProblemDesc) == 16*4 + 24*8 + 4*8
+    # size of msd_problem_desc as laid out by ctypes == 16 ints + 24 doubles + 5 pointers + 2 ints (ABI version 2)
+    from mseetc._device import ProblemDesc, ABI_VERSION
+    assert ctypes.sizeof(ProblemDesc) == 16*4 + 24*8 + 5*8 + 2*4
+    header = (ROOT / 'include' / 'mseetc_hip.h').read_text()
+    assert '#define MSD_ABI_VERSION {}'.format(ABI_VERSION) in header
 
 
 def test_no_device_fails_loudly(built):

@@ -1,0 +1,125 @@
+"""
+Dynamic loss model (reference mseetc/efficiency.py + data.py): host model, oracle rows, full solves.  CPU only.
+Pins: simulations/figure3.py:113-115 (max static / max dynamic losses within 1 %), the documented side effects on the train
+(efficiency.py:64-71), exact interpolation of the measured table.
+"""
+
+import numpy as np
+import pytest
+
+import cases
+from mseetc.train import Train
+from mseetc.track import Track, computeDiscretizationPoints
+from mseetc.efficiency import totalLossesFunction, motorLossesFunction, loadToForce, forceToLoad
+from mseetc.data import dataLosses
+from mseetc.utils import classifyLosses, LOSS_DYNAMIC
+from oracle import oracle
+
+
+def model():
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    train.forceMinPn = 0
+    return train, totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+
+
+def test_side_effects_on_the_train():
+    # efficiency.py:64-71: powerMax = Fmax * v(55 Hz), powerMin = -powerMax, forceMin = -Fmax, velocityMax = 160 km/h
+    train, fun = model()
+    assert abs(train.powerMax - 3129277.7777777775) < 1e-6 and train.powerMin == -train.powerMax
+    assert train.forceMin == -train.forceMax and abs(train.velocityMax - 160/3.6) < 1e-12
+    t2 = Train(config={'id': 'NL_Intercity_VIRM6'})
+    t2.forceMin = 0
+    totalLossesFunction(t2)
+    assert t2.forceMin == 0        # stays disabled (efficiency.py:70)
+    assert classifyLosses(fun)[0] == LOSS_DYNAMIC
+
+
+def test_table_interpolates_the_measurements():
+    train, fun = model()
+    a, b = dataLosses()
+    vals = np.minimum(np.array(a['losses']), np.array(b['losses']))*4
+    hz = lambda f: ((f - 20)/(170 - 20))*(160 - 20) + 20
+    for i, load in enumerate(b['loads']):
+        for j, fr in enumerate(b['frequencies']):
+            v = hz(fr)/3.6
+            F = loadToForce(load, v, fun.forceMax, fun.powerMax)
+            assert abs(forceToLoad(F, v, fun.forceMax, fun.powerMax) - load) < 1e-9
+            # the last load knot sits at 100.0001 (efficiency.py:27-28), so the 100 % row is met to 1e-6 relative only
+            tol = 5e-6 if load == 100 else 1e-7
+            assert abs(fun.motor(F, v) - vals[i, j]) <= tol*max(1.0, vals[i, j])
+
+
+def test_figure3_maximum_losses_ratio():
+    # simulations/figure3.py:102-115: eta = 0.73 is tuned so that the two maxima over the evaluation grid agree within 1 %
+    train, fun2 = model()
+    etaMax = 0.73
+    fun1 = lambda f, v: f*v*(f > 0)*(1 - etaMax)/etaMax - (1 - etaMax)*f*v*(f < 0)
+    tp = fun2.powerMax/fun2.forceMax
+    m1 = m2 = 0.0
+    for l in np.linspace(-100, 100, 200):
+        for v in np.linspace(1, 170, 170)/3.6:
+            F = (l/100)*(fun2.forceMax if v <= tp else fun2.powerMax/v)
+            m1, m2 = max(m1, fun1(F, v)), max(m2, fun2(F, v))
+    assert 0.99 <= m1/m2 <= 1.01
+    assert abs(m1/m2 - 0.9954) < 5e-4      # value of the SURVEY probe with scipy's not-a-knot spline
+
+
+def test_oracle_loss_rows_against_complex_step_of_the_host_model():
+    train, fun = model()
+    M = train.mass*train.rho
+    block = fun.parameters(M)
+    spec = lambda f, v: fun(f*M, v)/M
+    h = 1e-30
+    rng = np.random.default_rng(2)
+    for _ in range(40):
+        f, v = rng.uniform(-0.5, 0.5), rng.uniform(1.5, 43.0)
+        r = oracle.loss_rows(block, f, v)
+        k = 0 if f >= 0 else 1          # the row that evaluates the true branch
+        val = spec(f, v)/v
+        gf = np.imag(spec(f + 1j*h, v)/v)/h
+        gv = np.imag(spec(f, v + 1j*h)/(v + 1j*h))/h
+        assert abs(r[k, 0] - val) <= 1e-12*max(1e-3, abs(val))
+        assert abs(r[k, 1] - gf) <= 1e-10*max(1e-3, abs(gf)) and abs(r[k, 2] - gv) <= 1e-10*max(1e-3, abs(gv))
+        # second derivatives: central differences of the first ones
+        e = 1e-6
+        if abs(f) > 2*e and val > 0:
+            rp, rm = oracle.loss_rows(block, f + e, v), oracle.loss_rows(block, f - e, v)
+            vp, vm = oracle.loss_rows(block, f, v*(1 + e)), oracle.loss_rows(block, f, v*(1 - e))
+            assert abs(r[k, 3] - (rp[k, 1] - rm[k, 1])/(2*e)) <= 1e-5*max(1e-2, abs(r[k, 3]))
+            assert abs(r[k, 4] - (vp[k, 1] - vm[k, 1])/(2*e*v)) <= 1e-5*max(1e-2, abs(r[k, 4]))
+            assert abs(r[k, 5] - (vp[k, 2] - vm[k, 2])/(2*e*v)) <= 1e-4*max(1e-3, abs(r[k, 5]))
+        # linear extension of the other row (utils.py:197-220): slope at +-1e-10, intercept at 0
+        o = 1 - k
+        a = np.imag(spec((1e-10 if o == 0 else -1e-10) + 1j*h, v))/h
+        assert abs(r[o, 0] - (a*f + spec(0.0, v))/v) <= 1e-12*max(1e-3, abs(r[o, 0]))
+        assert abs(r[o, 1] - a/v) <= 1e-10*max(1e-3, abs(a/v))
+
+
+def _dyn_problem(train, fun, track, N):
+    oracle.set_loss_table(fun.parameters(train.mass*train.rho))
+    pts = computeDiscretizationPoints(track, N)
+    opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1)
+    return oracle.pack_problem(train, pts, opts, 2, 0.0, 0.0, track.length)
+
+
+def test_oracle_solves_the_figure5_configuration_with_dynamic_losses():
+    # simulations/figure5.py:84-146: 8.5 km, v0 = 1, vN = 100 km/h, time reserves over minimumTime = 272.4726
+    train, fun = model()
+    train.powerLosses = fun
+    track = cases.track_00(8500)
+    prob = _dyn_problem(train, fun, track, 100)
+    costs = []
+    for reserve in (1.1, 1.2, 1.3):
+        res = oracle.solve(prob, prob.scenario(272.4726*reserve, terminalVelocity=100/3.6, initialVelocity=1))
+        assert res['stats']['STATUS'] == 0
+        costs.append(res['stats']['OBJ'])
+        # energy accounting of the solution with the host model == NLP objective without the smoothing term
+        z = res['z']; N = 100
+        f, s, b = z[0:4*N:4], z[1:4*N:4], np.append(z[3:4*N:4], z[-1])
+        M = train.mass*train.rho
+        vm = 0.5*(np.sqrt(b[:-1]) + np.sqrt(b[1:]))
+        loss = np.array([fun(fk*M, vk)/vk for fk, vk in zip(f, vm)])
+        energy = (1e-6/3.6)*np.sum(prob.ds*(f*M + loss))
+        smooth = 1e-3*np.sum(np.diff(f)**2)/prob.dp[oracle.DP['OBJ_DEN']]
+        assert abs(energy - (res['stats']['OBJ'] - smooth)) <= 1e-6*energy      # the active slack row is tight
+    assert costs[0] > costs[1] > costs[2]

@@ -212,3 +212,30 @@ def test_config4_shrinking_horizon_vs_oracle():
         assert np.array_equal(g['status'], r['status']) and np.all(g['status'] == 0)
         assert np.allclose(g['t0'], r['t0'], rtol=1e-7) and np.allclose(g['v0'], r['v0'], rtol=1e-7)
         assert np.allclose(g['cost'], r['cost'], rtol=1e-7)
+
+
+def test_dynamic_loss_model_vs_oracle():
+    # simulations/figure5.py configuration with the dynamic losses of efficiency.py (fun2): 8.5 km, v0 = 1, vN = 100 km/h
+    from oracle import oracle
+    from mseetc.train import Train
+    from mseetc.efficiency import totalLossesFunction
+    from mseetc.track import computeDiscretizationPoints
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    train.forceMinPn = 0
+    train.powerLosses = totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+    track = cases.track_00(8500)
+    oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+    for N, reserves in ((100, (1.1, 1.2, 1.3)), (300, (1.0, 1.1))):
+        solver = _solver(train, track, N)
+        pts = computeDiscretizationPoints(track, N)
+        prob = oracle.pack_problem(train, pts, dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1),
+                                   2, 0.0, 0.0, track.length)
+        T = [272.4726*r for r in reserves]
+        res = solver.solveBatch(T, terminalVelocity=100/3.6, initialVelocity=1)
+        assert np.all(res['status'] == 0)
+        for k, t in enumerate(T):
+            ref = oracle.solve(prob, prob.scenario(t, terminalVelocity=100/3.6, initialVelocity=1))
+            assert ref['stats']['STATUS'] == 0
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+            assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+            assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2
