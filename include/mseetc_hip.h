@@ -173,6 +173,22 @@ int msd_set_history(msd_handle h, double *host_hist, int cap);
 
 const char *msd_last_error(void);
 
+/*
+ * Post-processing integrations (no problem handle needed).  train5 = {sr0, sr1, sr2, g, rho}; forces are specific [N/kg].
+ *
+ * msd_resimulate replaces simulateCVODES / IVP (mseetc/utils.py:110-194): time-domain re-simulation of every interval of
+ * `nscen` trajectories with accumulated errors; force/dts are [nscen][N], grad/curv [N], outputs [nscen][N+1].
+ * msd_integrate_losses replaces TrainIntegrator.initLosses/calcLosses as used by postProcessDataFrame(integrateLosses=True)
+ * (mseetc/train.py:367-413, utils.py:261-289): energy lost in traction / regenerative braking over every interval [J/kg];
+ * inputs and outputs are [nscen][N]; loss model as in msd_problem_desc.
+ */
+int msd_resimulate(int device, int nscen, int N, const double *train5, const double *force, const double *dts, const double *grad, const double *curv,
+                   const double *s0, const double *v0, double abstol, double reltol, double *pos_out, double *vel_out);
+int msd_integrate_losses(int device, int nscen, int N, const double *train5, int loss_kind, double ct, double cr, const double *loss_table, int loss_table_len,
+                         const double *force_el, const double *force_pn, const double *dts, const double *grad, const double *curv, const double *vstart,
+                         double abstol, double reltol, double *etr_out, double *ebr_out);
+const char *msd_post_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,12 @@
 #ifndef MSD_PHASE_FENCE
 #define MSD_PHASE_FENCE 1
 #endif
+#ifndef MSD_FENCE_PHASES
+#define MSD_FENCE_PHASES 0x3ff      /* bit k: fence after phase k (enum PH_*) */
+#endif
+#ifndef MSD_FENCE_DUALS
+#define MSD_FENCE_DUALS 1           /* also fence multipliers and residuals, not only the primal point */
+#endif
 #ifndef MSD_RICCATI_INLINE
 #define MSD_RICCATI_INLINE 1
 #endif
@@ -652,17 +658,18 @@ struct Solver {
 
     /* phase boundary: keeps the optimiser from carrying subexpressions of the state (slacks, reciprocals, Sigma ...) from one
      * phase to the next in registers -- recomputing them is cheaper than the spills they cause */
-    __device__ __forceinline__ void phase_fence()
+    __device__ __forceinline__ void phase_fence(int phase)
     {
 #if MSD_PHASE_FENCE
+        if (!((MSD_FENCE_PHASES >> phase) & 1)) return;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             Node &nd = n[j];
 #pragma unroll
-            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); opaque(nd.zL[k]); opaque(nd.zU[k]); }
+            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); if (MSD_FENCE_DUALS) { opaque(nd.zL[k]); opaque(nd.zU[k]); } }
 #pragma unroll
-            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); opaque(nd.nu[r]); opaque(nd.zLs[r]); opaque(nd.zUs[r]); opaque(nd.dsg[r]); opaque(resd[j][r]); }
-            opaque(nd.lam[0]); opaque(nd.lam[1]); opaque(resc[j][0]); opaque(resc[j][1]);
+            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); if (MSD_FENCE_DUALS) { opaque(nd.nu[r]); opaque(nd.zLs[r]); opaque(nd.zUs[r]); opaque(nd.dsg[r]); opaque(resd[j][r]); } }
+            if (MSD_FENCE_DUALS) { opaque(nd.lam[0]); opaque(nd.lam[1]); opaque(resc[j][0]); opaque(resc[j][1]); }
         }
 #endif
     }
@@ -950,16 +957,16 @@ struct Solver {
     /* KKT solve: assemble, serial Riccati, read the direction back.  Returns the inertia flag (uniform). */
     __device__ __forceinline__ bool direction(const Ev (&e)[SPT], const int mode, double mu_, double dw)
     {
-        c.mark(PH_OTHER); phase_fence();
+        c.mark(PH_OTHER); phase_fence(PH_OTHER);
         assemble(e, mode, mu_, dw);
-        c.mark(PH_ASSEMBLE); phase_fence();
+        c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
         if (c.tid == 0) {
             const unsigned long long t0 = __builtin_readcyclecounter();
             c.misc[0] = riccati_solve<DYN>(P, c.S) ? 1.0 : 0.0;
             c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
         }
         __syncthreads();
-        c.mark(PH_RICCATI); phase_fence();
+        c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
         const bool ok = uni(c.misc[0]) != 0.0;
         if (ok) {
 #pragma unroll
@@ -983,7 +990,7 @@ struct Solver {
             }
         }
         __syncthreads();
-        c.mark(PH_READBACK); phase_fence();
+        c.mark(PH_READBACK); phase_fence(PH_READBACK);
         return ok;
     }
 
@@ -1304,11 +1311,11 @@ struct Solver {
         const double mu_floor = fmin(P.tol, 1e-4)/(K_EPS + 1.0);
 
         for (iter = 0;; iter++) {
-            c.mark(PH_OTHER); phase_fence();
+            c.mark(PH_OTHER); phase_fence(PH_OTHER);
             if (iter > 0) evaluate_current(e);
-            c.mark(PH_EVAL); phase_fence();
+            c.mark(PH_EVAL); phase_fence(PH_EVAL);
             kkt_pass(e, E);
-            c.mark(PH_KKT); phase_fence();
+            c.mark(PH_KKT); phase_fence(PH_KKT);
             objv = E.obj/U.sf;
             if (iter == 0) { theta_max = 1e4*fmax(1.0, E.theta); theta_min = 1e-4*fmax(1.0, E.theta); }
             if (hist && c.tid == 0 && iter < hist_cap) {
@@ -1391,11 +1398,11 @@ struct Solver {
                 double v2[2] = {dn, rel}; block_reduce<2>(v2, OpMax(), c);
                 gphid = uni(v1[0]); dnorm = uni(v2[0]); rel_step = uni(v2[1]);
             }
-            c.mark(PH_GPHID); phase_fence();
+            c.mark(PH_GPHID); phase_fence(PH_GPHID);
 
             double amax;
             step_lengths(mu, tau, amax, alpha_du);
-            c.mark(PH_STEPLEN); phase_fence();
+            c.mark(PH_STEPLEN); phase_fence(PH_STEPLEN);
 
             const bool tiny = rel_step < 10*DBL_EPSILON;
             double alpha = amax;
@@ -1461,7 +1468,7 @@ struct Solver {
             }
             if (!accepted) { status = MSD_STATUS_LINESEARCH; break; }
             alpha_pr = alpha;
-            c.mark(PH_MERIT); phase_fence();
+            c.mark(PH_MERIT); phase_fence(PH_MERIT);
 
             /* filter augmentation (W&B eq. (22)) */
             if (!tiny && !ftype_armijo && nfilt < FILT_CAP) {
@@ -1505,7 +1512,7 @@ struct Solver {
                     nd.lam[0] += alpha_pr*(dd.lt - nd.lam[0]); nd.lam[1] += alpha_pr*(dd.lb - nd.lam[1]);
                 }
             }
-            c.mark(PH_UPDATE); phase_fence();
+            c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
         }
 
         /* ---- outputs: z in the reference's layout (ocp.py:166-272), multipliers in the reference's row order ---- */

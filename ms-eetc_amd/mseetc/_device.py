@@ -82,6 +82,11 @@ def lib():
         L.msd_timer_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.msd_stage_eval.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, _dptr]
         L.msd_set_history.argtypes = [vp, _dptr, ctypes.c_int]
+        L.msd_post_last_error.restype = ctypes.c_char_p
+        L.msd_resimulate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, _dptr,
+                                     ctypes.c_double, ctypes.c_double, _dptr, _dptr]
+        L.msd_integrate_losses.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, ctypes.c_int,
+                                           _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr]
 
         _lib = L
 
@@ -234,3 +239,46 @@ def stage_eval(model, optsRK, time, velocitySquared, ds, force, gradient, curvat
         prob.close()
 
     return {'time': np.atleast_1d(np.asarray(time, dtype=float)) + out[:, 0], 'velSquared': out[:, 1], 'sens': out}
+
+
+def _check_post(rc):
+
+    if rc != 0:
+        msg = lib().msd_post_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise DeviceError("msd post-processing error {}: {}".format(rc, msg))
+
+
+def _c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def resimulate(model, force, dts, grad, curv, s0, v0, abstol=1e-12, reltol=1e-14, device=0):
+    """
+    Time-domain re-simulation with accumulated errors (utils.py:164-194).  force, dts: (B, N) specific total force and interval
+    durations; grad, curv: (N,); s0, v0: (B,).  Returns positions and velocities (B, N+1).
+    """
+
+    force, dts = _c(force), _c(dts)
+    B, N = force.shape
+    pos, vel = np.zeros((B, N + 1)), np.zeros((B, N + 1))
+    train5 = _c([model.sr0, model.sr1, model.sr2, model.g, model.rho])
+    _check_post(lib().msd_resimulate(int(device), B, N, _d(train5), _d(force), _d(dts), _d(_c(grad)), _d(_c(curv)), _d(_c(s0)), _d(_c(v0)),
+                                     float(abstol), float(reltol), _d(pos), _d(vel)))
+    return pos, vel
+
+
+def integrate_losses(model, lossKind, ct, cr, lossTable, forceEl, forcePn, dts, grad, curv, vstart, abstol=1e-8, reltol=1e-6, device=0):
+    "Energy [J/kg] lost in traction / regenerative braking over every interval (train.py:367-413); arrays (B, N)."
+
+    forceEl, forcePn, dts, vstart = _c(forceEl), _c(forcePn), _c(dts), _c(vstart)
+    B, N = forceEl.shape
+    etr, ebr = np.zeros((B, N)), np.zeros((B, N))
+    train5 = _c([model.sr0, model.sr1, model.sr2, model.g, model.rho])
+    tab = _c(lossTable) if lossTable is not None else None
+    _check_post(lib().msd_integrate_losses(int(device), B, N, _d(train5), int(lossKind), float(ct), float(cr), _d(tab) if tab is not None else None,
+                                           len(tab) if tab is not None else 0, _d(forceEl), _d(forcePn), _d(dts), _d(_c(grad)), _d(_c(curv)), _d(vstart),
+                                           float(abstol), float(reltol), _d(etr), _d(ebr)))
+    return etr, ebr

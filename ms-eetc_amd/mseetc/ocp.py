@@ -302,7 +302,7 @@ class casadiSolver():
 
         print("Solver converged in {:4d} iterations.".format(stats['IP iterations']))
 
-        df = postProcessDataFrame(self.unpack(res['z'][0]), self.points, self.train)
+        df = postProcessDataFrame(self.unpack(res['z'][0]), self.points, self.train, device=self._device)   # CVODES=True like ocp.py:407
 
         return df, stats
 

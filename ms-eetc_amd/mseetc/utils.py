@@ -239,20 +239,16 @@ def curvatureResistance(curv, g, rho):
     return (g*0.5*c/(1 - 30*c) if c <= 1/300 else g*0.65*c/(1 - 55*c))/rho
 
 
-def postProcessDataFrame(dfIn, points, train, CVODES=False, integrateLosses=False, integrateRollingResistance=False):
+def postProcessDataFrame(dfIn, points, train, CVODES=True, integrateLosses=False, integrateRollingResistance=False, device=0):
     """
-    Adds the force / power / energy columns the reference computes after a solve
-    (utils.py:230-259,291-294,330).  Differences, by scope:
-    the CVODES re-simulation columns and the `integrateLosses` /
-    `integrateRollingResistance` branches need an adaptive ODE integrator and are
-    not part of the hot path; requesting them raises NotImplementedError.
+    Adds the force / power / energy columns the reference computes after a solve (utils.py:223-336).  The two integrations
+    run on the GPU (csrc/msd_post.hip): `CVODES=True` re-simulates the trajectory in the time domain with accumulated errors
+    (utils.py:164-194), `integrateLosses=True` integrates the losses over every interval instead of the mid-point rule
+    (utils.py:261-289).  `integrateRollingResistance` is not available.
     """
 
-    if integrateLosses or integrateRollingResistance:
-        raise NotImplementedError("Integrated losses / rolling resistance are outside the device hot path.")
-
-    if CVODES:
-        raise NotImplementedError("CVODES re-simulation is outside the device hot path.")
+    if integrateRollingResistance:
+        raise NotImplementedError("Integrated rolling resistance is outside the device hot path.")
 
     unitScaling = 1e-6/3.6  # Nm -> kWh
     totalMass = train.mass*train.rho
@@ -282,25 +278,52 @@ def postProcessDataFrame(dfIn, points, train, CVODES=False, integrateLosses=Fals
     df['Max. Power [kW]'] = np.maximum(facc*vel/1e3, facc*velNext/1e3)
     df['Min. Power [kW]'] = np.minimum(frgb*vel/1e3, frgb*velNext/1e3)
 
-    losses = train.powerLossesFuns(split=False)   # specific: f [N/kg] -> [W/kg]
-    vm = 0.5*(vel + velNext)
+    grad = df['Gradient [permil]'].values/1000
+    curv = df['Curvature [1/m]'].values
+    times = df.index.values.astype(float)
+    model = train.exportModel()
 
     lossE = np.full(len(df), np.nan)
 
-    for k in range(len(df) - 1):
-        lossE[k] = unitScaling*ds[k]*totalMass*losses(fel[k]/totalMass, vm[k])/vm[k]
+    if not integrateLosses:
+
+        losses = train.powerLossesFuns(split=False)   # specific: f [N/kg] -> [W/kg]
+        vm = 0.5*(vel + velNext)
+
+        for k in range(len(df) - 1):
+            lossE[k] = unitScaling*ds[k]*totalMass*losses(fel[k]/totalMass, vm[k])/vm[k]
+
+    else:
+
+        from . import _device
+
+        fun = train.lossesCallable()
+        kind, ct, cr = classifyLosses(fun)
+        table = fun.parameters(totalMass) if kind == LOSS_DYNAMIC else None
+        etr, ebr = _device.integrate_losses(model, kind, ct, cr, table, [fel[:-1]/totalMass], [fpb[:-1]/totalMass], [np.diff(times)],
+                                            grad[:-1], curv[:-1], [vel[:-1]], device=device)
+        lossE[:-1] = unitScaling*totalMass*np.where(fel[:-1] >= 0, etr[0], ebr[0])     # utils.py:283-287
 
     df['Losses [kWh]'] = lossE
     df['Energy [kWh]'] = unitScaling*ds*facc + unitScaling*ds*frgb + lossE
     df['Energy (pnb) [kWh]'] = -unitScaling*ds*fpb
     df['Energy (kin) [kWh]'] = unitScaling*0.5*train.mass*vel**2   # train.mass, not mass*rho (utils.py:294)
 
-    grad = df['Gradient [permil]'].values/1000
-    curv = df['Curvature [1/m]'].values
-
     rr = (train.r0 + train.r1*vel + train.r2*vel**2)/totalMass
     cr = np.array([curvatureResistance(c, train.g, train.rho) for c in curv])
 
     df['Acceleration [m/s^2]'] = df['Force [N]'].values/totalMass - rr - train.g*grad/train.rho - cr
+
+    if CVODES:   # simulateCVODES (utils.py:164-194, 332-334)
+
+        from . import _device
+
+        total = (df['Force [N]'].values[:-1]/totalMass)
+        p, v = _device.resimulate(model, [total], [np.diff(times)], grad[:-1], curv[:-1], [pos[0]], [vel[0]], device=device)
+
+        df['Position - cvodes [m]'] = p[0]
+        df['Velocity - cvodes [m/s]'] = v[0]
+        df['Error position [m]'] = np.abs(p[0] - pos)
+        df['Error velocity [m/s]'] = np.abs(v[0] - vel)
 
     return df

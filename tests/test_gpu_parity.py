@@ -239,3 +239,49 @@ def test_dynamic_loss_model_vs_oracle():
             assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
             assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
             assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2
+
+
+def test_postprocessing_integrations_vs_scipy():
+    # simulateCVODES (utils.py:164-194) and integrateLosses=True (utils.py:261-289) on the device,
+    # checked against scipy's DOP853 at tight tolerance on the same controls.
+    from scipy.integrate import solve_ivp
+    from mseetc.utils import postProcessDataFrame
+    train, track = cases.train_default(), cases.track_00()
+    solver = _solver(train, track, 100)
+    df, stats = solver.solve(1600)
+    assert df is not None
+    for col in ('Position - cvodes [m]', 'Velocity - cvodes [m/s]', 'Error position [m]', 'Error velocity [m/s]'):
+        assert col in df.columns
+    M = train.mass*train.rho
+    model = train.exportModel()
+    t = df.index.values
+    f = df['Force [N]'].values/M
+    s, v = df['Position [m]'].values[0], df['Velocity [m/s]'].values[0]
+    ps, vs = [s], [v]
+    for i in range(100):
+        G = model.resistance(df['Gradient [permil]'].values[i]/1e3, df['Curvature [1/m]'].values[i])
+        rhs = lambda tt, y: [y[1], f[i] - (model.sr0 + model.sr1*y[1] + model.sr2*y[1]**2) - G]
+        sol = solve_ivp(rhs, [0, t[i + 1] - t[i]], [s, v], method='DOP853', rtol=1e-13, atol=1e-13)
+        s, v = sol.y[0, -1], sol.y[1, -1]
+        ps.append(s); vs.append(v)
+    assert np.max(np.abs(df['Position - cvodes [m]'].values - np.array(ps))) < 1e-6
+    assert np.max(np.abs(df['Velocity - cvodes [m/s]'].values - np.array(vs))) < 1e-8
+    # the RK4/trapezoid transcription error the reference plots (figure5): small but not zero
+    assert 0 < df['Error position [m]'].max() < 50 and 0 < df['Error velocity [m/s]'].max() < 1.0
+
+    # integrated losses vs quadrature of the static loss model along the re-integrated speed of each interval
+    raw = solver.unpack(solver.solveBatch(1600.0)['z'][0])
+    dfb = postProcessDataFrame(raw, solver.points, train, CVODES=False, integrateLosses=True)
+    fun = train.lossesCallable()
+    fel = raw['Force (el) [N]'].values
+    ref = []
+    for i in range(100):
+        G = model.resistance(df['Gradient [permil]'].values[i]/1e3, df['Curvature [1/m]'].values[i])
+        ftot = df['Force [N]'].values[i]/M
+        rhs = lambda tt, y: [ftot - (model.sr0 + model.sr1*y[0] + model.sr2*y[0]**2) - G, fun(fel[i], y[0])]
+        sol = solve_ivp(rhs, [0, t[i + 1] - t[i]], [raw['Velocity [m/s]'].values[i], 0.0], method='DOP853', rtol=1e-12, atol=1e-12)
+        ref.append(sol.y[1, -1]*(1e-6/3.6))
+    got = dfb['Losses [kWh]'].values[:-1]
+    assert np.allclose(got, np.array(ref), rtol=1e-5, atol=1e-9)
+    # mid-point rule (default) and integration agree to the discretisation error
+    assert abs(np.nansum(dfb['Losses [kWh]'].values) - np.nansum(df['Losses [kWh]'].values)) < 0.02*np.nansum(df['Losses [kWh]'].values)
