@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU')
     ap.add_argument('--intervals', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='c1', choices=['c1', 'c2'], help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil (extra measurement)')
     args = ap.parse_args()
 
     import torch
@@ -73,12 +74,15 @@ def main():
 
     B, N = args.batch, args.intervals
 
-    train, track = cases.train_default(), cases.track_00()
+    if args.workload == 'c2':
+        N = 200 if args.intervals == 100 else args.intervals
+
+    train, track = cases.train_default(), (cases.track_00() if args.workload == 'c1' else cases.track_CH())
     opts = dict(numIntervals=N, maxIterations=500, integrationOptions=dict(numSteps=1, numApproxSteps=1))
     solver = casadiSolver(train, track, opts, device=local_rank)
     prob = solver.problem
 
-    T = cases.c1_times(B, seed=20260612 + rank)
+    T = cases.c1_times(B, seed=20260612 + rank) if args.workload == 'c1' else cases.c2_times(B, seed=20260613 + rank)
     scen = solver._scenarios(T, 0, 1, 1)
 
     # inputs resident in HBM before the timed region
@@ -148,8 +152,10 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 1: B={} scenarios per GPU, N={}, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 (JSON defaults, both brakes), "
-                                   "RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1541(1+0.15u_i) seed 20260612+rank, cold start, KKT<=1e-8".format(B, N),
+            "config": {"workload": ("config 1: B={} scenarios per GPU, N={}, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 (JSON defaults, both brakes), "
+                                    "RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1541(1+0.15u_i) seed 20260612+rank, cold start, KKT<=1e-8" if args.workload == 'c1' else
+                                    "config 2 (extra): B={} scenarios per GPU, N={}, track CH_StGallen_Wil, train NL_Intercity_VIRM6, RK4 numSteps=1 numApproxSteps=1, "
+                                    "v0=vN=1, T_i=1242(1+0.15u_i) seed 20260613+rank, cold start, KKT<=1e-8").format(B, N),
                        "batch_per_gpu": B, "num_intervals": N, "converged": n_ok_all, "scenarios": B*world,
                        "kkt_cycle_share": float(np.sum(st[:, ST['CYC_KKT']])/max(1.0, np.sum(st[:, ST['CYC_TOTAL']]))), "cycles_per_solve_mean": float(np.mean(st[:, ST['CYC_TOTAL']])),
                        "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)), "parallelism": "scenarios sharded, no collective"},

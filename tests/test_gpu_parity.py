@@ -285,3 +285,56 @@ def test_postprocessing_integrations_vs_scipy():
     assert np.allclose(got, np.array(ref), rtol=1e-5, atol=1e-9)
     # mid-point rule (default) and integration agree to the discretisation error
     assert abs(np.nansum(dfb['Losses [kWh]'].values) - np.nansum(df['Losses [kWh]'].values)) < 0.02*np.nansum(df['Losses [kWh]'].values)
+
+
+def test_edge_cases_sizes_and_errors():
+    from mseetc.ocp import casadiSolver
+    from mseetc import _device
+    from oracle import oracle
+    train = cases.train_default()
+    # smallest horizons the grid allows on a single-section track: N = 1, 2, 3 (one wave, mostly idle lanes)
+    track = cases.track_00(crop=3000)
+    for N, T in ((1, 400.0), (2, 330.0), (3, 300.0)):
+        s = _solver(train, track, N)
+        prob = cases.oracle_problem(train, track, N)
+        res = s.solveBatch([T])
+        ref = oracle.solve(prob, prob.scenario(T))
+        assert res['status'][0] == int(ref['stats']['STATUS'])
+        if res['status'][0] == 0:
+            assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ'])
+    # geometry boundaries: 63/64 intervals (one node per lane <-> two), 127/128 (one wave <-> two)
+    track = cases.track_00(crop=29000)     # (a crop where no fill-in node coincides with the 25 km speed-limit breakpoint)
+    for N in (63, 64, 127, 128):
+        s = _solver(train, track, N)
+        prob = cases.oracle_problem(train, track, N)
+        res = s.solveBatch([1100.0, 1250.0])
+        assert np.all(res['status'] == 0)
+        for k, T in enumerate((1100.0, 1250.0)):
+            ref = oracle.solve(prob, prob.scenario(T))
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+    # largest horizon family (320 threads x 2 nodes) and the limit: N = 560 runs, N = 600 does not fit the 160 KB of LDS -> rejected loudly
+    track = cases.track_00()
+    s = _solver(train, track, 560)
+    res = s.solveBatch([1541.0])
+    prob = cases.oracle_problem(train, track, 560)
+    ref = oracle.solve(prob, prob.scenario(1541.0))
+    assert res['status'][0] == 0 and abs(res['cost'][0] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+    with pytest.raises(_device.DeviceError):
+        _solver(train, track, 600).solveBatch([1541.0])
+    # infeasible scenarios fail individually without poisoning their neighbours (failure isolation)
+    s = _solver(train, track, 100)
+    res = s.solveBatch([1541.0, 900.0, 1600.0, 1000.0])
+    assert list(res['status'] >= 0) == [True, False, True, False]
+    alone = s.solveBatch([1541.0, 1600.0])
+    assert np.array_equal(res['z'][[0, 2]], alone['z'])
+    # bad arguments are ValueErrors like the reference's (ocp.py:314-320)
+    with pytest.raises(ValueError):
+        s.solveBatch([-5.0])
+    with pytest.raises(ValueError):
+        s.solveBatch([100.0], initialTime=-1.0)
+    with pytest.raises(ValueError):
+        s.solveBatch([1541.0], mass=[-1.0])
+    # maxIterations is honoured and reported like IPOPT's Maximum_Iterations_Exceeded
+    few = casadiSolver(train, track, dict(numIntervals=100, maxIterations=5, integrationOptions=dict(numApproxSteps=1)))
+    r = few.solveBatch([1541.0])
+    assert r['status'][0] == -1 and r['iterations'][0] == 5
