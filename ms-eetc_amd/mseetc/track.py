@@ -165,22 +165,27 @@ class Track():
 
     def lengthOk(self):
 
-        return self.length is not None and self.length > 0 and not np.isinf(self.length)
+        L = self.length
+
+        return L is not None and 0 < L < np.inf
+
+    def _profileOk(self, df):
+
+        return bool(len(df) > 0 and checkDataFrame(df, self.length))
 
     def gradientsOk(self):
 
-        return bool(self.gradients.shape[0] > 0 and checkDataFrame(self.gradients, self.length))
+        return self._profileOk(self.gradients)
 
     def speedLimitsOk(self):
 
-        return bool(self.speedLimits.shape[0] > 0 and checkDataFrame(self.speedLimits, self.length))
+        return self._profileOk(self.speedLimits)
 
     def curvaturesOk(self):
 
-        if (np.abs(self.curvatures[_CURV].values) > Track.CURVATURE_THRESHOLD).any():
-            return False
+        tooTight = np.abs(self.curvatures[_CURV].values) > Track.CURVATURE_THRESHOLD
 
-        return bool(self.curvatures.shape[0] > 0 and checkDataFrame(self.curvatures, self.length))
+        return (not tooTight.any()) and self._profileOk(self.curvatures)
 
     def checkFields(self):
 
@@ -190,102 +195,98 @@ class Track():
         if self.altitude is None or np.isinf(self.altitude):
             raise ValueError("Altitude must be a number, not {}!".format(self.altitude))
 
-        if not self.gradientsOk():
-            raise ValueError("Issue with track gradients!")
-
-        if not self.speedLimitsOk():
-            raise ValueError("Issue with track speed limits!")
-
-        if not self.curvaturesOk():
-            raise ValueError("Issue with track curvatures!")
+        for ok, what in ((self.gradientsOk, 'gradients'), (self.speedLimitsOk, 'speed limits'), (self.curvaturesOk, 'curvatures')):
+            if not ok():
+                raise ValueError("Issue with track {}!".format(what))
 
     # ---- importers --------------------------------------------------------
 
-    def importGradientTuples(self, tuples, unit='permil'):
+    def _requireLength(self, what):
 
         if not self.lengthOk():
-            raise ValueError("Cannot import gradients without a valid track length!")
+            raise ValueError("Cannot import {} without a valid track length!".format(what))
 
-        if unit not in {'permil'}:
+    def importGradientTuples(self, tuples, unit='permil'):
+
+        self._requireLength('gradients')
+
+        if unit != 'permil':
             raise ValueError("Specified gradient unit not supported!")
 
-        self.gradients = importTuples(tuples, _POS, _GRAD)
-
-        checkDataFrame(self.gradients, self.length)
+        frame = importTuples(tuples, _POS, _GRAD)
+        checkDataFrame(frame, self.length)
+        self.gradients = frame
 
     def importSpeedLimitTuples(self, tuples, unit='km/h'):
 
-        if not self.lengthOk():
-            raise ValueError("Cannot import speed limits without a valid track length!")
+        self._requireLength('speed limits')
 
-        if unit not in {'km/h', 'm/s'}:
+        if unit not in ('km/h', 'm/s'):
             raise ValueError("Specified speed unit not supported!")
 
-        self.speedLimits = importTuples([(p, convertUnit(v, unit)) for p, v in tuples], _POS, _VLIM)
-
-        checkDataFrame(self.speedLimits, self.length)
+        frame = importTuples([(pos, convertUnit(lim, unit)) for pos, lim in tuples], _POS, _VLIM)
+        checkDataFrame(frame, self.length)
+        self.speedLimits = frame
 
     def importCurvatureTuples(self, tuples, unitRadiusStart='m', unitRadiusEnd='m', clothoidSamplingInterval=None):
 
-        if not self.lengthOk():
-            raise ValueError("Cannot import curvature without a valid track length!")
+        self._requireLength('curvature')
 
-        if unitRadiusStart not in {'m', 'km'} or unitRadiusEnd not in {'m', 'km'}:
+        if not {unitRadiusStart, unitRadiusEnd} <= {'m', 'km'}:
             raise ValueError("Specified curvature radius unit not supported!")
 
-        # "infinity" -> float inf -> curvature 0
-        radii = [(p, convertUnit(float(r0), unitRadiusStart), convertUnit(float(r1), unitRadiusEnd)) for p, r0, r1 in tuples]
+        # float("infinity") is inf, i.e. a straight section
+        sections = [(pos, convertUnit(float(ra), unitRadiusStart), convertUnit(float(rb), unitRadiusEnd)) for pos, ra, rb in tuples]
 
-        self.curvatures = importTuples(self.sampleClothoid(radii, clothoidSamplingInterval), _POS, [_CURV])
-
-        checkDataFrame(self.curvatures, self.length)
+        frame = importTuples(self.sampleClothoid(sections, clothoidSamplingInterval), _POS, [_CURV])
+        checkDataFrame(frame, self.length)
+        self.curvatures = frame
 
     def sampleClothoid(self, tuples, ds=None):
         """
-        Piecewise-constant approximation of transition curves (reference: track.py:270-348).
-        A section (p, Rstart, Rend) whose two curvatures differ is a clothoid with curvature
-        linear in position; it is cut into floor(len/ds) pieces of length ds (the last one
-        absorbs the remainder) and each piece gets the mean of its end curvatures.  Without
-        ds (or with ds longer than the section) the whole section gets the mean.
+        Piecewise-constant curvature from (position, radius at start, radius at end) sections (reference: track.py:270-348).
+        Equal end radii: the section keeps its curvature.  Otherwise the section is a clothoid (curvature linear in
+        position); with a sampling interval ds it is cut into floor(length/ds) pieces, each carrying the mean of the
+        curvatures at its two ends, the last piece reaching to the end of the section; without ds (or ds longer than the
+        section) the whole section carries the mean of its end curvatures.
         """
 
-        for sec in tuples:
-            if sec[1] == 0 or sec[2] == 0:
-                raise ValueError("Curvature radius cannot be 0!")
+        starts = [sec[0] for sec in tuples]
 
-        if any(sec[0] < 0 for sec in tuples):
+        if any(r == 0 for sec in tuples for r in sec[1:3]):
+            raise ValueError("Curvature radius cannot be 0!")
+
+        if min(starts, default=0) < 0:
             raise ValueError("Positions cannot be negative!")
 
-        if any(tuples[k][0] == tuples[k + 1][0] for k in range(len(tuples) - 1)):
+        if any(a == b for a, b in zip(starts, starts[1:])):
             raise ValueError("Positions must be monotonically increasing")
 
         if ds is not None and ds <= 0:
             raise ValueError("Discretization step must be greater than zero or None!")
 
+        ends = starts[1:] + [self.length]
         out = []
 
-        for k, (start, rStart, rEnd) in enumerate(tuples):
+        for (start, ra, rb), end in zip(tuples, ends):
 
-            kStart, kEnd = 1/rStart, 1/rEnd
+            k0, k1 = 1/ra, 1/rb
 
-            if abs(kStart - kEnd) <= sys.float_info.epsilon:
-                out.append((start, kStart))
+            if abs(k0 - k1) <= sys.float_info.epsilon:
+                out.append((start, k0))
                 continue
 
-            end = tuples[k + 1][0] if k + 1 < len(tuples) else self.length
-            pieces = 0 if ds is None else int((end - start)/ds)
+            pieces = int((end - start)/ds) if ds is not None else 0
 
             if pieces == 0:
-                out.append((start, (kStart + kEnd)/2))
+                out.append((start, (k0 + k1)/2))
                 continue
 
-            alpha = (end - start)/(kEnd - kStart)  # K(s) = kStart + (s - start)/alpha
+            alpha = (end - start)/(k1 - k0)      # K(s) = k0 + (s - start)/alpha
 
             for j in range(pieces):
-
-                kHere = kStart + j*ds/alpha
-                mean = (kHere + kEnd)/2 if j == pieces - 1 else kHere + ds/(2*alpha)
-
+                here = k0 + j*ds/alpha
+                mean = (here + k1)/2 if j == pieces - 1 else here + ds/(2*alpha)
                 out.append((start + j*ds, mean))
 
         return out

@@ -106,11 +106,11 @@ class Train():
         self.checkFields()
 
     def checkFields(self):
+        "Same rules and messages as the reference (train.py:116-172), table driven."
 
-        def bad(x):
-            return x is None or (isinstance(x, float) and math.isinf(x))
+        inf = lambda x: x is not None and np.isinf(x)
 
-        if self.mass is None or self.mass < 0 or np.isinf(self.mass):
+        if self.mass is None or self.mass < 0 or inf(self.mass):
             raise ValueError("Train mass must be a positive number, not {}!".format(self.mass))
 
         if self.g is None or not 9 <= self.g <= 10:
@@ -119,37 +119,38 @@ class Train():
         if self.rho is None or not 1 <= self.rho <= 1.5:
             raise ValueError("Rotation mass factor must be between 1 and 1.5, not {}!".format(self.rho))
 
-        if self.velocityMax is None or self.velocityMax <= 0 or np.isinf(self.velocityMax):
+        if self.velocityMax is None or self.velocityMax <= 0 or inf(self.velocityMax):
             raise ValueError("Maximum velocity must be a strictly positive number, not {}!".format(self.velocityMax))
 
-        if self.forceMax is not None and (self.forceMax <= 0 or np.isinf(self.forceMax)):
-            raise ValueError("Maximum traction force must be strictly positive or free (None), not {}!".format(self.forceMax))
+        # (attribute, admissible if None, predicate of a bad value, message)
+        rules = (
+            ('forceMax', lambda x: x <= 0, "Maximum traction force must be strictly positive or free (None), not {}!"),
+            ('forceMinPn', lambda x: x > 0, "Maximum pneumatic braking force must be negative, zero or free (None), not {}!"),
+            ('forceMin', lambda x: x > 0, "Maximum regenerative braking force must be negative, zero or free (None), not {}!"),
+        )
 
-        if self.forceMinPn is not None and (self.forceMinPn > 0 or np.isinf(self.forceMinPn)):
-            raise ValueError("Maximum pneumatic braking force must be negative, zero or free (None), not {}!".format(self.forceMinPn))
-
-        if self.forceMin is not None and (self.forceMin > 0 or np.isinf(self.forceMin)):
-            raise ValueError("Maximum regenerative braking force must be negative, zero or free (None), not {}!".format(self.forceMin))
+        for name, bad, msg in rules:
+            val = getattr(self, name)
+            if val is not None and (bad(val) or inf(val)):
+                raise ValueError(msg.format(val))
 
         if self.forceMin == 0 and self.forceMinPn == 0:
             raise ValueError("Both brakes cannot be deactivated simultaneously!")
 
-        if self.powerMax is not None and (self.powerMax <= 0 or np.isinf(self.powerMax)):
-            raise ValueError("Maximum traction power must be strictly positive or free (None), not {}!".format(self.powerMax))
+        rules = (
+            ('powerMax', lambda x: x <= 0, "Maximum traction power must be strictly positive or free (None), not {}!"),
+            ('powerMin', lambda x: x >= 0, "Maximum regenerative brake power must be strictly negative or free (None), not {}!"),
+            ('accMax', lambda x: x <= 0, "Maximum acceleration must be strictly positive or free (None), not {}!"),
+            ('accMin', lambda x: x >= 0, "Maximum deceleration must be strictly negative or free (None), not {}!"),
+        )
 
-        if self.powerMin is not None and (self.powerMin >= 0 or np.isinf(self.powerMin)):
-            raise ValueError("Maximum regenerative brake power must be strictly negative or free (None), not {}!".format(self.powerMin))
-
-        if self.accMax is not None and (self.accMax <= 0 or np.isinf(self.accMax)):
-            raise ValueError("Maximum acceleration must be strictly positive or free (None), not {}!".format(self.accMax))
-
-        if self.accMin is not None and (self.accMin >= 0 or np.isinf(self.accMin)):
-            raise ValueError("Maximum deceleration must be strictly negative or free (None), not {}!".format(self.accMin))
+        for name, bad, msg in rules:
+            val = getattr(self, name)
+            if val is not None and (bad(val) or inf(val)):
+                raise ValueError(msg.format(val))
 
         for name in ('r0', 'r1', 'r2'):
-
             coef = getattr(self, name)
-
             if coef is None or coef < 0:
                 raise ValueError("Rolling resistance coefficient {} must be positive, not {}!".format(name, coef))
 
