@@ -149,6 +149,18 @@ int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double
 /* msd_solve_batch with per-scenario rolling-stock overrides: overrides[nscen][MSD_OV_COUNT] (host), NULL = none */
 int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats,
                        float *kernel_ms);
+
+/*
+ * msd_solve_batch_ex with a primal warm start (the reference always cold-starts,
+ * ocp.py:325-339, so this has no reference counterpart: it reaches the same optimum in fewer iterations).
+ *   z_guess    : [nscen][nz] starting points in the layout of z_out (e.g. the previous MPC solution moved to the new
+ *                grid); NULL = cold start, mu_init/bound_push ignored
+ *   mu_init    : initial barrier parameter (IPOPT option mu_init; cold start uses 0.1)
+ *   bound_push : relative distance the guess keeps from bounds (IPOPT warm_start_bound_push/_frac; cold start 1e-2).
+ * Bound and slack multipliers start at mu_init/slack, equality multipliers from the least-squares estimate.
+ */
+int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init,
+                         double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms);
 int msd_synchronize(msd_handle h);
 
 /* device scratch management for callers without their own allocator (ctypes): */

@@ -8,6 +8,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,8 +43,8 @@ struct msd_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr, *d_loss = nullptr;
     /* grow-only scratch of the host-buffer entry point */
-    double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr;
-    int cap_scen = 0;
+    double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
+    int cap_scen = 0, cap_guess = 0;
     double *h_hist = nullptr;
     int hist_cap = 0;
 };
@@ -101,6 +102,7 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
+    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0;
 
 #define UPLOAD(dst, src, n)                                                                    \
     do {                                                                                       \
@@ -135,7 +137,7 @@ int msd_problem_destroy(msd_handle h)
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
     hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax); hipFree(h->d_loss);
-    hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist);
+    hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -146,10 +148,15 @@ int msd_problem_destroy(msd_handle h)
 int msd_problem_nz(msd_handle h) { return h ? (4 + h->P.withPn)*h->P.N + 2 : 0; }
 int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 : 0) + 3 + (h->P.energyOpt ? 2 : 0) : 0; }
 
-static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap)
+struct WarmStart { const double *d_guess = nullptr; double mu = 0, push = 0; };
+
+static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
+                  const WarmStart &ws = WarmStart())
 {
     const int grid = nscen < h->max_grid ? nscen : h->max_grid;
-    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, h->P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap);
+    msd::DevProb P = h->P;
+    P.guess = ws.d_guess; P.warmMu = ws.mu; P.warmPush = ws.push;
+    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap);
     HIP_TRY(hipGetLastError());
     return MSD_OK;
 }
@@ -183,7 +190,15 @@ int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, 
 
 int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats, float *kernel_ms)
 {
+    return msd_solve_batch_warm(h, nscen, scen, overrides, nullptr, 0.0, 0.0, z_out, lam_out, stats, kernel_ms);
+}
+
+int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
+                         double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
     if (!h || nscen < 1 || !scen || !z_out || !stats) return fail(MSD_E_INVALID, "bad argument");
+    if (z_guess && (!(mu_init > 0) || !(mu_init <= 1e3) || !(bound_push > 0) || !(bound_push <= 0.5)))
+        return fail(MSD_E_INVALID, "warm start needs 0 < mu_init <= 1e3 and 0 < bound_push <= 0.5");
     if (overrides)
         for (int k = 0; k < nscen; k++) {
             const double *o = overrides + (size_t)MSD_OV_COUNT*k;
@@ -215,10 +230,22 @@ int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double
         HIP_TRY(hipMemsetAsync(h->d_hist, 0, sizeof(double)*msd::HIST_COLS*h->hist_cap, h->stream));
         d_hist = h->d_hist;
     }
+    WarmStart ws;
+    if (z_guess) {
+        for (size_t k = 0; k < nz*(size_t)nscen; k++)
+            if (!std::isfinite(z_guess[k])) return fail(MSD_E_INVALID, "warm start guess must be finite");
+        if (nscen > h->cap_guess) {
+            hipFree(h->d_guess); h->d_guess = nullptr; h->cap_guess = 0;
+            HIP_TRY(hipMalloc((void **)&h->d_guess, sizeof(double)*nz*nscen));
+            h->cap_guess = nscen;
+        }
+        HIP_TRY(hipMemcpyAsync(h->d_guess, z_guess, sizeof(double)*nz*nscen, hipMemcpyHostToDevice, h->stream));
+        ws.d_guess = h->d_guess; ws.mu = mu_init; ws.push = bound_push;
+    }
     HIP_TRY(hipMemcpyAsync(h->d_scen, scen, sizeof(double)*MSD_SC_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
     if (overrides) HIP_TRY(hipMemcpyAsync(h->d_ovr, overrides, sizeof(double)*MSD_OV_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap);
+    int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap, ws);
     if (rc != MSD_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));

@@ -61,11 +61,14 @@ struct DevProb {
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     const double *ds, *grad, *curv, *bmax;
     const double *loss;      /* parameter block of the dynamic loss model (lossKind == 2), see DynLoss */
+    /* primal warm start (set per launch by msd_solve_batch_warm, null = the reference's cold start) */
+    const double *guess;
+    double warmMu, warmPush;
 };
 
 /* IPOPT default option values */
 constexpr double K_BOUND_RELAX = 1e-8;
-constexpr double K_PUSH = 1e-2, K_FRAC = 1e-2;
+constexpr double K_PUSH = 1e-2;      /* bound_push = bound_frac */
 constexpr double K_MU_INIT = 0.1, K_EPS = 10.0, K_MU_LIN = 0.2, K_MU_SUP = 1.5, K_TAU_MIN = 0.99;
 constexpr double K_SMAX = 100.0, K_SIGMA = 1e10, K_D = 1e-5;
 constexpr double G_THETA = 1e-5, G_PHI = 1e-8, K_DELTA = 1.0, S_THETA = 1.1, S_PHI = 2.3, ETA_PHI = 1e-8;
@@ -346,15 +349,16 @@ __device__ __forceinline__ void bar_terms(double x, double lb, double ub, bool h
     Sg = S; gphi = g;
 }
 
-__device__ __forceinline__ double push_in(double x, double lb, double ub, bool hasL, bool hasU)
+/* kp: bound_push = bound_frac (1e-2) for a cold start, the caller's push for a warm one */
+__device__ __forceinline__ double push_in(double x, double lb, double ub, bool hasL, bool hasU, double kp)
 {
     if (hasL && hasU) {
-        double pL = fmin(K_PUSH*fmax(1.0, fabs(lb)), K_FRAC*(ub - lb));
-        double pU = fmin(K_PUSH*fmax(1.0, fabs(ub)), K_FRAC*(ub - lb));
+        double pL = fmin(kp*fmax(1.0, fabs(lb)), kp*(ub - lb));
+        double pU = fmin(kp*fmax(1.0, fabs(ub)), kp*(ub - lb));
         if (x < lb + pL) x = lb + pL;
         if (x > ub - pU) x = ub - pU;
-    } else if (hasL) { double pL = K_PUSH*fmax(1.0, fabs(lb)); if (x < lb + pL) x = lb + pL; }
-    else if (hasU) { double pU = K_PUSH*fmax(1.0, fabs(ub)); if (x > ub - pU) x = ub - pU; }
+    } else if (hasL) { double pL = kp*fmax(1.0, fabs(lb)); if (x < lb + pL) x = lb + pL; }
+    else if (hasU) { double pU = kp*fmax(1.0, fabs(ub)); if (x > ub - pU) x = ub - pU; }
     return x;
 }
 
@@ -908,7 +912,7 @@ struct Solver {
                     if (!U.rowOn[r]) continue;
                     double Sg, coef;
                     if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*resd[j][r] + gphi; }
-                    else { Sg = 1.0; coef = -(U.rL[r] ? 1.0 : 0.0) + (U.rU[r] ? 1.0 : 0.0); }
+                    else { Sg = 1.0; coef = -nd.zLs[r] + nd.zUs[r]; }
                     hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
                     Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
                     Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
@@ -925,7 +929,7 @@ struct Solver {
                     Sv[k] = 0; gv[k] = 0;
                     if (!nd.on(k)) continue;
                     if (mode == MODE_NEWTON) { var_terms(j, k, mu_, Sv[k], gv[k]); Sv[k] += dw; }
-                    else { Sv[k] = 1.0; gv[k] = -1.0 + (hasU(k) ? 1.0 : 0.0); }
+                    else { Sv[k] = 1.0; gv[k] = -nd.zL[k] + nd.zU[k]; }
                 }
                 Htt += Sv[VT]; ht += gv[VT]; Hbb += Sv[VB]; hb += gv[VB]; Hff += Sv[VF]; hf += gv[VF]; Hpp += Sv[VP]; hp += gv[VP]; Hss += Sv[VS]; hs += gv[VS];
                 double *s = c.S + nd.i*S_STRIDE;
@@ -985,7 +989,7 @@ struct Solver {
                     if (!U.rowOn[r]) continue;
                     const double lin = gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1;
                     /* Newton: slack step; least squares: nu = Sigma dsigma + (-zL + zU) with Sigma = 1, parked in dsg */
-                    nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-(U.rL[r] ? 1.0 : 0.0) + (U.rU[r] ? 1.0 : 0.0));
+                    nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-nd.zLs[r] + nd.zUs[r]);
                 }
             }
         }
@@ -1149,9 +1153,11 @@ struct Solver {
     }
 
     /* ---------------------------------------------------------------------------------------- */
-    __device__ __forceinline__ void run(const double *scen, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+    __device__ __forceinline__ void run(const double *scen, const double *guess, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
     {
         const int N = P.N;
+        const bool warm = guess != nullptr;
+        const double kp = warm ? P.warmPush : K_PUSH;
         const unsigned long long cyc0 = __builtin_readcyclecounter();
         if (c.tid == 0) { c.misc[1] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
         c.tmark = cyc0;
@@ -1179,6 +1185,13 @@ struct Solver {
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
             nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = P.withPn ? -0.1 : 0.0; nd.x[VS] = 1;
+            if (warm && node) {
+                /* layout of z_out (ocp.py:166-272): [Fel,(Fpb),s,t,b] per interval, then t_N, b_N */
+                const int nu = 1 + P.withPn;
+                const double *q = guess + (nu + 3)*nd.i;
+                if (ival) { nd.x[VF] = q[0]; nd.x[VP] = P.withPn ? q[1] : 0.0; nd.x[VS] = q[nu]; nd.x[VT] = q[nu + 1]; nd.x[VB] = q[nu + 2]; }
+                else { nd.x[VT] = q[0]; nd.x[VB] = q[1]; }
+            }
             if (nd.i == 0) { nd.x[VT] = t0; nd.x[VB] = v0sq; }
             if (nd.i == N) nd.x[VB] = vNsq;
 #pragma unroll
@@ -1254,8 +1267,9 @@ struct Solver {
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 if (!n[j].on(k)) continue;
-                n[j].x[k] = push_in(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k));
-                n[j].zL[k] = 1.0; n[j].zU[k] = hasU(k) ? 1.0 : 0.0;
+                n[j].x[k] = push_in(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k), kp);
+                n[j].zL[k] = warm ? P.warmMu/(n[j].x[k] - lbv(k)) : 1.0;
+                n[j].zU[k] = hasU(k) ? (warm ? P.warmMu/(ubv(j, k) - n[j].x[k]) : 1.0) : 0.0;
             }
         }
         evaluate_current(e);     /* resd = d(x) since the slacks are still zero */
@@ -1266,13 +1280,14 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 if (!U.rowOn[r]) continue;
-                n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], U.rL[r], U.rU[r]);
-                n[j].zLs[r] = U.rL[r] ? 1.0 : 0.0; n[j].zUs[r] = U.rU[r] ? 1.0 : 0.0;
+                n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], kp);
+                n[j].zLs[r] = U.rL[r] ? (warm ? P.warmMu/(n[j].sg[r] - U.dL[r]) : 1.0) : 0.0;
+                n[j].zUs[r] = U.rU[r] ? (warm ? P.warmMu/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
                 resd[j][r] -= n[j].sg[r];
             }
         }
 
-        double mu = K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
+        double mu = warm ? P.warmMu : K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
         {
@@ -1576,7 +1591,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
         }
         Solver<SPT, DYN> s(Ps, c);
-        s.run(scen + (size_t)MSD_SC_COUNT*sidx, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
+        s.run(scen + (size_t)MSD_SC_COUNT*sidx, P.guess ? P.guess + (size_t)nz*sidx : nullptr, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
               stats + (size_t)MSD_ST_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
         __syncthreads();
     }

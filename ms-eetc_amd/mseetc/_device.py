@@ -72,6 +72,8 @@ def lib():
         L.msd_problem_rows_per_interval.argtypes = [vp]
         L.msd_solve_batch.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_ex.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
+        L.msd_solve_batch_warm.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr,
+                                           ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
         L.msd_synchronize.argtypes = [vp]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
@@ -155,8 +157,11 @@ class DeviceProblem():
         except Exception:
             pass
 
-    def solve_batch(self, scen, want_multipliers=False, history=0, overrides=None):
-        "scen: (B,4) host array (t0, T, v0sq, vNsq), overrides: optional (B, OV['COUNT']) -> dict(z, stats, lam_g, kernel_ms[, hist])"
+    def solve_batch(self, scen, want_multipliers=False, history=0, overrides=None, guess=None, warmMu=1e-2, warmPush=1e-3):
+        """
+        scen: (B,4) host array (t0, T, v0sq, vNsq), overrides: optional (B, OV['COUNT']), guess: optional (B, nz) primal
+        warm start (barrier parameter warmMu, interior push warmPush) -> dict(z, stats, lam_g, kernel_ms[, hist])
+        """
 
         L = lib()
         scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
@@ -174,8 +179,12 @@ class DeviceProblem():
         if overrides is not None:
             overrides = np.ascontiguousarray(overrides, dtype=np.float64).reshape(B, OV['COUNT'])
 
-        _check(L.msd_solve_batch_ex(self._h, B, _d(scen), _d(overrides) if overrides is not None else None, _d(z),
-                                    _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+        if guess is not None:
+            guess = np.ascontiguousarray(guess, dtype=np.float64).reshape(B, self.nz)
+
+        _check(L.msd_solve_batch_warm(self._h, B, _d(scen), _d(overrides) if overrides is not None else None,
+                                      _d(guess) if guess is not None else None, float(warmMu), float(warmPush), _d(z),
+                                      _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
 
         out = dict(z=z, stats=st, lam_g=lam, kernel_ms=float(ms.value))
 

@@ -15,12 +15,56 @@ import numpy as np
 from .ocp import casadiSolver
 
 
+def transferSolution(z, positionsOld, positionsNew, withPnBrake):
+    """
+    Move solutions z (B, nz_old), laid out as ocp.py:166-272 on the grid `positionsOld`, onto the grid `positionsNew`
+    (same length unit and origin, covered by the old grid): states t and b = v^2 are interpolated linearly in position,
+    the piecewise-constant controls and slacks are taken from the old interval that contains the midpoint of the new
+    one.  Used to warm-start a re-solve on a shorter horizon.  Returns (B, nz_new).
+    """
+
+    z = np.atleast_2d(np.asarray(z, dtype=float))
+    pOld = np.asarray(positionsOld, dtype=float)
+    pNew = np.asarray(positionsNew, dtype=float)
+    No, Nn = len(pOld) - 1, len(pNew) - 1
+    pn = int(bool(withPnBrake))
+    stp = 4 + pn
+
+    if z.shape[1] != stp*No + 2:
+        raise ValueError("Solution does not match the old grid!")
+
+    body = z[:, :stp*No].reshape(-1, No, stp)
+    tOld = np.concatenate([body[:, :, 2 + pn], z[:, stp*No:stp*No + 1]], axis=1)
+    bOld = np.concatenate([body[:, :, 3 + pn], z[:, stp*No + 1:stp*No + 2]], axis=1)
+
+    k = np.clip(np.searchsorted(pOld, pNew, side='right') - 1, 0, No - 1)
+    w = np.clip((pNew - pOld[k])/(pOld[k + 1] - pOld[k]), 0.0, 1.0)
+    tNew = tOld[:, k]*(1 - w) + tOld[:, k + 1]*w
+    bNew = bOld[:, k]*(1 - w) + bOld[:, k + 1]*w
+
+    mid = 0.5*(pNew[:-1] + pNew[1:])
+    km = np.clip(np.searchsorted(pOld, mid, side='right') - 1, 0, No - 1)
+
+    out = np.empty((z.shape[0], stp*Nn + 2))
+    nb = out[:, :stp*Nn].reshape(-1, Nn, stp)
+    nb[:, :, :2 + pn] = body[:, km, :2 + pn]
+    nb[:, :, 2 + pn] = tNew[:, :Nn]
+    nb[:, :, 3 + pn] = bNew[:, :Nn]
+    out[:, stp*Nn] = tNew[:, Nn]
+    out[:, stp*Nn + 1] = bNew[:, Nn]
+
+    return out
+
+
 def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2, noise=0.0, seed=0,
-                     initialTime=0.0, initialVelocity=1.0, terminalVelocity=1.0, device=0, solverFactory=None):
+                     initialTime=0.0, initialVelocity=1.0, terminalVelocity=1.0, device=0, solverFactory=None,
+                     warmStart=False, warmMu=1e-2, warmPush=1e-3):
     """
     Re-solve `numResolves` times; after each solve the train advances `stride` intervals of the current grid, the
     measured time and speed at that node are perturbed by `noise` (relative, standard normal) and the remaining
-    horizon (stride intervals shorter) is solved again from a cold start.
+    horizon (stride intervals shorter) is solved again -- from a cold start like the reference, or with
+    `warmStart=True` from the previous solution moved onto the new grid (scenarios whose previous solve failed are
+    re-solved cold in a second launch).
 
     terminalTime: array (B,) of arrival times (absolute).
     Returns a list of dicts per re-solve: position [m], numIntervals, t0 (B,), v0 (B,), status, iterations, cost, z.
@@ -38,6 +82,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     v_now = np.full(B, float(initialVelocity))
     position = 0.0
     current = copy.deepcopy(track)
+    previous = None
     log = []
 
     for k in range(numResolves):
@@ -51,7 +96,21 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         opts['numIntervals'] = Nk
 
         solver = make(train, current, opts)
-        res = solver.solveBatch(T, initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
+        common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
+
+        if warmStart and previous is not None:
+            zPrev, posPrev, okPrev = previous
+            guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
+            res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, **common)
+            redo = np.flatnonzero(~okPrev | (res['status'] < 0))
+            if redo.size:
+                sub = solver.solveBatch(T[redo], initialTime=t_now[redo], terminalVelocity=terminalVelocity, initialVelocity=v_now[redo])
+                for key in ('z', 'status', 'iterations', 'cost'):
+                    res[key][redo] = sub[key]
+        else:
+            res = solver.solveBatch(T, **common)
+
+        previous = (res['z'], position + solver.points.index.values, res['status'] >= 0)
 
         log.append(dict(position=position, numIntervals=Nk, t0=t_now.copy(), v0=v_now.copy(), status=res['status'].copy(),
                         iterations=res['iterations'].copy(), cost=res['cost'].copy(), z=res['z']))

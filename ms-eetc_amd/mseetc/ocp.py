@@ -232,10 +232,12 @@ class casadiSolver():
         return out
 
     def solveBatch(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1, multipliers=False,
-                   mass=None, r0=None, r1=None, r2=None):
+                   mass=None, r0=None, r1=None, r2=None, guess=None, warmMu=1e-2, warmPush=1e-3):
         """
         Solve many scenarios of this problem in one launch.  Arguments broadcast against each other; `mass`, `r0`, `r1`, `r2`
-        (SI units, scalars or one value per scenario) perturb the rolling stock per scenario.
+        (SI units, scalars or one value per scenario) perturb the rolling stock per scenario.  `guess` (B, nz) or (nz,), in the
+        layout of 'z', warm-starts the solves (barrier parameter `warmMu`, interior push `warmPush`); without it every solve
+        cold-starts like the reference (ocp.py:325-339).
         Returns dict: 'z' (B, nz) in the reference's variable layout, 'status' (B,), 'iterations' (B,), 'cost' (B,)
         [kWh or s], 'stats' (raw records), 'kernel_ms', optionally 'lam_g'.
         """
@@ -246,7 +248,17 @@ class casadiSolver():
         if scen.shape[0] != B:
             scen = np.broadcast_to(scen, (B, scen.shape[1])).copy()
 
-        out = self.problem.solve_batch(scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2))
+        if guess is not None:
+            guess = np.asarray(guess, dtype=float)
+            nz = (4 + int(self.withPnBrake))*self.numIntervals + 2
+            if guess.shape[-1] != nz or guess.ndim > 2 or (guess.ndim == 2 and guess.shape[0] not in (1, B)):
+                raise ValueError("Warm-start guess must have shape ({}, {}) or ({},)!".format(B, nz, nz))
+            if not np.all(np.isfinite(guess)):
+                raise ValueError("Warm-start guess must be finite!")
+            guess = np.broadcast_to(guess.reshape(-1, nz), (B, nz))
+
+        out = self.problem.solve_batch(scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2),
+                                       guess=guess, warmMu=warmMu, warmPush=warmPush)
 
         st = out['stats']
         ST = _device.ST

@@ -391,7 +391,7 @@ typedef struct {
 
 /* IPOPT default option values (Waechter & Biegler 2006, section 3 + IPOPT 3.14 defaults) */
 static const double K_BOUND_RELAX = 1e-8;
-static const double K_PUSH = 1e-2, K_FRAC = 1e-2;          /* bound_push, bound_frac (kappa_1, kappa_2) */
+static const double K_PUSH = 1e-2;                          /* bound_push = bound_frac (kappa_1, kappa_2) */
 static const double K_MU_INIT = 0.1, K_EPS = 10.0;          /* mu_init, barrier_tol_factor (kappa_eps) */
 static const double K_MU_LIN = 0.2, K_MU_SUP = 1.5;         /* kappa_mu, theta_mu */
 static const double K_TAU_MIN = 0.99;
@@ -1017,15 +1017,16 @@ static void ws_free(Ws *W)
     free(W->it); free(W->trial); free(W->bd); free(W->ev); free(W->kk); free(W->dir); free(W->soc); free(W->sct); free(W->scb); free(W->G);
 }
 
-static double push_in(double x, double lb, double ub, int hasL, int hasU)
+/* kp: bound_push and bound_frac (both 1e-2 for a cold start; warm_start_bound_push/_frac for a warm one) */
+static double push_in(double x, double lb, double ub, int hasL, int hasU, double kp)
 {
     if (hasL && hasU) {
-        double pL = fmin(K_PUSH*fmax(1.0, fabs(lb)), K_FRAC*(ub - lb));
-        double pU = fmin(K_PUSH*fmax(1.0, fabs(ub)), K_FRAC*(ub - lb));
+        double pL = fmin(kp*fmax(1.0, fabs(lb)), kp*(ub - lb));
+        double pU = fmin(kp*fmax(1.0, fabs(ub)), kp*(ub - lb));
         if (x < lb + pL) x = lb + pL;
         if (x > ub - pU) x = ub - pU;
-    } else if (hasL) { double pL = K_PUSH*fmax(1.0, fabs(lb)); if (x < lb + pL) x = lb + pL; }
-    else if (hasU) { double pU = K_PUSH*fmax(1.0, fabs(ub)); if (x > ub - pU) x = ub - pU; }
+    } else if (hasL) { double pL = kp*fmax(1.0, fabs(lb)); if (x < lb + pL) x = lb + pL; }
+    else if (hasU) { double pU = kp*fmax(1.0, fabs(ub)); if (x > ub - pU) x = ub - pU; }
     return x;
 }
 
@@ -1034,6 +1035,21 @@ static int debug_level(void) { const char *s = getenv("ORACLE_DEBUG"); return s 
 int oracle_solve(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                  const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
 {
+    return oracle_solve_warm(ip, dp, ds, grad, curv, bmax, NULL, 0.0, 0.0, z_out, lam_out, stats, hist, hist_cap);
+}
+
+/*
+ * Warm start (not in the reference, which always cold-starts, ocp.py:325-339): the primal guess replaces the
+ * cold-start values, is pushed into the interior with `push` instead of bound_push/bound_frac, the bound and slack
+ * multipliers start on the central path of mu0 (z = mu0/slack) and the barrier parameter starts at mu0.
+ * Scaling factors are still computed at the (warm) starting point like IPOPT does.
+ */
+int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, const double *guess, double mu0, double push,
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+{
+    const int warm = guess != NULL;
+    const double kp = warm ? push : K_PUSH;
     Ws Wst; Ws *W = &Wst; memset(W, 0, sizeof *W);
     prob_init(&W->P, ip, dp, ds, grad, curv, bmax);
     const Prob *P = &W->P; int N = P->N; int dbg = debug_level();
@@ -1047,6 +1063,15 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
         for (int i = 0; i <= N; i++) {
             StageIt *I = &W->it[i];
             I->x[VT] = P->t0 + dt*i; I->x[VB] = vel0; I->x[VF] = 0.5; I->x[VP] = P->withPn ? -0.1 : 0.0; I->x[VS] = 1;
+        }
+        if (warm) {
+            const int nu = 1 + (P->withPn ? 1 : 0), stp = nu + 3;
+            for (int i = 0; i <= N; i++) {
+                StageIt *I = &W->it[i];
+                const double *q = guess + stp*i;
+                if (i < N) { I->x[VF] = q[0]; I->x[VP] = P->withPn ? q[1] : 0.0; I->x[VS] = q[nu]; I->x[VT] = q[nu + 1]; I->x[VB] = q[nu + 2]; }
+                else { I->x[VT] = q[0]; I->x[VB] = q[1]; }
+            }
         }
     }
     /* ---- gradient-based scaling at the user's starting point (nlp_scaling_method = gradient-based, max gradient 100) ---- */
@@ -1086,20 +1111,22 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
         StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
         for (int k = 0; k < NV; k++) {
             if (!B->on[k]) continue;
-            I->x[k] = push_in(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k]);
-            I->zL[k] = B->hasL[k] ? 1 : 0; I->zU[k] = B->hasU[k] ? 1 : 0;
+            I->x[k] = push_in(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], kp);
+            I->zL[k] = B->hasL[k] ? (warm ? mu0/(I->x[k] - B->lb[k]) : 1) : 0;
+            I->zU[k] = B->hasU[k] ? (warm ? mu0/(B->ub[k] - I->x[k]) : 1) : 0;
         }
     }
     for (int i = 0; i < N; i++) {
         eval_interval(W, W->it, i, &W->ev[i], 2);
         for (int r = 0; r < NR; r++) {
             if (!W->rowOn[r]) continue;
-            W->it[i].sig[r] = push_in(W->ev[i].d[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r]);
-            W->it[i].zLs[r] = W->rhasL[r] ? 1 : 0; W->it[i].zUs[r] = W->rhasU[r] ? 1 : 0;
+            W->it[i].sig[r] = push_in(W->ev[i].d[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], kp);
+            W->it[i].zLs[r] = W->rhasL[r] ? (warm ? mu0/(W->it[i].sig[r] - W->dL[r]) : 1) : 0;
+            W->it[i].zUs[r] = W->rhasU[r] ? (warm ? mu0/(W->dU[r] - W->it[i].sig[r]) : 1) : 0;
         }
     }
 
-    double mu = K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
+    double mu = warm ? mu0 : K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
     double (*res_c)[2] = calloc(N + 1, sizeof *res_c);
     double (*res_d)[NR] = calloc(N + 1, sizeof *res_d);
     double (*soc_c)[2] = calloc(N + 1, sizeof *soc_c);
@@ -1136,14 +1163,14 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
             StageBd *B = &W->bd[i];
             for (int k = 0; k < NV; k++) {
                 if (!B->on[k]) continue;
-                double gadd = -(B->hasL[k] ? 1.0 : 0.0) + (B->hasU[k] ? 1.0 : 0.0);
+                double gadd = -(B->hasL[k] ? save[i].zL[k] : 0.0) + (B->hasU[k] ? save[i].zU[k] : 0.0);
                 int a = var2loc[k];
                 if (i < N) W->ev[i].objg[a] += gadd;
                 else W->ev[N - 1].objg[k == VT ? LT1 : LB1] += gadd;
             }
         }
         /* slack gradient -zLs + zUs: enters as gphi in the row condensation; emulate through res_d: coef = Sg*res_d + gphi with Sg = 1 */
-        for (int i = 0; i < N; i++) { res_c[i][0] = res_c[i][1] = 0; for (int r = 0; r < NR; r++) res_d[i][r] = W->rowOn[r] ? (-(W->rhasL[r] ? 1.0 : 0.0) + (W->rhasU[r] ? 1.0 : 0.0)) : 0; }
+        for (int i = 0; i < N; i++) { res_c[i][0] = res_c[i][1] = 0; for (int r = 0; r < NR; r++) res_d[i][r] = W->rowOn[r] ? (-(W->rhasL[r] ? save[i].zLs[r] : 0.0) + (W->rhasU[r] ? save[i].zUs[r] : 0.0)) : 0; }
         int ok = compute_direction(W, 0.0, 0.0, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
         double lmax = 0;
         if (ok) {

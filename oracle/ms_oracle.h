@@ -99,6 +99,11 @@ enum {
 int oracle_solve(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                  const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
 
+/* Same with a primal warm start: guess in the layout of z_out (NULL = cold start), barrier parameter mu0, interior push `push`. */
+int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, const double *guess, double mu0, double push,
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+
 /* Batch of scenarios (t0, T, v0sq, vNsq per scenario, 4 doubles each) with OpenMP over scenarios. */
 int oracle_solve_batch(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                        const double *bmax, int nscen, const double *scen, double *z_out, double *stats, int nthreads);

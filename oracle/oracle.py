@@ -57,6 +57,9 @@ def lib():
         _lib.oracle_solve.restype = ctypes.c_int
         _lib.oracle_solve.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int]
         _lib.oracle_solve_batch.restype = ctypes.c_int
+        _lib.oracle_solve_warm.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_double, ctypes.c_double, dptr, dptr, dptr, dptr,
+                                           ctypes.c_int]
+        _lib.oracle_solve_warm.restype = ctypes.c_int
         _lib.oracle_solve_batch.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
         _lib.oracle_stage_eval.restype = None
         _lib.oracle_stage_eval.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
@@ -218,8 +221,8 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     return Problem(ip, dp, np.diff(pos), grad, curv, bmax, float(vlim[0]), float(vlim[-1]), totalMass, pos)
 
 
-def solve(prob, dp, history=False):
-    "One solve -> dict(z, lam_g, stats[, hist])."
+def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3):
+    "One solve -> dict(z, lam_g, stats[, hist]).  guess (nz,): primal warm start with barrier parameter mu0 and interior push."
 
     L = lib()
     z = np.zeros(prob.nz)
@@ -229,8 +232,13 @@ def solve(prob, dp, history=False):
     hist = np.zeros((max(cap, 1), 8))
     dp = np.ascontiguousarray(dp, dtype=np.float64)
 
-    L.oracle_solve(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), _d(z), _d(lam), _d(st),
-                   _d(hist) if history else None, cap)
+    if guess is not None:
+        guess = np.ascontiguousarray(guess, dtype=np.float64)
+        assert guess.shape == (prob.nz,)
+
+    L.oracle_solve_warm(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax),
+                        _d(guess) if guess is not None else None, float(mu0), float(push), _d(z), _d(lam), _d(st),
+                        _d(hist) if history else None, cap)
 
     out = dict(z=z, lam_g=lam, stats={k: st[v] for k, v in ST.items() if k != 'COUNT'})
 

@@ -41,9 +41,17 @@ extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const doubl
 {
     return emu_solve_batch_ex(d, nscen, scen, nullptr, z, lam, stats, hist, cap);
 }
+extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, const double *guess, double mu0, double push,
+                                   double *z, double *lam, double *stats, double *hist, int cap);
 extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
+    return emu_solve_batch_warm(d, nscen, scen, ovr, nullptr, 0.0, 0.0, z, lam, stats, hist, cap);
+}
+extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, const double *guess, double mu0, double push,
+                                   double *z, double *lam, double *stats, double *hist, int cap)
+{
     msd::DevProb P;
+    P.guess = guess; P.warmMu = mu0; P.warmPush = push;
     P.N = d->num_intervals; P.withPn = d->with_pn_brake; P.hasPower = d->has_power_rows; P.energyOpt = d->energy_optimal;
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;

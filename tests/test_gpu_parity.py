@@ -214,6 +214,55 @@ def test_config4_shrinking_horizon_vs_oracle():
         assert np.allclose(g['cost'], r['cost'], rtol=1e-7)
 
 
+def test_warm_start_vs_oracle():
+    # msd_solve_batch_warm: same iterates as the oracle's warm start (iteration counts equal), same optimum as a cold solve
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00()
+    N = 100
+    solver = _solver(train, track, N)
+    prob = cases.oracle_problem(train, track, N)
+    T = np.array([1500.0, 1560.0, 1620.0, 1700.0])
+    first = solver.solveBatch(T)
+    assert np.all(first['status'] == 0)
+    T2 = T*1.005
+    cold = solver.solveBatch(T2)
+    warm = solver.solveBatch(T2, guess=first['z'], warmMu=1e-2, warmPush=1e-3)
+    assert np.all(warm['status'] == 0) and np.all(cold['status'] == 0)
+    assert np.all(warm['iterations'] < cold['iterations'])
+    assert np.allclose(warm['cost'], cold['cost'], rtol=1e-7)
+    for k in range(len(T)):
+        ref = oracle.solve(prob, prob.scenario(T2[k]), guess=first['z'][k], mu0=1e-2, push=1e-3)
+        assert ref['stats']['STATUS'] == 0 and int(ref['stats']['ITERS']) == warm['iterations'][k]
+        assert np.max(np.abs(warm['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-7
+    # one guess broadcast over the batch; bad guesses are rejected before the launch
+    one = solver.solveBatch(T2, guess=first['z'][1])
+    assert np.all(one['status'] == 0) and np.allclose(one['cost'], cold['cost'], rtol=1e-7)
+    with pytest.raises(ValueError):
+        solver.solveBatch(T2, guess=first['z'][:, :-1])
+    bad = first['z'].copy(); bad[0, 3] = np.nan
+    with pytest.raises(ValueError):
+        solver.solveBatch(T2, guess=bad)
+
+
+def test_config4_warm_started_mpc_matches_cold():
+    # warm-started shrinking horizon: same closed loop as the cold one, fewer iterations
+    from mseetc.mpc import shrinkingHorizon
+    train, track = cases.train_default(), cases.track_00()
+    opts = dict(numIntervals=100, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+    T = 1541*(1 + 0.15*np.random.default_rng(5).random(16))
+    cold = shrinkingHorizon(train, track, opts, T, numResolves=6, noise=0.01, seed=11)
+    warm = shrinkingHorizon(train, track, opts, T, numResolves=6, noise=0.01, seed=11, warmStart=True)
+    assert len(cold) == len(warm) == 6
+    itc = itw = 0
+    for k, (c, w) in enumerate(zip(cold, warm)):
+        assert np.all(c['status'] == 0) and np.all(w['status'] == 0)
+        assert np.allclose(c['t0'], w['t0'], rtol=1e-6) and np.allclose(c['v0'], w['v0'], rtol=1e-6)
+        assert np.allclose(c['cost'], w['cost'], rtol=1e-6)
+        if k > 0:
+            itc += c['iterations'].sum(); itw += w['iterations'].sum()
+    assert itw < 0.7*itc
+
+
 def test_dynamic_loss_model_vs_oracle():
     # simulations/figure5.py configuration with the dynamic losses of efficiency.py (fun2): 8.5 km, v0 = 1, vN = 100 km/h
     from oracle import oracle

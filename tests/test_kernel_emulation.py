@@ -45,3 +45,33 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T):
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
     assert np.max(np.abs(lam[0] - ref['lam_g'])) < 1e-7
+
+
+def test_emulated_warm_start_matches_oracle(emu):
+    "msd_solve_batch_warm semantics: same iterates as the oracle's warm start, same optimum as a cold solve, fewer iterations."
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ProblemDesc, ST
+    from oracle import oracle
+    N, crop, T = 40, 16000, 700.0
+    train, track = cases.train_default(), cases.track_00(crop)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
+    prob = cases.oracle_problem(train, track, N)
+    first = oracle.solve(prob, prob.scenario(T))
+    assert first['stats']['STATUS'] == 0
+    T2 = T*1.01
+    cold = oracle.solve(prob, prob.scenario(T2))
+    warm = oracle.solve(prob, prob.scenario(T2), guess=first['z'], mu0=1e-2, push=1e-3)
+    assert warm['stats']['STATUS'] == 0 and warm['stats']['ITERS'] < cold['stats']['ITERS']
+    assert abs(warm['stats']['OBJ'] - cold['stats']['OBJ']) < 1e-7*abs(cold['stats']['OBJ'])
+    dp = ctypes.POINTER(ctypes.c_double)
+    emu.emu_solve_batch_warm.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, dp, dp, dp, ctypes.c_double, ctypes.c_double, dp, dp, dp, dp,
+                                         ctypes.c_int]
+    scen = solver._scenarios(T2, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(dp)
+    guess = np.ascontiguousarray(first['z'])
+    assert emu.emu_solve_batch_warm(ctypes.byref(solver._desc), 1, d(scen), None, d(guess), 1e-2, 1e-3, d(z), d(lam), d(st), d(hist), 8) == 0
+    assert st[0, ST['STATUS']] == 0
+    assert int(st[0, ST['ITERS']]) == int(warm['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - warm['z'])/np.maximum(1, np.abs(warm['z']))) < 1e-8
