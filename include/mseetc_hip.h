@@ -39,6 +39,16 @@ extern "C" {
 #define MSD_STATUS_NUMERIC (-4)
 #define MSD_STATUS_TINY_STEP (-5)
 
+/*
+ * Starting point of a solve.  REFERENCE: the reference's cold start (ocp.py:325-339: Fel 0.5, Fpb -0.1, s 1, t linear,
+ * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
+ * consistent forces (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the iterations, and a
+ * scenario that breaks down from it (any failure
+ * but the iteration limit) is solved again from the reference's point inside the same launch.
+ */
+#define MSD_START_REFERENCE 0
+#define MSD_START_PROFILE 1
+
 /* stats record: MSD_ST_COUNT doubles per scenario */
 enum {
     MSD_ST_STATUS = 0,
@@ -89,7 +99,8 @@ typedef struct msd_problem_desc {
     int num_approx_steps;    /* OptionsRK.numApproxSteps (train.py:465)                       */
     int loss_kind;           /* 0 none, 1 static efficiencies (train.py:199-212), 2 dynamic table (efficiency.py) */
     int max_iterations;      /* ocp.py:18,290                                                 */
-    int reserved_i[7];
+    int start_kind;          /* MSD_START_REFERENCE (0) or MSD_START_PROFILE                  */
+    int reserved_i[6];
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
     double g, rho;
     double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */

@@ -41,7 +41,7 @@ struct msd_problem {
     msd::KernelFn kernel = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr, *d_loss = nullptr;
+    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr, *d_loss = nullptr, *d_pos = nullptr;
     /* grow-only scratch of the host-buffer entry point */
     double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
     int cap_scen = 0, cap_guess = 0;
@@ -69,6 +69,7 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     if (d->num_steps < 1 || d->num_approx_steps < 0) return fail(MSD_E_INVALID, "bad integrator options");
     if (!d->ds || !d->grad || !d->curv || !d->bmax) return fail(MSD_E_INVALID, "null profile array");
     if (!(d->vmin_sq > 0) || !(d->obj_den > 0) || !(d->tol > 0)) return fail(MSD_E_INVALID, "vmin_sq, obj_den and tol must be positive");
+    if (d->start_kind != MSD_START_REFERENCE && d->start_kind != MSD_START_PROFILE) return fail(MSD_E_INVALID, "unknown starting point");
     if (d->loss_kind < 0 || d->loss_kind > 2) return fail(MSD_E_UNSUPPORTED, "loss model not available on the device");
     if (d->loss_kind == 2) {
         if (!d->loss_table || d->loss_table_len < 13) return fail(MSD_E_INVALID, "dynamic loss model without its table");
@@ -102,7 +103,7 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0;
+    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0; P.pos = nullptr; P.start = d->start_kind;
 
 #define UPLOAD(dst, src, n)                                                                    \
     do {                                                                                       \
@@ -114,8 +115,17 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     } while (0)
     UPLOAD(h->d_ds, d->ds, N); UPLOAD(h->d_grad, d->grad, N); UPLOAD(h->d_curv, d->curv, N); UPLOAD(h->d_bmax, d->bmax, N + 1);
     if (d->loss_kind == 2) UPLOAD(h->d_loss, d->loss_table, d->loss_table_len);
+    {
+        double *pos = new double[N + 1];
+        pos[0] = 0;
+        for (int i = 0; i < N; i++) pos[i + 1] = pos[i] + d->ds[i];
+        hipError_t e1 = hipMalloc((void **)&h->d_pos, sizeof(double)*(N + 1));
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(h->d_pos, pos, sizeof(double)*(N + 1), hipMemcpyHostToDevice) : e1;
+        delete[] pos;
+        if (e2 != hipSuccess) { msd_problem_destroy(h); return fail(MSD_E_HIP, "profile upload failed"); }
+    }
 #undef UPLOAD
-    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax; P.loss = h->d_loss;
+    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax; P.loss = h->d_loss; P.pos = h->d_pos;
 
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         msd_problem_destroy(h);
@@ -136,7 +146,7 @@ int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax); hipFree(h->d_loss);
+    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax); hipFree(h->d_loss); hipFree(h->d_pos);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);

@@ -61,7 +61,9 @@ struct DevProb {
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     const double *ds, *grad, *curv, *bmax;
     const double *loss;      /* parameter block of the dynamic loss model (lossKind == 2), see DynLoss */
-    /* primal warm start (set per launch by msd_solve_batch_warm, null = the reference's cold start) */
+    const double *pos;       /* [N+1] node positions (cumulative ds), used by the profile start */
+    int start;               /* MSD_START_REFERENCE: cold start of ocp.py:325-339; MSD_START_PROFILE: profile start */
+    /* primal warm start (set per launch by msd_solve_batch_warm, null = none) */
     const double *guess;
     double warmMu, warmPush;
 };
@@ -1153,11 +1155,88 @@ struct Solver {
     }
 
     /* ---------------------------------------------------------------------------------------- */
-    __device__ __forceinline__ void run(const double *scen, const double *guess, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+    /*
+     * Profile start (not in the reference, which starts every solve from ocp.py:325-339): a speed profile that respects the
+     * limits, accelerates from v0 and brakes to vN with 0.3 m/s^2 and cruises at the speed that uses up the running time; times
+     * from the trapezoidal rule; forces from the acceleration the profile needs (profile floored at 5 m/s there, so that the
+     * integrator stays away from b = 0), cut to the force and power limits; slacks just above the loss rows.  Same optimum,
+     * about half the iterations.  Node-parallel except for the running sum of the times (thread 0, N additions).
+     */
+    __device__ __forceinline__ void profile_start(double t0, double tEnd, double v0sq, double vNsq)
     {
         const int N = P.N;
-        const bool warm = guess != nullptr;
-        const double kp = warm ? P.warmPush : K_PUSH;
+        constexpr double A = 0.3, MARG = 0.97*0.97, BFL = 25.0, S0 = 0.02, TFR = 0.995;
+        const double L = P.pos[N], span = tEnd - t0;
+        double cs = L/span;
+        double cap[SPT], up[SPT], dn[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int i = n[j].i;
+            const double ps = (i <= N) ? P.pos[i] : L;
+            cap[j] = (i >= 1 && i < N) ? MARG*P.bmax[i] : INFINITY;
+            up[j] = v0sq + 2*A*ps; dn[j] = vNsq + 2*A*(L - ps);
+        }
+#pragma unroll 1
+        for (int it = 0; it < 3; it++) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int i = n[j].i;
+                double bi = fmin(fmin(cap[j], cs*cs), fmin(up[j], dn[j]));
+                if (i == 0) bi = v0sq;
+                if (i == N) bi = vNsq;
+                n[j].x[VB] = bi;
+                if (i <= N) { c.xb[i] = sqrt(bi); c.o2[i] = bi; }
+            }
+            __syncthreads();
+            double tt = 0;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (!n[j].ival()) continue;
+                const int i = n[j].i;
+                const double dti = 2*n[j].ds/(c.xb[i] + c.xb[i + 1]);
+                c.o1[i] = dti; tt += dti;
+            }
+            double v[1] = {tt};
+            block_reduce<1>(v, OpSum(), c);
+            if (it < 2) cs *= uni(v[0])/(span*TFR);
+            __syncthreads();
+        }
+        if (c.tid == 0) {
+            double acc = t0;
+            for (int i = 0; i <= N; i++) { c.xt[i] = fmin(acc, tEnd); if (i < N) acc += c.o1[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            Node &nd = n[j];
+            const int i = nd.i;
+            if (!nd.node()) continue;
+            nd.x[VT] = c.xt[i];
+            if (!nd.ival()) continue;
+            const double b0 = c.o2[i], b1 = c.o2[i + 1], v0 = c.xb[i], v1 = c.xb[i + 1];
+            const double bs0 = fmax(b0, BFL), bs1 = fmax(b1, BFL);
+            const double vm = 0.5*(sqrt(bs0) + sqrt(bs1));
+            const double f = (bs1 - bs0)/(2*nd.ds) + P.sr0 + P.sr1*vm + P.sr2*vm*vm + nd.G;
+            double fel = fmin(fmax(f, P.fmin), P.fmax);
+            if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
+            const double fpb = P.withPn ? fmin(fmax(f - fel, P.fminPn), 0.0) : 0.0;
+            double sl;
+            if (DYN) { const DynLoss D(P.loss); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
+            else sl = fmax(P.ct*fel, -P.cr*fel) + S0;
+            nd.x[VF] = fel; nd.x[VP] = fpb; nd.x[VS] = sl;
+        }
+        __syncthreads();
+    }
+
+    /* one solve; startKind: MSD_START_* (ignored with an external guess); returns the status, iters_out = iterations spent */
+    __device__ __forceinline__ int run(const double *scen, const double *guess, int startKind, int iter_offset, int &iters_out,
+                                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+    {
+        const int N = P.N;
+        const bool ext = guess != nullptr;
+        const bool warm = ext || startKind == MSD_START_PROFILE;
+        const double kp = ext ? P.warmPush : K_PUSH;
+        const double mu_start = ext ? P.warmMu : K_MU_INIT;
         const unsigned long long cyc0 = __builtin_readcyclecounter();
         if (c.tid == 0) { c.misc[1] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
         c.tmark = cyc0;
@@ -1185,7 +1264,7 @@ struct Solver {
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
             nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = P.withPn ? -0.1 : 0.0; nd.x[VS] = 1;
-            if (warm && node) {
+            if (ext && node) {
                 /* layout of z_out (ocp.py:166-272): [Fel,(Fpb),s,t,b] per interval, then t_N, b_N */
                 const int nu = 1 + P.withPn;
                 const double *q = guess + (nu + 3)*nd.i;
@@ -1201,6 +1280,7 @@ struct Solver {
             nd.lam[0] = nd.lam[1] = 0;
             nd.sct = nd.scb = 1;
         }
+        if (!ext && startKind == MSD_START_PROFILE) profile_start(t0, tEnd, v0sq, vNsq);
         U.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); U.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
         U.blo = P.vminSq - K_BOUND_RELAX*fmax(1.0, fabs(P.vminSq));
         U.flo = P.fmin - K_BOUND_RELAX*fmax(1.0, fabs(P.fmin)); U.fhi = P.fmax + K_BOUND_RELAX*fmax(1.0, fabs(P.fmax));
@@ -1268,8 +1348,8 @@ struct Solver {
             for (int k = 0; k < NV; k++) {
                 if (!n[j].on(k)) continue;
                 n[j].x[k] = push_in(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k), kp);
-                n[j].zL[k] = warm ? P.warmMu/(n[j].x[k] - lbv(k)) : 1.0;
-                n[j].zU[k] = hasU(k) ? (warm ? P.warmMu/(ubv(j, k) - n[j].x[k]) : 1.0) : 0.0;
+                n[j].zL[k] = warm ? mu_start/(n[j].x[k] - lbv(k)) : 1.0;
+                n[j].zU[k] = hasU(k) ? (warm ? mu_start/(ubv(j, k) - n[j].x[k]) : 1.0) : 0.0;
             }
         }
         evaluate_current(e);     /* resd = d(x) since the slacks are still zero */
@@ -1281,13 +1361,13 @@ struct Solver {
             for (int r = 0; r < NR; r++) {
                 if (!U.rowOn[r]) continue;
                 n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], kp);
-                n[j].zLs[r] = U.rL[r] ? (warm ? P.warmMu/(n[j].sg[r] - U.dL[r]) : 1.0) : 0.0;
-                n[j].zUs[r] = U.rU[r] ? (warm ? P.warmMu/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
+                n[j].zLs[r] = U.rL[r] ? (warm ? mu_start/(n[j].sg[r] - U.dL[r]) : 1.0) : 0.0;
+                n[j].zUs[r] = U.rU[r] ? (warm ? mu_start/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
                 resd[j][r] -= n[j].sg[r];
             }
         }
 
-        double mu = warm ? P.warmMu : K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
+        double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
         {
@@ -1551,7 +1631,7 @@ struct Solver {
             } else if (nd.i == N) { z_out[stp*N] = nd.x[VT]; z_out[stp*N + 1] = nd.x[VB]; }
         }
         if (c.tid == 0) {
-            stats[MSD_ST_STATUS] = status; stats[MSD_ST_ITERS] = iter; stats[MSD_ST_OBJ] = objv;
+            stats[MSD_ST_STATUS] = status; stats[MSD_ST_ITERS] = iter + iter_offset; stats[MSD_ST_OBJ] = objv;
             stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/U.sf;
             stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/U.sf;
             stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back;
@@ -1560,6 +1640,8 @@ struct Solver {
             if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
         }
         __syncthreads();
+        iters_out = iter;
+        return status;
     }
 };
 
@@ -1591,9 +1673,19 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
         }
         Solver<SPT, DYN> s(Ps, c);
-        s.run(scen + (size_t)MSD_SC_COUNT*sidx, P.guess ? P.guess + (size_t)nz*sidx : nullptr, z_out + (size_t)nz*sidx, lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr,
-              stats + (size_t)MSD_ST_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
-        __syncthreads();
+        const double *guess = P.guess ? P.guess + (size_t)nz*sidx : nullptr;
+        int startKind = guess ? MSD_START_REFERENCE : P.start, spent = 0;
+        /* a profile start that breaks down (not: runs out of iterations) is repeated from the reference's starting point */
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; attempt++) {
+            int iters = 0;
+            const int st = s.run(scen + (size_t)MSD_SC_COUNT*sidx, guess, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                 lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, stats + (size_t)MSD_ST_COUNT*sidx,
+                                 (hist && sidx == 0) ? hist : nullptr, hist_cap);
+            __syncthreads();
+            if (st >= 0 || st == MSD_STATUS_MAXITER || startKind != MSD_START_PROFILE) break;
+            spent = iters; startKind = MSD_START_REFERENCE;
+        }
     }
 }
 

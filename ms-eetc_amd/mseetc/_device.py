@@ -33,7 +33,7 @@ class ProblemDesc(ctypes.Structure):
     _fields_ = [('abi_version', ctypes.c_int), ('num_intervals', ctypes.c_int), ('with_pn_brake', ctypes.c_int),
                 ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
                 ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
-                ('reserved_i', ctypes.c_int*7),
+                ('start_kind', ctypes.c_int), ('reserved_i', ctypes.c_int*6),
                 ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
                 ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
@@ -108,14 +108,18 @@ def _d(a):
     return a.ctypes.data_as(_dptr)
 
 
+START = dict(reference=0, profile=1)   # MSD_START_*
+
+
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
-              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None):
+              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference'):
     "Fill a ProblemDesc; the numpy arrays are kept alive on the returned object."
 
     d = ProblemDesc()
     d.abi_version = ABI_VERSION
     d.num_intervals, d.with_pn_brake, d.has_power_rows, d.energy_optimal = int(N), int(withPn), int(hasPower), int(energyOptimal)
     d.num_steps, d.num_approx_steps, d.loss_kind, d.max_iterations = int(numSteps), int(numApproxSteps), int(lossKind), int(maxIterations)
+    d.start_kind = START[start]
     d.sr0, d.sr1, d.sr2 = sr
     d.g, d.rho = g, rho
     d.f_max, d.f_min, d.f_min_pn = fmax, fmin, fminPn

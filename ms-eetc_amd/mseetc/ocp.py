@@ -78,7 +78,18 @@ class casadiSolver():
 
     TOLERANCE = 1e-8   # IPOPT default `tol`; the reference passes only max_iter (ocp.py:290)
 
-    def __init__(self, train, track, optsDict={}, device=0):
+    def __init__(self, train, track, optsDict={}, device=0, startingPoint='profile'):
+        """
+        Same arguments as the reference (ocp.py:79) plus two that have no counterpart there: `device` (GPU index) and
+        `startingPoint`: 'reference' starts every solve from the reference's point (ocp.py:325-339), 'profile' (default)
+        from a speed profile built on the device from the limits, the running time and the end speeds -- same optimum,
+        about half the interior-point iterations; a scenario that breaks down from it is repeated from the reference's point.
+        """
+
+        if startingPoint not in _device.START:
+            raise ValueError("Unknown starting point '{}'!".format(startingPoint))
+
+        self.startingPoint = startingPoint
 
         track.checkFields()
         train.checkFields()
@@ -144,7 +155,7 @@ class casadiSolver():
             (model.sr0, model.sr1, model.sr2), train.g, rho, forceMax, forceMin if withRgBrake else 0.0, forceMinPn,
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
             self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
-            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None)
+            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU

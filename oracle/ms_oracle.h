@@ -104,6 +104,12 @@ int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const d
                       const double *bmax, const double *guess, double mu0, double push,
                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
 
+/* start = 0: the reference's cold start (ocp.py:325-339); start = 1: profile start (see ms_oracle.c), repeated cold when it breaks down (any failure but the iteration limit) */
+int oracle_solve_start(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                       const double *bmax, int start, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+int oracle_solve_batch_start(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                             const double *bmax, int start, int nscen, const double *scen, double *z_out, double *stats, int nthreads);
+
 /* Batch of scenarios (t0, T, v0sq, vNsq per scenario, 4 doubles each) with OpenMP over scenarios. */
 int oracle_solve_batch(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                        const double *bmax, int nscen, const double *scen, double *z_out, double *stats, int nthreads);

@@ -60,6 +60,10 @@ def lib():
         _lib.oracle_solve_warm.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_double, ctypes.c_double, dptr, dptr, dptr, dptr,
                                            ctypes.c_int]
         _lib.oracle_solve_warm.restype = ctypes.c_int
+        _lib.oracle_solve_start.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, dptr, ctypes.c_int]
+        _lib.oracle_solve_start.restype = ctypes.c_int
+        _lib.oracle_solve_batch_start.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
+        _lib.oracle_solve_batch_start.restype = ctypes.c_int
         _lib.oracle_solve_batch.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
         _lib.oracle_stage_eval.restype = None
         _lib.oracle_stage_eval.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
@@ -221,8 +225,14 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     return Problem(ip, dp, np.diff(pos), grad, curv, bmax, float(vlim[0]), float(vlim[-1]), totalMass, pos)
 
 
-def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3):
-    "One solve -> dict(z, lam_g, stats[, hist]).  guess (nz,): primal warm start with barrier parameter mu0 and interior push."
+START = dict(reference=0, profile=1)
+
+
+def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3, start='reference'):
+    """
+    One solve -> dict(z, lam_g, stats[, hist]).  guess (nz,): primal warm start with barrier parameter mu0 and interior
+    push; otherwise start = 'reference' (cold start of ocp.py:325-339) or 'profile' (see ms_oracle.c).
+    """
 
     L = lib()
     z = np.zeros(prob.nz)
@@ -236,9 +246,12 @@ def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3):
         guess = np.ascontiguousarray(guess, dtype=np.float64)
         assert guess.shape == (prob.nz,)
 
-    L.oracle_solve_warm(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax),
-                        _d(guess) if guess is not None else None, float(mu0), float(push), _d(z), _d(lam), _d(st),
-                        _d(hist) if history else None, cap)
+    if guess is None:
+        L.oracle_solve_start(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), START[start], _d(z), _d(lam),
+                             _d(st), _d(hist) if history else None, cap)
+    else:
+        L.oracle_solve_warm(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), _d(guess), float(mu0),
+                            float(push), _d(z), _d(lam), _d(st), _d(hist) if history else None, cap)
 
     out = dict(z=z, lam_g=lam, stats={k: st[v] for k, v in ST.items() if k != 'COUNT'})
 
@@ -248,7 +261,7 @@ def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3):
     return out
 
 
-def solve_batch(prob, scen, nthreads=0):
+def solve_batch(prob, scen, nthreads=0, start='reference'):
     "scen: (B,4) array of (t0, T, v0sq, vNsq).  Returns (z (B,nz), stats (B,ST_COUNT), nfail)."
 
     L = lib()
@@ -257,8 +270,8 @@ def solve_batch(prob, scen, nthreads=0):
     z = np.zeros((B, prob.nz))
     st = np.zeros((B, ST['COUNT']))
 
-    nfail = L.oracle_solve_batch(_i(prob.ip), _d(prob.dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), B, _d(scen),
-                                 _d(z), _d(st), int(nthreads))
+    nfail = L.oracle_solve_batch_start(_i(prob.ip), _d(prob.dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), START[start], B,
+                                       _d(scen), _d(z), _d(st), int(nthreads))
 
     return z, st, nfail
 

@@ -51,7 +51,10 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
                                    double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
-    P.guess = guess; P.warmMu = mu0; P.warmPush = push;
+    P.guess = guess; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind;
+    std::vector<double> pos(d->num_intervals + 1, 0.0);
+    for (int i = 0; i < d->num_intervals; i++) pos[i + 1] = pos[i] + d->ds[i];
+    P.pos = pos.data();
     P.N = d->num_intervals; P.withPn = d->with_pn_brake; P.hasPower = d->has_power_rows; P.energyOpt = d->energy_optimal;
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;

@@ -19,11 +19,12 @@ OBJ_RTOL = 1e-8
 Z_RTOL = 1e-6
 
 
-def _solver(train, track, N, energyOptimal=True, numSteps=1, numApproxSteps=1):
+def _solver(train, track, N, energyOptimal=True, numSteps=1, numApproxSteps=1, start='reference', maxIterations=500):
+    # the oracle comparisons pin the whole iteration, so both sides start from the same point; 'reference' unless a test says otherwise
     from mseetc.ocp import casadiSolver
-    opts = dict(numIntervals=N, maxIterations=500, energyOptimal=energyOptimal,
+    opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal,
                 integrationOptions=dict(numSteps=numSteps, numApproxSteps=numApproxSteps))
-    return casadiSolver(train, track, opts)
+    return casadiSolver(train, track, opts, startingPoint=start)
 
 
 def _compare(solver, prob, T, **kw):
@@ -35,7 +36,7 @@ def _compare(solver, prob, T, **kw):
         dp = prob.dp.copy()
         from oracle.oracle import DP
         dp[DP['T0']], dp[DP['TEND']], dp[DP['V0SQ']], dp[DP['VNSQ']] = sc
-        ref = oracle.solve(prob, dp)
+        ref = oracle.solve(prob, dp, start=solver.startingPoint)
         assert ref['stats']['STATUS'] == 0
         obj = res['stats'][k, 2]
         assert abs(obj - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
@@ -204,7 +205,9 @@ def test_config4_shrinking_horizon_vs_oracle():
     train, track = cases.train_default(), cases.track_00(crop=20000)
     opts = dict(numIntervals=40, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1))
     T = np.linspace(800.0, 950.0, 6)
-    gpu = shrinkingHorizon(train, track, opts, T, numResolves=4, noise=0.01, seed=3)
+    from mseetc.ocp import casadiSolver
+    gpu = shrinkingHorizon(train, track, opts, T, numResolves=4, noise=0.01, seed=3,
+                           solverFactory=lambda a, b, c: casadiSolver(a, b, c, startingPoint='reference'))
     ref = shrinkingHorizon(train, track, opts, T, numResolves=4, noise=0.01, seed=3, solverFactory=lambda a, b, c: OracleSolver(a, b, c))
     assert len(gpu) == len(ref) == 4
     for g, r in zip(gpu, ref):
@@ -212,6 +215,56 @@ def test_config4_shrinking_horizon_vs_oracle():
         assert np.array_equal(g['status'], r['status']) and np.all(g['status'] == 0)
         assert np.allclose(g['t0'], r['t0'], rtol=1e-7) and np.allclose(g['v0'], r['v0'], rtol=1e-7)
         assert np.allclose(g['cost'], r['cost'], rtol=1e-7)
+
+
+@pytest.mark.parametrize('case', ['config1', 'config2', 'fig10', 'fig5', 'mintime'])
+def test_profile_start_same_optimum_fewer_iterations(case):
+    # the default starting point (MSD_START_PROFILE): iterate-for-iterate equal to the oracle's profile start, the optimum of
+    # the reference's cold start, and markedly fewer iterations
+    if case == 'config1':
+        train, track, N, kw, T = cases.train_default(), cases.track_00(), 100, {}, cases.c1_times(12)
+    elif case == 'config2':
+        train, track, N, kw, T = cases.train_default(), cases.track_CH(), 200, {}, cases.c2_times(6)
+    elif case == 'fig10':
+        train, track, N, kw, T = cases.train_fig10(), cases.track_00(), 300, {}, np.array([1541.0])
+    elif case == 'fig5':
+        train = cases.train_fig5(); train.etaTraction = train.etaRgBrake = 0.73
+        track, N, kw, T = cases.track_00(8500), 100, dict(terminalVelocity=100/3.6, initialVelocity=1), 272.4726*np.array([1.05, 1.2, 1.3])
+    else:
+        train = cases.train_fig5()
+        track, N, kw, T = cases.track_00(8500), 300, dict(terminalVelocity=100/3.6, initialVelocity=1), np.array([400.0])
+    eo = case != 'mintime'
+    prob = cases.oracle_problem(train, track, N, energyOptimal=eo, losses='static' if eo else 'none')
+    fast = _solver(train, track, N, energyOptimal=eo, start='profile')
+    res = _compare(fast, prob, T, **kw)
+    cold = _solver(train, track, N, energyOptimal=eo, start='reference').solveBatch(T, **kw)
+    assert np.all(cold['status'] == 0)
+    assert np.allclose(res['cost'], cold['cost'], rtol=1e-8)
+    assert np.max(np.abs(res['z'] - cold['z'])/np.maximum(1.0, np.abs(cold['z']))) <= 1e-5
+    assert res['iterations'].mean() < 0.7*cold['iterations'].mean()
+
+
+def test_profile_start_falls_back_to_the_reference_point():
+    # a scenario that breaks down from the profile start (here: infeasible running times, the line search gives up) is repeated
+    # from the reference's point inside the launch; the iterations of both attempts are reported, exactly like the oracle does
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00()
+    fast = _solver(train, track, 100, start='profile')
+    cold = _solver(train, track, 100, start='reference')
+    T = [1541.0, 900.0, 1000.0]
+    res, ref = fast.solveBatch(T), cold.solveBatch(T)
+    assert list(res['status'] >= 0) == [True, False, False]
+    prob = cases.oracle_problem(train, track, 100)
+    for k in (1, 2):
+        chk = oracle.solve(prob, prob.scenario(T[k]), start='profile')
+        assert res['status'][k] == int(chk['stats']['STATUS']) == ref['status'][k]
+        assert res['iterations'][k] == int(chk['stats']['ITERS']) > ref['iterations'][k]
+    # the iteration limit is not a breakdown: no second attempt, and a cap between the two starting points' needs separates them
+    few = _solver(train, track, 100, start='profile', maxIterations=12).solveBatch([1541.0])
+    assert few['status'][0] == -1 and few['iterations'][0] == 12
+    mid = _solver(train, track, 100, start='profile', maxIterations=30).solveBatch([1541.0])
+    late = _solver(train, track, 100, start='reference', maxIterations=30).solveBatch([1541.0])
+    assert mid['status'][0] == 0 and late['status'][0] == -1
 
 
 def test_warm_start_vs_oracle():
@@ -260,7 +313,7 @@ def test_config4_warm_started_mpc_matches_cold():
         assert np.allclose(c['cost'], w['cost'], rtol=1e-6)
         if k > 0:
             itc += c['iterations'].sum(); itw += w['iterations'].sum()
-    assert itw < 0.7*itc
+    assert itw < 0.85*itc      # the cold re-solves already use the profile start (about 21 iterations); warm ones need about 15
 
 
 def test_dynamic_loss_model_vs_oracle():

@@ -27,20 +27,20 @@ def emu():
     return lib
 
 
-@pytest.mark.parametrize('N,crop,T', [(30, 12000, 520.0), (70, 30000, 1100.0)])
-def test_emulated_kernel_matches_oracle(emu, N, crop, T):
+@pytest.mark.parametrize('N,crop,T,start', [(30, 12000, 520.0, 'reference'), (70, 30000, 1100.0, 'reference'), (70, 30000, 1100.0, 'profile')])
+def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
     from oracle import oracle
     train, track = cases.train_default(), cases.track_00(crop)
-    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint=start)
     scen = solver._scenarios(T, 0, 1, 1)
     nz = (4 + int(solver.withPnBrake))*N + 2
     z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
     d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
     prob = cases.oracle_problem(train, track, N)
-    ref = oracle.solve(prob, prob.scenario(T))
+    ref = oracle.solve(prob, prob.scenario(T), start=start)
     assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
@@ -54,7 +54,7 @@ def test_emulated_warm_start_matches_oracle(emu):
     from oracle import oracle
     N, crop, T = 40, 16000, 700.0
     train, track = cases.train_default(), cases.track_00(crop)
-    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='reference')
     prob = cases.oracle_problem(train, track, N)
     first = oracle.solve(prob, prob.scenario(T))
     assert first['stats']['STATUS'] == 0
