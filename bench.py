@@ -173,7 +173,11 @@ def main():
             from oracle import oracle
             oprob = cases.oracle_problem(train, track, N)
             ncores = os.cpu_count() or 1
-            reps = max(1, int(np.ceil(16*ncores/B)))          # ~10-30 s of CPU work: at least 16 solves per core
+            # bounded sample of the same workload, sized from a first pass to about 12 s of wall time on all host cores
+            t1 = time.perf_counter()
+            oracle.solve_batch(oprob, scen, nthreads=ncores, start=args.start)
+            first = time.perf_counter() - t1
+            reps = int(min(64, max(1, np.ceil(12.0/max(first, 1e-3)))))
             sc = np.tile(scen, (reps, 1))
             sample = sc.shape[0]
             t1 = time.perf_counter()
