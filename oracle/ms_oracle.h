@@ -11,7 +11,8 @@
  *   - the interval integrator of mseetc/train.py:225-277,294-301,324-344 (RK4 via
  *     casadi.simpleRK semantics + trapezoidal time update), with first and second
  *     derivatives (CasADi AD in the reference),
- *   - the static loss rows of mseetc/train.py:199-216 + mseetc/utils.py:197-220,
+ *   - the static loss rows of mseetc/train.py:199-216 + mseetc/utils.py:197-220 and the dynamic
+ *     loss model of mseetc/efficiency.py:7-141 (table handed over as bicubic patches),
  *   - the NLP solver: the reference calls casadi.nlpsol('ipopt') (ocp.py:290,359), i.e.
  *     the third-party IPOPT bundled with casadi==3.6.3 (setup.py:12; IPOPT 3.14.x with
  *     MUMPS), which is NOT present under /root/reference and not installable here.  Its
@@ -22,10 +23,18 @@
  *     recursion over the stages, whose pivots carry the same inertia information.
  *
  * PARITY STATUS: the NLP/integrator/grid restatement is pinned by the reference's own
- * stored numbers (tests/test_oracle_pins.py: GPOPS energies, figure4/figure5 constants).
+ * stored numbers (tests/test_oracle_pins.py: GPOPS energies 440.14 kWh in the limit N -> inf,
+ * figure5.py:96 minimumTime = 272.4726 s reproduced as 272.47254 s, figure4.py:22-23 speeds,
+ * figure3.py:113-115 loss ratio) and by the reference's unit tests restated in
+ * tests/test_reference_unit_tests.py.
  * At the IPOPT boundary parity is UNPINNED: the repository stores no casadiSolver output and
  * casadi cannot run here.  Substitute evidence: an independent numpy KKT +
- * second-order certificate of every oracle solution (tests/kkt_certificate.py).
+ * second-order certificate of every oracle solution (tests/nlp_numpy.py: kkt_certificate).
+ *
+ * Two things here have no counterpart in the reference and exist so that the product's versions
+ * of them can be checked iterate for iterate: the profile starting point (oracle_solve_start,
+ * start = 1) and the primal warm start (oracle_solve_warm).  Both end at the optimum of the
+ * reference's cold start (start = 0, ocp.py:325-339), which is what the pins above refer to.
  */
 #ifndef MS_ORACLE_H
 #define MS_ORACLE_H
