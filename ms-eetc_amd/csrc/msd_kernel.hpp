@@ -399,6 +399,14 @@ __device__ __forceinline__ void node_fence() { __builtin_amdgcn_sched_barrier(0)
 
 /* value the optimiser must treat as redefined here (no instruction is emitted) */
 __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); }
+/* same, but pins the value in an accumulation register at the fence: state that the next phase does not touch stays out of the
+ * 256 architectural VGPRs (MSD_FENCE_AGPR: 0 none, 1 bound/slack multipliers, 2 all duals, steps and residuals) */
+#ifndef MSD_FENCE_AGPR
+#define MSD_FENCE_AGPR 0
+#endif
+__device__ __forceinline__ void opaque_a(double &v) { asm volatile("" : "+a"(v)); }
+__device__ __forceinline__ void opaque_z(double &v) { if (MSD_FENCE_AGPR >= 1) opaque_a(v); else opaque(v); }
+__device__ __forceinline__ void opaque_d(double &v) { if (MSD_FENCE_AGPR >= 2) opaque_a(v); else opaque(v); }
 
 /* a workgroup-uniform double into scalar registers */
 __device__ __forceinline__ double uni(double v)
@@ -672,10 +680,10 @@ struct Solver {
         for (int j = 0; j < SPT; j++) {
             Node &nd = n[j];
 #pragma unroll
-            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); if (MSD_FENCE_DUALS) { opaque(nd.zL[k]); opaque(nd.zU[k]); } }
+            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); if (MSD_FENCE_DUALS) { opaque_z(nd.zL[k]); opaque_z(nd.zU[k]); } }
 #pragma unroll
-            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); if (MSD_FENCE_DUALS) { opaque(nd.nu[r]); opaque(nd.zLs[r]); opaque(nd.zUs[r]); opaque(nd.dsg[r]); opaque(resd[j][r]); } }
-            if (MSD_FENCE_DUALS) { opaque(nd.lam[0]); opaque(nd.lam[1]); opaque(resc[j][0]); opaque(resc[j][1]); }
+            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); if (MSD_FENCE_DUALS) { opaque_d(nd.nu[r]); opaque_z(nd.zLs[r]); opaque_z(nd.zUs[r]); opaque_d(nd.dsg[r]); opaque_d(resd[j][r]); } }
+            if (MSD_FENCE_DUALS) { opaque_d(nd.lam[0]); opaque_d(nd.lam[1]); opaque_d(resc[j][0]); opaque_d(resc[j][1]); }
         }
 #endif
     }
