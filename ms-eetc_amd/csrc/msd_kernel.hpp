@@ -93,14 +93,20 @@ constexpr int FILT_CAP = 64;
 constexpr int RED_K = 8, RED_SLOTS = 4, MAX_WAVES = 16;
 constexpr int HIST_COLS = 8;
 
-/* stage block slots */
+/* stage block slots.  Written by the owning thread in assemble(): the dynamics (0..5, never overwritten), the condensed
+ * Hessian/gradient of (t, b, q | f, p) with the slack variable s already eliminated (6..22), and what the elimination needs
+ * afterwards (23..).  The serial sweeps overwrite 6..22 with the feedback, the value function and the step. */
 constexpr int S_TB = 0, S_TW = 1, S_BB = 2, S_BW = 3, S_RT = 4, S_RB = 5;
-constexpr int S_HTT = 6, S_HBB = 7, S_HBQ = 8, S_HBF = 9, S_HBP = 10, S_HQQ = 11, S_HQF = 12, S_HFF = 13, S_HFP = 14, S_HFS = 15,
-              S_HPP = 16, S_HSS = 17, S_HT = 18, S_HB = 19, S_HQ = 20, S_HF = 21, S_HP = 22, S_HS = 23;
-constexpr int S_K = 6 /* 9 */, S_KV = 15 /* 3 */, S_PN = 18 /* 6 */, S_PV = 24 /* 3 */;
+constexpr int S_HTT = 6, S_HBB = 7, S_HBQ = 8, S_HBF = 9, S_HBP = 10, S_HQQ = 11, S_HQF = 12, S_HFF = 13, S_HFP = 14, S_HPP = 15,
+              S_HT = 18, S_HB = 19, S_HQ = 20, S_HF = 21, S_HP = 22;
+/* s-elimination data: ds = -(GS + GBS db + GFS df + GPS dp) IS; the last interval keeps its (unreduced) s row here and the
+ * backward sweep leaves the feedback of s in 23..26 */
+constexpr int S_GFS = 23, S_IS = 24, S_GS = 25, S_GBS = 26 /* dynamic only */, S_GPS = 27 /* dynamic only */;
+constexpr int S_KS = 23 /* 4, last interval only */;
+constexpr int S_K = 6 /* 6: f and p rows */, S_KV = 12 /* 2 */, S_PN = 14 /* 6 */, S_PV = 20 /* 3 */;
 constexpr int S_DT = 6, S_DB = 7, S_DF = 8, S_DP = 9, S_DS = 10, S_LT = 11, S_LB = 12;
-/* dynamic loss model only: (b,s) entry and the couplings of (b_i, s_i) with b_{i+1}; never overwritten by the sweeps */
-constexpr int S_HBS = 27, S_EB = 28, S_ES = 29;
+/* dynamic loss model only: couplings of (b_i, s_i) with b_{i+1}; never overwritten by the sweeps */
+constexpr int S_EB = 28, S_ES = 29;
 
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NT, bool dyn)
 {
@@ -501,12 +507,9 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
-                     Hff = s[S_HFF], Hfp = s[S_HFP], Hfs = s[S_HFS], Hpp = s[S_HPP], Hss = s[S_HSS];
-        const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP], hs = s[S_HS];
-        /* dynamic loss rows: (b,s) entry and couplings e_b db_i db_{i+1} + e_s ds_i db_{i+1}; b_N is a parameter, so none in the last interval */
-        const double Hbs = DYN ? s[S_HBS] : 0.0;
-        const double ceb = (DYN && i < N - 1) ? s[S_EB] : 0.0, ces = (DYN && i < N - 1) ? s[S_ES] : 0.0;
-        /* stash the value function of stage i+1 for the forward sweep */
+                     Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
+        const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+        /* stash the value function of stage i+1 for the multipliers */
         s[S_PN + 0] = Ptt; s[S_PN + 1] = Ptb; s[S_PN + 2] = Ptq; s[S_PN + 3] = Pbb; s[S_PN + 4] = Pbq; s[S_PN + 5] = Pqq;
         s[S_PV + 0] = pt; s[S_PV + 1] = pb; s[S_PV + 2] = pq;
 
@@ -520,37 +523,31 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         double Gtt = Htt + Ptt, Gtb = Mbt, Gtf = Mft, Gtp = Mpt;
         double Gbb = Hbb + Tb*Mbt + Bb*Mbb, Gbq = Hbq, Gbf = Hbf + Tb*Mft + Bb*Mfb, Gbp = Hbp + Tb*Mpt + Bb*Mpb;
         double Gqq = Hqq, Gqf = Hqf;
-        double Gff = Hff + Tw*Mft + Bw*Mfb + Mfq, Gfp = Hfp + Tw*Mpt + Bw*Mpb + Mpq, Gfs = Hfs;
-        double Gpp = Hpp + Tw*Mpt + Bw*Mpb, Gss = Hss;
+        double Gff = Hff + Tw*Mft + Bw*Mfb + Mfq, Gfp = Hfp + Tw*Mpt + Bw*Mpb + Mpq;
+        double Gpp = Hpp + Tw*Mpt + Bw*Mpb;
         double gt = ht + Prt, gb = hb + Tb*Prt + Bb*Prb, gq = hq;
-        double gf = hf + Tw*Prt + Bw*Prb + Prq, gp = hp + Tw*Prt + Bw*Prb, gs = hs;
-        double Gbs = 0, Gps = 0;
-        if (DYN) {
-            /* substitute db+ = Bb db + Bw (df + dp) + rb into the coupling terms */
-            Gbb += 2*ceb*Bb; Gbf += ceb*Bw; Gbp += ceb*Bw; gb += ceb*rb;
-            Gbs = Hbs + ces*Bb; Gfs += ces*Bw; Gps = ces*Bw; gs += ces*rb;
-        }
-        if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; Gps = 0; }
+        double gf = hf + Tw*Prt + Bw*Prb + Prq, gp = hp + Tw*Prt + Bw*Prb;
+        if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; }
 
-        double Kft, Kfb, Kfq, Kpt, Kpb, Kpq, Kst, Ksb, Ksq, kf, kp, ks;
+        double Kft, Kfb, Kfq, Kpt, Kpb, Kpq, kf, kp;
         double nPtt, nPtb, nPtq, nPbb, nPbq, nPqq, npt, npb, npq;
 
         if (i == N - 1) {
-            /* df = eb db - dp + e0 from the b row */
+            /* the last interval still carries its s row: b_N is a parameter, df = eb db - dp + e0 from the b row */
+            const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0;
             const double eb = -Bb/Bw, e0 = -rb/Bw;
             LGtf = Gtf; LGbf = Gbf; LGqf = Gqf; LGff = Gff; LGfp = Gfp; LGfs = Gfs; Lgf = gf;
             const double gfe = gf + Gff*e0;
             /* reduced blocks over (t, b, q | p, s) */
-            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs, Hss2 = Gss;
+            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs;
             double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
             double Hsb = Gfs*eb + Gbs;
             double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
             double Xtt = Gtt, Xtb = Gtb + Gtf*eb, Xbb = Gbb + 2*eb*Gbf + eb*eb*Gff, Xbq = Gbq + eb*Gqf, Xqq = Gqq;
             double xt = gt + Gtf*e0, xb = gb + Gbf*e0 + eb*gfe, xq = gq + Gqf*e0;
             if (!pn) { Hpp2 = 1; Hps2 = 0; Hpt = 0; Hpb = 0; Hpq = 0; gp2 = 0; }
-            /* 2x2 pivots: s first, then p */
-            if (!(Hss2 > 0)) return false;
-            const double is = 1.0/Hss2, lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
+            /* 2x2 pivots: s first (its reciprocal comes from assemble(), NaN when the pivot is not positive), then p */
+            const double lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
             if (!(dp_ > 0)) return false;
             const double ip = 1.0/dp_;
             /* columns t, b, q and the vector: rhs = -(row p, row s) */
@@ -568,46 +565,19 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
             npt = xt + Hpt*kp2; npb = xb + Hpb*kp2 + Hsb*ks2; npq = xq + Hpq*kp2;
             /* uniform feedback form: df = eb db - dp + e0 */
             Kpt = Kp2t; Kpb = Kp2b; Kpq = Kp2q; kp = kp2;
-            Kst = Ks2t; Ksb = Ks2b; Ksq = Ks2q; ks = ks2;
             Kft = -Kp2t; Kfb = eb - Kp2b; Kfq = -Kp2q; kf = e0 - kp2;
-        } else if (DYN) {
-            /* full 3x3 LDL^T of Guu in the order s, p, f */
-            if (!(Gss > 0)) return false;
-            const double is = 1.0/Gss, lps = Gps*is, lfs = Gfs*is;
-            const double Gpp1 = Gpp - Gps*lps, Gfp1 = Gfp - Gfs*lps, Gff1 = Gff - Gfs*lfs;
-            if (!(Gpp1 > 0)) return false;
-            const double ip = 1.0/Gpp1, lfp = Gfp1*ip;
-            const double df_ = Gff1 - Gfp1*lfp;
-            if (!(df_ > 0)) return false;
-            const double iff = 1.0/df_;
-            auto solve = [&](double Rf, double Rp, double Rs, double &xf, double &xp, double &xs) {
-                const double yp = Rp - lps*Rs, yf = Rf - lfs*Rs - lfp*yp;
-                xf = yf*iff; xp = yp*ip - lfp*xf; xs = Rs*is - lps*xp - lfs*xf;
-            };
-            solve(-Gtf, -Gtp, 0.0, Kft, Kpt, Kst);
-            solve(-Gbf, -Gbp, -Gbs, Kfb, Kpb, Ksb);
-            solve(-Gqf, 0.0, 0.0, Kfq, Kpq, Ksq);
-            solve(-gf, -gp, -gs, kf, kp, ks);
-            nPtt = Gtt + Gtf*Kft + Gtp*Kpt;
-            nPtb = Gtb + Gtf*Kfb + Gtp*Kpb;
-            nPtq = Gtf*Kfq + Gtp*Kpq;
-            nPbb = Gbb + Gbf*Kfb + Gbp*Kpb + Gbs*Ksb;
-            nPbq = Gbq + Gbf*Kfq + Gbp*Kpq + Gbs*Ksq;
-            nPqq = Gqq + Gqf*Kfq;
-            npt = gt + Gtf*kf + Gtp*kp; npb = gb + Gbf*kf + Gbp*kp + Gbs*ks; npq = gq + Gqf*kf;
+            s[S_KS + 0] = Ks2t; s[S_KS + 1] = Ks2b; s[S_KS + 2] = Ks2q; s[S_KS + 3] = ks2;
         } else {
-            /* pivots of Guu in the order s, p, f (s and p couple only with f) */
-            if (!(Gss > 0) || !(Gpp > 0)) return false;
-            const double is = 1.0/Gss, ip = 1.0/Gpp;
-            const double lfs = Gfs*is, lfp = Gfp*ip;
-            const double df_ = Gff - Gfs*lfs - Gfp*lfp;
+            /* s is already eliminated (assemble()): pivots of Guu in the order p, f */
+            if (!(Gpp > 0)) return false;
+            const double ip = 1.0/Gpp, lfp = Gfp*ip;
+            const double df_ = Gff - Gfp*lfp;
             if (!(df_ > 0)) return false;
             const double iff = 1.0/df_;
-            /* rhs columns: -(Gfx, Gpx, Gsx); Gsx = 0 */
-            Kft = -(Gtf - lfp*Gtp)*iff; Kpt = -(Gtp + Gfp*Kft)*ip; Kst = -(Gfs*Kft)*is;
-            Kfb = -(Gbf - lfp*Gbp)*iff; Kpb = -(Gbp + Gfp*Kfb)*ip; Ksb = -(Gfs*Kfb)*is;
-            Kfq = -(Gqf)*iff;           Kpq = -(Gfp*Kfq)*ip;       Ksq = -(Gfs*Kfq)*is;
-            kf = -(gf - lfs*gs - lfp*gp)*iff; kp = -(gp + Gfp*kf)*ip; ks = -(gs + Gfs*kf)*is;
+            Kft = -(Gtf - lfp*Gtp)*iff; Kpt = -(Gtp + Gfp*Kft)*ip;
+            Kfb = -(Gbf - lfp*Gbp)*iff; Kpb = -(Gbp + Gfp*Kfb)*ip;
+            Kfq = -(Gqf)*iff;           Kpq = -(Gfp*Kfq)*ip;
+            kf = -(gf - lfp*gp)*iff;    kp = -(gp + Gfp*kf)*ip;
             nPtt = Gtt + Gtf*Kft + Gtp*Kpt;
             nPtb = Gtb + Gtf*Kfb + Gtp*Kpb;
             nPtq = Gtf*Kfq + Gtp*Kpq;
@@ -618,29 +588,28 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         }
         if (!pn) { Kpt = 0; Kpb = 0; Kpq = 0; kp = 0; }
         s[S_K + 0] = Kft; s[S_K + 1] = Kfb; s[S_K + 2] = Kfq; s[S_K + 3] = Kpt; s[S_K + 4] = Kpb; s[S_K + 5] = Kpq;
-        s[S_K + 6] = Kst; s[S_K + 7] = Ksb; s[S_K + 8] = Ksq; s[S_KV + 0] = kf; s[S_KV + 1] = kp; s[S_KV + 2] = ks;
+        s[S_KV + 0] = kf; s[S_KV + 1] = kp;
         Ptt = nPtt; Ptb = nPtb; Ptq = nPtq; Pbb = nPbb; Pbq = nPbq; Pqq = nPqq; pt = npt; pb = npb; pq = npq;
     }
 
-    /* forward sweep; x_0 is a parameter */
+    /* forward sweep of (dt, db, dq) and the controls; x_0 is a parameter.  The step of s and the multipliers of the dynamics
+     * follow from these per node (Solver::finish_direction), except in the last interval */
     double dt = 0, db = 0, dq = 0;
     for (int i = 0; i < N; i++) {
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double df = s[S_K + 0]*dt + s[S_K + 1]*db + s[S_K + 2]*dq + s[S_KV + 0];
         const double dp = pn ? s[S_K + 3]*dt + s[S_K + 4]*db + s[S_K + 5]*dq + s[S_KV + 1] : 0.0;
-        const double dsl = s[S_K + 6]*dt + s[S_K + 7]*db + s[S_K + 8]*dq + s[S_KV + 2];
         const double dw = df + dp;
         const double nt = dt + Tb*db + Tw*dw + rt;
         const double nb = (i == N - 1) ? 0.0 : Bb*db + Bw*dw + rb;
-        const double nq = df;
-        const double *Pn = s + S_PN, *pv = s + S_PV;
-        double lt = -(Pn[0]*nt + Pn[1]*nb + Pn[2]*nq + pv[0]);
-        double lb = -(Pn[1]*nt + Pn[3]*nb + Pn[4]*nq + pv[1]);
-        if (DYN && i < N - 1) lb -= s[S_EB]*db + s[S_ES]*dsl;      /* coupling terms of the dynamic loss rows */
-        if (i == N - 1) lb = (LGtf*dt + LGbf*db + LGqf*dq + LGff*df + LGfp*dp + LGfs*dsl + Lgf)/Bw;
-        s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp; s[S_DS] = dsl; s[S_LT] = lt; s[S_LB] = lb;
-        dt = nt; db = nb; dq = nq;
+        if (i == N - 1) {
+            const double dsl = s[S_KS + 0]*dt + s[S_KS + 1]*db + s[S_KS + 2]*dq + s[S_KS + 3];
+            s[S_DS] = dsl;
+            s[S_LB] = (LGtf*dt + LGbf*db + LGqf*dq + LGff*df + LGfp*dp + LGfs*dsl + Lgf)/Bw;
+        }
+        s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp;
+        dt = nt; db = nb; dq = df;
     }
     S[N*S_STRIDE + S_DT] = dt; S[N*S_STRIDE + S_DB] = 0.0; S[N*S_STRIDE + S_DF] = 0.0;
     return true;
@@ -947,10 +916,36 @@ struct Solver {
                     s[S_TB] = e[j].tb; s[S_TW] = e[j].tw; s[S_BB] = e[j].Bb; s[S_BW] = e[j].Bw;
                     s[S_RT] = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0; s[S_RB] = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
                 }
+                if (nd.ival()) {
+                    /* everything that does not depend on the value function is folded in here, off the serial path: the couplings
+                     * with b_{i+1} (dynamic loss rows; db+ = Bb db + Bw (df + dp) + rb) and the elimination of the slack variable s,
+                     * whose pivot is Hss.  A pivot that is not positive poisons the block with NaN: the sweep then reports the
+                     * wrong inertia.  The last interval keeps its s row (b_N is a parameter; riccati_solve) */
+                    const double Bb = e[j].Bb, Bw = e[j].Bw, rb = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
+                    const bool last = nd.i == P.N - 1;
+                    double Gbs = Hbs, Gfs = Hfs, Gps = 0, gsv = hs;
+                    if (DYN && !last) {
+                        Hbb += 2*Eb*Bb; Hbf += Eb*Bw; hb += Eb*rb;
+                        if (P.withPn) Hbp += Eb*Bw;
+                        Gbs += Es*Bb; Gfs += Es*Bw; gsv += Es*rb;
+                        if (P.withPn) Gps = Es*Bw;
+                    }
+                    const double is = (Hss > 0) ? 1.0/Hss : NAN;
+                    if (!last) {
+                        const double wf = Gfs*is;
+                        Hff -= Gfs*wf; hf -= wf*gsv;
+                        if (DYN) {
+                            const double wb = Gbs*is, wp = Gps*is;
+                            Hbb -= Gbs*wb; Hbf -= Gfs*wb; Hbp -= Gps*wb; Hfp -= Gps*wf; Hpp -= Gps*wp;
+                            hb -= wb*gsv; hp -= wp*gsv;
+                        }
+                    }
+                    s[S_GFS] = Gfs; s[S_IS] = is; s[S_GS] = gsv;
+                    if (DYN) { s[S_GBS] = Gbs; s[S_GPS] = Gps; s[S_EB] = last ? 0.0 : Eb; s[S_ES] = last ? 0.0 : Es; }
+                }
                 s[S_HTT] = Htt; s[S_HBB] = Hbb; s[S_HBQ] = Hbq; s[S_HBF] = Hbf; s[S_HBP] = Hbp; s[S_HQQ] = Hqq; s[S_HQF] = Hqf;
-                s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HFS] = Hfs; s[S_HPP] = Hpp; s[S_HSS] = Hss;
-                s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp; s[S_HS] = hs;
-                if (DYN) { s[S_HBS] = Hbs; s[S_EB] = Eb; s[S_ES] = Es; }
+                s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HPP] = Hpp;
+                s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp;
             }
             /* the end-of-interval power row lives in the next stage's (b, q) block */
             c.o1[nd.i] = nHbb; c.o2[nd.i] = nHbq; c.o3[nd.i] = nhb;
@@ -964,6 +959,36 @@ struct Solver {
                 double *s = c.S + nd.i*S_STRIDE;
                 s[S_HBB] += c.o1[nd.i - 1]; s[S_HBQ] += c.o2[nd.i - 1]; s[S_HB] += c.o3[nd.i - 1];
             }
+        }
+        __syncthreads();
+    }
+
+    /*
+     * What the serial sweeps leave to the nodes: the step of the slack variable s (eliminated in assemble()) and the new
+     * multipliers of the dynamics, lam+ = -(P+ x+ + p+ + E^T y), from the value function stashed in the node's own block and
+     * the step of the next node.  The last interval's ds and lam_b come from the sweep itself.
+     */
+    __device__ __forceinline__ void finish_direction()
+    {
+        const int N = P.N;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const Node &nd = n[j];
+            if (!nd.ival()) continue;
+            double *s = c.S + nd.i*S_STRIDE;
+            const double *s1 = s + S_STRIDE;
+            const double nt = s1[S_DT], nb = s1[S_DB], df = s[S_DF];
+            const double lt = -(s[S_PN + 0]*nt + s[S_PN + 1]*nb + s[S_PN + 2]*df + s[S_PV + 0]);
+            if (nd.i < N - 1) {
+                const double db = s[S_DB], dp = s[S_DP];
+                double acc = s[S_GS] + s[S_GFS]*df;
+                if (DYN) acc += s[S_GBS]*db + s[S_GPS]*dp;
+                const double dsl = -acc*s[S_IS];
+                double lb = -(s[S_PN + 1]*nt + s[S_PN + 3]*nb + s[S_PN + 4]*df + s[S_PV + 1]);
+                if (DYN) lb -= s[S_EB]*db + s[S_ES]*dsl;      /* coupling terms of the dynamic loss rows */
+                s[S_DS] = dsl; s[S_LB] = lb;
+            }
+            s[S_LT] = lt;
         }
         __syncthreads();
     }
@@ -982,6 +1007,7 @@ struct Solver {
         __syncthreads();
         c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
         const bool ok = uni(c.misc[0]) != 0.0;
+        if (ok) finish_direction();
         if (ok) {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
