@@ -174,6 +174,24 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
                          double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms);
 int msd_synchronize(msd_handle h);
 
+/*
+ * The other two interval integrators of TrainIntegrator (mseetc/train.py:303-322) for n independent intervals -- what
+ * TrainIntegrator(model, 'CVODES' | 'IRK', opts).solve(...) (train.py:347-364) evaluates, e.g. in simulations/figure4.py.
+ *   train5 : sr0, sr1, sr2, g, rho
+ *   method : MSD_INTEGRATOR_ADAPTIVE     params = {abstol, reltol}                         (OptionsCVODES, train.py:522-534)
+ *            MSD_INTEGRATOR_COLLOCATION  params = {order, numSteps, numApproxSteps, maxIter, C[(order+1)^2], D[order+1]}
+ *                                        (OptionsIRK, train.py:484-519; C[r][j] = dL_r/dtau(tau_j), D[r] = L_r(1) on the points
+ *                                        {0} + casadi.collocation_points(order, 'radau' | 'legendre'))
+ *   t0, b0, ds, w, grad, curv : [n] time, velocity squared, interval length, specific force Fel + Fpb, gradient/1000, curvature
+ *   t_out, b_out : [n];  status_out (may be NULL): 0, or 1 where the integrator gave up (Newton not converged / step underflow)
+ */
+#define MSD_INTEGRATOR_ADAPTIVE 1
+#define MSD_INTEGRATOR_COLLOCATION 2
+int msd_interval_integrate(int device, int n, const double *train5, int method, const double *params, int nparams,
+                           const double *t0, const double *b0, const double *ds, const double *w, const double *grad, const double *curv,
+                           double *t_out, double *b_out, int *status_out);
+const char *msd_interval_last_error(void);
+
 /* device scratch management for callers without their own allocator (ctypes): */
 int msd_device_alloc(msd_handle h, unsigned long long bytes, void **dptr);
 int msd_device_free(msd_handle h, void *dptr);

@@ -74,6 +74,8 @@ def lib():
         L.msd_solve_batch_ex.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_warm.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr,
                                            ctypes.POINTER(ctypes.c_float)]
+        L.msd_interval_integrate.argtypes = [ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, _dptr, ctypes.c_int] + [_dptr]*8 + [ctypes.POINTER(ctypes.c_int)]
+        L.msd_interval_last_error.restype = ctypes.c_char_p
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
         L.msd_synchronize.argtypes = [vp]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
@@ -252,6 +254,31 @@ def stage_eval(model, optsRK, time, velocitySquared, ds, force, gradient, curvat
         prob.close()
 
     return {'time': np.atleast_1d(np.asarray(time, dtype=float)) + out[:, 0], 'velSquared': out[:, 1], 'sens': out}
+
+
+def interval_integrate(model, method, params, time, velocitySquared, ds, force, gradient, curvature, device=0):
+    """
+    TrainIntegrator.solve with the adaptive ('CVODES') or the collocation ('IRK') integrator for arrays of intervals.
+    method: 1 adaptive, params (abstol, reltol); 2 collocation, params (order, numSteps, numApproxSteps, maxIter, C.ravel(), D).
+    Returns dict(time, velSquared, status).
+    """
+
+    arrs = [np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64) for a in (time, velocitySquared, ds, force, gradient, curvature)]
+    n = max(len(a) for a in arrs)
+    arrs = [np.ascontiguousarray(np.broadcast_to(a, (n,))) for a in arrs]
+    params = _c(params)
+    train5 = _c([model.sr0, model.sr1, model.sr2, model.g, model.rho])
+    t, b, st = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
+    L = lib()
+    rc = L.msd_interval_integrate(int(device), n, _d(train5), int(method), _d(params), len(params), *[_d(a) for a in arrs], _d(t), _d(b),
+                                  st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if rc != 0:
+        msg = L.msd_interval_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise DeviceError("msd integrator error {}: {}".format(rc, msg))
+
+    return {'time': t, 'velSquared': b, 'status': st}
 
 
 def _check_post(rc):

@@ -210,11 +210,58 @@ class TrainModel():
         return traction + (pnBrake if self.withPnBrake else 0) - rr - self.resistance(gradient, curvature)
 
 
+def collocationPoints(order, scheme='radau'):
+    """
+    casadi.collocation_points(order, scheme) restated: the `order` roots, in (0, 1], of the shifted Legendre polynomial
+    ('legendre', Gauss points) or of P_{order-1} - P_order ('radau', Radau IIA points, the last one is 1).
+    """
+
+    if int(order) != order or not 1 <= order <= 9:
+        raise ValueError("Order of implicit Runge-Kutta should be a positive integer between 1 and 9!")
+
+    d = int(order)
+    leg = np.polynomial.legendre
+
+    if scheme == 'legendre':
+        x = leg.leggauss(d)[0]
+    elif scheme == 'radau':
+        coef = np.zeros(d + 1)
+        coef[d - 1], coef[d] = 1.0, -1.0
+        x = np.sort(leg.legroots(coef).real)
+        # two Newton steps on P_{d-1} - P_d polish the companion-matrix roots to working precision
+        for _ in range(2):
+            x = x - leg.legval(x, coef)/leg.legval(x, leg.legder(coef))
+        x[-1] = 1.0
+    else:
+        raise ValueError("Unknown collocation method: {}!".format(scheme))
+
+    return list(0.5*(np.sort(x) + 1.0))
+
+
+def collocationTables(order, scheme='radau'):
+    """
+    casadi.collocation_interpolators on the points {0} + collocationPoints: C[r][j] = dL_r/dtau(tau_j), D[r] = L_r(1) for the
+    Lagrange polynomials L_r of those order + 1 points.
+    """
+
+    tau = np.array([0.0] + collocationPoints(order, scheme))
+    n = len(tau)
+    C, D = np.zeros((n, n)), np.zeros(n)
+
+    for r in range(n):
+        others = np.delete(tau, r)
+        basis = np.poly1d(others, r=True)/np.prod(tau[r] - others)
+        D[r] = basis(1.0)
+        C[r, :] = basis.deriv()(tau)
+
+    return C, D
+
+
 class TrainIntegrator():
     """
-    One shooting interval (reference: train.py:280-364).  Only the explicit RK4
-    branch exists on the device; 'IRK' and 'CVODES' are validated like the
-    reference but not implemented.
+    One shooting interval (reference: train.py:280-364), evaluated on the device.  'RK' is the explicit Runge-Kutta map of the
+    OCP transcription (with sensitivities, csrc/msd_kernel.hpp); 'IRK' (collocation, casadi.simpleIRK) and 'CVODES' (adaptive
+    integration to tolerances) evaluate single intervals like simulations/figure4.py does (csrc/msd_integrators.hip).
     """
 
     def __init__(self, model, solver, optsDict={}) -> None:
@@ -222,11 +269,19 @@ class TrainIntegrator():
         if solver not in {'RK', 'IRK', 'CVODES'}:
             raise ValueError("Unknown integration method!")
 
-        if solver != 'RK':
-            raise NotImplementedError("Only the explicit Runge-Kutta integrator runs on the device.")
-
         self.model = model
-        self.opts = OptionsRK(optsDict)
+        self.solver = solver
+
+        if solver == 'RK':
+            self.opts = OptionsRK(optsDict)
+        elif solver == 'IRK':
+            self.opts = OptionsIRK(optsDict)
+            C, D = collocationTables(self.opts.order, self.opts.collMethod)
+            self._params = np.concatenate([[self.opts.order, self.opts.numSteps, self.opts.numApproxSteps, self.opts.maxIter], C.ravel(), D])
+        else:
+            self.opts = OptionsCVODES(optsDict)
+            self.opts.numApproxSteps = 0     # train.py:317
+            self._params = np.array([self.opts.absTol, self.opts.relTol])
 
     def solve(self, time, velocitySquared, ds, traction=0, pnBrake=0, gradient=0, curvature=0):
 
@@ -235,10 +290,28 @@ class TrainIntegrator():
 
         from . import _device
 
-        out = _device.stage_eval(self.model, self.opts, [time], [velocitySquared], [ds], [traction + pnBrake],
-                                 [gradient], [curvature])
+        if self.solver == 'RK':
+            out = _device.stage_eval(self.model, self.opts, [time], [velocitySquared], [ds], [traction + pnBrake], [gradient], [curvature])
+        else:
+            out = _device.interval_integrate(self.model, 1 if self.solver == 'CVODES' else 2, self._params, [time], [velocitySquared], [ds],
+                                             [traction + pnBrake], [gradient], [curvature])
 
         return {'time': float(out['time'][0]), 'velSquared': float(out['velSquared'][0])}
+
+    def solveMany(self, time, velocitySquared, ds, force, gradient=0.0, curvature=0.0):
+        "Arrays of independent intervals in one launch (no counterpart in the reference); force = traction + pnBrake."
+
+        from . import _device
+
+        if self.solver == 'RK':
+            n = len(np.atleast_1d(velocitySquared))
+            full = lambda a: np.broadcast_to(np.asarray(a, dtype=float), (n,))
+            out = _device.stage_eval(self.model, self.opts, full(time), full(velocitySquared), full(ds), full(force), full(gradient), full(curvature))
+        else:
+            out = _device.interval_integrate(self.model, 1 if self.solver == 'CVODES' else 2, self._params, time, velocitySquared, ds, force,
+                                             gradient, curvature)
+
+        return {'time': out['time'], 'velSquared': out['velSquared']}
 
 
 class OptionsRK(Options):
