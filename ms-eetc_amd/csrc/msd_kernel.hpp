@@ -27,6 +27,7 @@
  * (ocp.py:189) then are stage-local, which keeps the KKT system block tridiagonal with 3x3 blocks.
  */
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -503,7 +504,10 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
     /* kept from the last interval for the multiplier of its eliminated row */
     double LGtf = 0, LGbf = 0, LGqf = 0, LGff = 0, LGfp = 0, LGfs = 0, Lgf = 0;
 
-    for (int i = N - 1; i >= 0; i--) {
+    bool ok = true;
+    /* one backward stage; the last interval (LAST) is peeled off the loop so that the loop body is branch free */
+    auto backward = [&](const int i, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
@@ -532,7 +536,7 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         double Kft, Kfb, Kfq, Kpt, Kpb, Kpq, kf, kp;
         double nPtt, nPtb, nPtq, nPbb, nPbq, nPqq, npt, npb, npq;
 
-        if (i == N - 1) {
+        if (LAST) {
             /* the last interval still carries its s row: b_N is a parameter, df = eb db - dp + e0 from the b row */
             const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0;
             const double eb = -Bb/Bw, e0 = -rb/Bw;
@@ -548,7 +552,7 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
             if (!pn) { Hpp2 = 1; Hps2 = 0; Hpt = 0; Hpb = 0; Hpq = 0; gp2 = 0; }
             /* 2x2 pivots: s first (its reciprocal comes from assemble(), NaN when the pivot is not positive), then p */
             const double lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
-            if (!(dp_ > 0)) return false;
+            if (!(dp_ > 0)) ok = false;
             const double ip = 1.0/dp_;
             /* columns t, b, q and the vector: rhs = -(row p, row s) */
             double Kp2t = -(Hpt)*ip, Ks2t = -(Hps2*Kp2t)*is;
@@ -569,10 +573,9 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
             s[S_KS + 0] = Ks2t; s[S_KS + 1] = Ks2b; s[S_KS + 2] = Ks2q; s[S_KS + 3] = ks2;
         } else {
             /* s is already eliminated (assemble()): pivots of Guu in the order p, f */
-            if (!(Gpp > 0)) return false;
             const double ip = 1.0/Gpp, lfp = Gfp*ip;
             const double df_ = Gff - Gfp*lfp;
-            if (!(df_ > 0)) return false;
+            if (!(Gpp > 0) || !(df_ > 0)) ok = false;
             const double iff = 1.0/df_;
             Kft = -(Gtf - lfp*Gtp)*iff; Kpt = -(Gtp + Gfp*Kft)*ip;
             Kfb = -(Gbf - lfp*Gbp)*iff; Kpb = -(Gbp + Gfp*Kfb)*ip;
@@ -590,27 +593,33 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S)
         s[S_K + 0] = Kft; s[S_K + 1] = Kfb; s[S_K + 2] = Kfq; s[S_K + 3] = Kpt; s[S_K + 4] = Kpb; s[S_K + 5] = Kpq;
         s[S_KV + 0] = kf; s[S_KV + 1] = kp;
         Ptt = nPtt; Ptb = nPtb; Ptq = nPtq; Pbb = nPbb; Pbq = nPbq; Pqq = nPqq; pt = npt; pb = npb; pq = npq;
-    }
+    };
+    backward(N - 1, std::true_type());
+    for (int i = N - 2; i >= 0; i--) backward(i, std::false_type());     /* no early exit: a wrong inertia is rare, the branch is not */
+    if (!ok) return false;
 
     /* forward sweep of (dt, db, dq) and the controls; x_0 is a parameter.  The step of s and the multipliers of the dynamics
      * follow from these per node (Solver::finish_direction), except in the last interval */
     double dt = 0, db = 0, dq = 0;
-    for (int i = 0; i < N; i++) {
+    auto forward = [&](const int i, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double df = s[S_K + 0]*dt + s[S_K + 1]*db + s[S_K + 2]*dq + s[S_KV + 0];
         const double dp = pn ? s[S_K + 3]*dt + s[S_K + 4]*db + s[S_K + 5]*dq + s[S_KV + 1] : 0.0;
         const double dw = df + dp;
         const double nt = dt + Tb*db + Tw*dw + rt;
-        const double nb = (i == N - 1) ? 0.0 : Bb*db + Bw*dw + rb;
-        if (i == N - 1) {
+        const double nb = LAST ? 0.0 : Bb*db + Bw*dw + rb;
+        if (LAST) {
             const double dsl = s[S_KS + 0]*dt + s[S_KS + 1]*db + s[S_KS + 2]*dq + s[S_KS + 3];
             s[S_DS] = dsl;
             s[S_LB] = (LGtf*dt + LGbf*db + LGqf*dq + LGff*df + LGfp*dp + LGfs*dsl + Lgf)/Bw;
         }
         s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp;
         dt = nt; db = nb; dq = df;
-    }
+    };
+    for (int i = 0; i < N - 1; i++) forward(i, std::false_type());
+    forward(N - 1, std::true_type());
     S[N*S_STRIDE + S_DT] = dt; S[N*S_STRIDE + S_DB] = 0.0; S[N*S_STRIDE + S_DF] = 0.0;
     return true;
 }
