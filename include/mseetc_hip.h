@@ -133,6 +133,9 @@ int msd_device_count(void);
 int msd_problem_create(const msd_problem_desc *desc, int device, msd_handle *out);
 
 int msd_problem_destroy(msd_handle h);
+/* Load another problem (other grid, horizon, train, options) into an existing handle: its stream, events and device buffers are
+ * kept and grown only when needed.  What constructing the next casadiSolver costs in a receding-horizon loop. */
+int msd_problem_reconfigure(msd_handle h, const msd_problem_desc *desc);
 
 /* nz = (4 + with_pn_brake)*N + 2 (ocp.py:166-272) and rows of g per interval (ocp.py:183-229) */
 int msd_problem_nz(msd_handle h);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "msd_kernel.hpp"
 #include "msd_geometry.hpp"
@@ -41,7 +42,8 @@ struct msd_problem {
     msd::KernelFn kernel = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *d_ds = nullptr, *d_grad = nullptr, *d_curv = nullptr, *d_bmax = nullptr, *d_loss = nullptr, *d_pos = nullptr;
+    double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
+    int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
     /* grow-only scratch of the host-buffer entry point */
     double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
     int cap_scen = 0, cap_guess = 0;
@@ -60,9 +62,9 @@ int msd_device_count(void)
     return n;
 }
 
-int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
+/* argument checks shared by create and reconfigure */
+static int check_desc(const msd_problem_desc *d)
 {
-    if (!d || !out) return fail(MSD_E_INVALID, "null argument");
     if (d->abi_version != MSD_ABI_VERSION) return fail(MSD_E_INVALID, "ABI version mismatch");
     if (d->num_intervals < 1) return fail(MSD_E_INVALID, "Number of intervals must be a strictly positive integer!");
     if (d->max_iterations < 1) return fail(MSD_E_INVALID, "Maximum number of iterations must be a strictly positive integer!");
@@ -78,75 +80,121 @@ int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
     }
     for (int i = 0; i < d->num_intervals; i++)
         if (!(d->ds[i] > 0)) return fail(MSD_E_INVALID, "interval lengths must be positive");
+    return MSD_OK;
+}
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MSD_E_NODEVICE, "no HIP device visible");
-    if (device < 0 || device >= ndev) return fail(MSD_E_INVALID, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-
-    const int N = d->num_intervals;
-    const msd::Geometry geo = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
-    msd::KernelFn k = geo.fn;
-    if (!k) return fail(MSD_E_UNSUPPORTED, "numIntervals > 639 is not supported by the LDS-resident kernel");
-    const int NT = geo.NT;
-    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2);
+static int cu_count(int device, int *out)
+{
+    static std::mutex mu;
+    static int cached[64] = {0};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 64 && cached[device] > 0) { *out = cached[device]; return MSD_OK; }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (lds > 160*1024)
-        return fail(MSD_E_UNSUPPORTED, "problem does not fit the 160 KB of LDS of a compute unit");
+    if (device < 64) cached[device] = prop.multiProcessorCount;
+    *out = prop.multiProcessorCount;
+    return MSD_OK;
+}
 
-    msd_problem *h = new msd_problem();
-    h->device = device; h->NT = NT; h->lds_bytes = lds; h->kernel = k;
+/*
+ * Load a problem into a handle: kernel geometry for its horizon, scalars, and the profile arrays in the handle's device
+ * buffer (grown when the horizon or the loss table outgrows it).  Streams, events and the scenario buffers are kept.
+ */
+static int configure(msd_problem *h, const msd_problem_desc *d)
+{
+    const int N = d->num_intervals;
+    const msd::Geometry geo = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
+    if (!geo.fn) return fail(MSD_E_UNSUPPORTED, "numIntervals > 639 is not supported by the LDS-resident kernel");
+    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2);
+    if (lds > 160*1024) return fail(MSD_E_UNSUPPORTED, "problem does not fit the 160 KB of LDS of a compute unit");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));      /* nothing of the previous problem may still be running */
+
+    /* ds | grad | curv | bmax | pos in one buffer */
+    if (N > h->cap_N) {
+        hipFree(h->d_prof); h->d_prof = nullptr; h->cap_N = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_prof, sizeof(double)*(5*(size_t)N + 2)));
+        h->cap_N = N;
+    }
+    {
+        std::vector<double> host(5*(size_t)N + 2);
+        double *ds = host.data(), *grad = ds + N, *curv = grad + N, *bmax = curv + N, *pos = bmax + N + 1;
+        memcpy(ds, d->ds, sizeof(double)*N); memcpy(grad, d->grad, sizeof(double)*N); memcpy(curv, d->curv, sizeof(double)*N);
+        memcpy(bmax, d->bmax, sizeof(double)*(N + 1));
+        pos[0] = 0;
+        for (int i = 0; i < N; i++) pos[i + 1] = pos[i] + d->ds[i];
+        HIP_TRY(hipMemcpy(h->d_prof, host.data(), sizeof(double)*host.size(), hipMemcpyHostToDevice));
+    }
+    if (d->loss_kind == 2) {
+        if (d->loss_table_len > h->cap_loss) {
+            hipFree(h->d_loss); h->d_loss = nullptr; h->cap_loss = 0;
+            HIP_TRY(hipMalloc((void **)&h->d_loss, sizeof(double)*d->loss_table_len));
+            h->cap_loss = d->loss_table_len;
+        }
+        HIP_TRY(hipMemcpy(h->d_loss, d->loss_table, sizeof(double)*d->loss_table_len, hipMemcpyHostToDevice));
+    }
+
+    h->NT = geo.NT; h->lds_bytes = lds; h->kernel = geo.fn;
     msd::DevProb &P = h->P;
     P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0; P.pos = nullptr; P.start = d->start_kind;
+    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind;
+    P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
+    P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
 
-#define UPLOAD(dst, src, n)                                                                    \
-    do {                                                                                       \
-        if (hipMalloc((void **)&(dst), sizeof(double)*(n)) != hipSuccess ||                    \
-            hipMemcpy((dst), (src), sizeof(double)*(n), hipMemcpyHostToDevice) != hipSuccess) { \
-            msd_problem_destroy(h);                                                            \
-            return fail(MSD_E_HIP, "profile upload failed");                                   \
-        }                                                                                      \
-    } while (0)
-    UPLOAD(h->d_ds, d->ds, N); UPLOAD(h->d_grad, d->grad, N); UPLOAD(h->d_curv, d->curv, N); UPLOAD(h->d_bmax, d->bmax, N + 1);
-    if (d->loss_kind == 2) UPLOAD(h->d_loss, d->loss_table, d->loss_table_len);
-    {
-        double *pos = new double[N + 1];
-        pos[0] = 0;
-        for (int i = 0; i < N; i++) pos[i + 1] = pos[i] + d->ds[i];
-        hipError_t e1 = hipMalloc((void **)&h->d_pos, sizeof(double)*(N + 1));
-        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(h->d_pos, pos, sizeof(double)*(N + 1), hipMemcpyHostToDevice) : e1;
-        delete[] pos;
-        if (e2 != hipSuccess) { msd_problem_destroy(h); return fail(MSD_E_HIP, "profile upload failed"); }
+    HIP_TRY(hipFuncSetAttribute((const void *)geo.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)geo.fn, geo.NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    int rc = cu_count(h->device, &cus);
+    if (rc != MSD_OK) return rc;
+    h->max_grid = per_cu*cus;
+    /* the scenario buffers are sized by nz: a different layout invalidates them */
+    const int nz = (4 + P.withPn)*N + 2, nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
+    if (nz > h->cap_nz || nl > h->cap_nl) {
+        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_guess);
+        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = h->d_guess = nullptr; h->cap_scen = 0; h->cap_guess = 0;
+        h->cap_nz = nz; h->cap_nl = nl;
     }
-#undef UPLOAD
-    P.ds = h->d_ds; P.grad = h->d_grad; P.curv = h->d_curv; P.bmax = h->d_bmax; P.loss = h->d_loss; P.pos = h->d_pos;
+    return MSD_OK;
+}
 
+int msd_problem_create(const msd_problem_desc *d, int device, msd_handle *out)
+{
+    if (!d || !out) return fail(MSD_E_INVALID, "null argument");
+    int rc = check_desc(d);
+    if (rc != MSD_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MSD_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(MSD_E_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    msd_problem *h = new msd_problem();
+    h->device = device;
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         msd_problem_destroy(h);
         return fail(MSD_E_HIP, "stream/event creation failed");
     }
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        msd_problem_destroy(h);
-        return fail(MSD_E_HIP, "cannot reserve dynamic LDS");
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    h->max_grid = per_cu*prop.multiProcessorCount;
+    rc = configure(h, d);
+    if (rc != MSD_OK) { const std::string keep = g_err; msd_problem_destroy(h); g_err = keep; return rc; }
     *out = h;
     return MSD_OK;
+}
+
+int msd_problem_reconfigure(msd_handle h, const msd_problem_desc *d)
+{
+    if (!h || !d) return fail(MSD_E_INVALID, "null argument");
+    int rc = check_desc(d);
+    if (rc != MSD_OK) return rc;
+    return configure(h, d);
 }
 
 int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_ds); hipFree(h->d_grad); hipFree(h->d_curv); hipFree(h->d_bmax); hipFree(h->d_loss); hipFree(h->d_pos);
+    hipFree(h->d_prof); hipFree(h->d_loss);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -228,8 +276,9 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
         h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = nullptr; h->cap_scen = 0;
         HIP_TRY(hipMalloc((void **)&h->d_scen, sizeof(double)*MSD_SC_COUNT*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_ovr, sizeof(double)*MSD_OV_COUNT*nscen));
-        HIP_TRY(hipMalloc((void **)&h->d_z, sizeof(double)*nz*nscen));
-        HIP_TRY(hipMalloc((void **)&h->d_lam, sizeof(double)*nl*nscen));
+        /* sized for the largest layout this handle has been configured for (msd_problem_reconfigure) */
+        HIP_TRY(hipMalloc((void **)&h->d_z, sizeof(double)*(size_t)h->cap_nz*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_lam, sizeof(double)*(size_t)h->cap_nl*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen));
         h->cap_scen = nscen;
     }
@@ -246,7 +295,7 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
             if (!std::isfinite(z_guess[k])) return fail(MSD_E_INVALID, "warm start guess must be finite");
         if (nscen > h->cap_guess) {
             hipFree(h->d_guess); h->d_guess = nullptr; h->cap_guess = 0;
-            HIP_TRY(hipMalloc((void **)&h->d_guess, sizeof(double)*nz*nscen));
+            HIP_TRY(hipMalloc((void **)&h->d_guess, sizeof(double)*(size_t)h->cap_nz*nscen));
             h->cap_guess = nscen;
         }
         HIP_TRY(hipMemcpyAsync(h->d_guess, z_guess, sizeof(double)*nz*nscen, hipMemcpyHostToDevice, h->stream));

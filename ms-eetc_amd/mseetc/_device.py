@@ -68,6 +68,7 @@ def lib():
         L.msd_device_count.restype = ctypes.c_int
         L.msd_problem_create.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, ctypes.POINTER(vp)]
         L.msd_problem_destroy.argtypes = [vp]
+        L.msd_problem_reconfigure.argtypes = [vp, ctypes.POINTER(ProblemDesc)]
         L.msd_problem_nz.argtypes = [vp]
         L.msd_problem_rows_per_interval.argtypes = [vp]
         L.msd_solve_batch.argtypes = [vp, ctypes.c_int, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
@@ -150,6 +151,18 @@ class DeviceProblem():
         self.nz = L.msd_problem_nz(self._h)
         self.rowsPerInterval = L.msd_problem_rows_per_interval(self._h)
         self.device = device
+
+    def reconfigure(self, desc):
+        "Load another problem into this handle (stream and device buffers are kept): msd_problem_reconfigure."
+
+        L = lib()
+        _check(L.msd_problem_reconfigure(self._h, ctypes.byref(desc)))
+        self.desc = desc
+        self.N = desc.num_intervals
+        self.nz = L.msd_problem_nz(self._h)
+        self.rowsPerInterval = L.msd_problem_rows_per_interval(self._h)
+
+        return self
 
     def close(self):
 

@@ -33,6 +33,11 @@ def transferSolution(z, positionsOld, positionsNew, withPnBrake):
     if z.shape[1] != stp*No + 2:
         raise ValueError("Solution does not match the old grid!")
 
+    # the common case of the shrinking horizon: the new grid is a tail of the old one -> a slice
+    off = No - Nn
+    if 0 <= off and np.allclose(pNew, pOld[off:], rtol=0, atol=1e-6):
+        return np.ascontiguousarray(z[:, stp*off:])
+
     body = z[:, :stp*No].reshape(-1, No, stp)
     tOld = np.concatenate([body[:, :, 2 + pn], z[:, stp*No:stp*No + 1]], axis=1)
     bOld = np.concatenate([body[:, :, 3 + pn], z[:, stp*No + 1:stp*No + 2]], axis=1)
@@ -83,6 +88,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     position = 0.0
     current = copy.deepcopy(track)
     previous = None
+    last = None
     log = []
 
     for k in range(numResolves):
@@ -96,13 +102,24 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         opts['numIntervals'] = Nk
 
         solver = make(train, current, opts)
+
+        if hasattr(solver, 'adoptDevice'):
+            solver.adoptDevice(last)      # same device handle for every re-solve
+
         common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 
         if warmStart and previous is not None:
             zPrev, posPrev, okPrev = previous
             guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
-            res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, **common)
-            redo = np.flatnonzero(~okPrev | (res['status'] < 0))
+            usable = okPrev & np.isfinite(guess).all(axis=1)
+            if usable.any() and not usable.all():
+                guess[~usable] = guess[np.flatnonzero(usable)[0]]      # placeholder rows: these scenarios are re-solved cold below
+            if usable.any():
+                res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, **common)
+                redo = np.flatnonzero(~usable | (res['status'] < 0))
+            else:
+                res = solver.solveBatch(T, **common)
+                redo = np.zeros(0, dtype=int)
             if redo.size:
                 sub = solver.solveBatch(T[redo], initialTime=t_now[redo], terminalVelocity=terminalVelocity, initialVelocity=v_now[redo])
                 for key in ('z', 'status', 'iterations', 'cost'):
@@ -115,8 +132,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         log.append(dict(position=position, numIntervals=Nk, t0=t_now.copy(), v0=v_now.copy(), status=res['status'].copy(),
                         iterations=res['iterations'].copy(), cost=res['cost'].copy(), z=res['z']))
 
-        if hasattr(solver, 'close'):
-            solver.close()
+        last = solver
 
         if Nk - stride < 1:
             break
@@ -136,5 +152,8 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         position += advance
         current = copy.deepcopy(current)
         current.updateLimits(positionStart=advance)
+
+    if last is not None and hasattr(last, 'close'):
+        last.close()
 
     return log

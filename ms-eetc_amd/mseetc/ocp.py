@@ -180,6 +180,17 @@ class casadiSolver():
 
         return self._problem
 
+    def adoptDevice(self, other):
+        """
+        Take over the device handle of another solver (which becomes unusable) instead of creating a new one: the next problem of a
+        receding-horizon loop reuses the stream and the device buffers of the previous one (msd_problem_reconfigure).
+        """
+
+        if other is not None and other._problem is not None and other._device == self._device and self._problem is None:
+            self._problem, other._problem = other._problem.reconfigure(self._desc), None
+
+        return self
+
     def close(self):
 
         if self._problem is not None:

@@ -316,6 +316,27 @@ def test_config4_warm_started_mpc_matches_cold():
     assert itw < 0.85*itc      # the cold re-solves already use the profile start (about 21 iterations); warm ones need about 15
 
 
+def test_handle_reuse_across_problems():
+    # msd_problem_reconfigure: one device handle carried through problems of different horizon, track and layout gives the
+    # results of fresh handles (the receding-horizon loop reuses its stream and buffers this way)
+    train = cases.train_default()
+    nopn = cases.train_default(); nopn.forceMinPn = 0
+    problems = [(train, cases.track_00(), 100, cases.c1_times(8)), (train, cases.track_00(crop=20000), 40, np.linspace(800.0, 950.0, 5)),
+                (train, cases.track_CH(), 200, cases.c2_times(12)), (nopn, cases.track_00(), 100, cases.c1_times(3))]
+    carried = None
+    for tr, tk, N, T in problems:
+        fresh = _solver(tr, tk, N, start='profile')
+        want = fresh.solveBatch(T, multipliers=True)
+        fresh.close()
+        solver = _solver(tr, tk, N, start='profile').adoptDevice(carried)
+        got = solver.solveBatch(T, multipliers=True)
+        assert np.array_equal(got['status'], want['status']) and np.all(got['status'] == 0)
+        assert np.array_equal(got['z'], want['z']) and np.array_equal(got['lam_g'], want['lam_g']) and np.array_equal(got['iterations'], want['iterations'])
+        assert carried is None or carried._problem is None
+        carried = solver
+    carried.close()
+
+
 def test_dynamic_loss_model_vs_oracle():
     # simulations/figure5.py configuration with the dynamic losses of efficiency.py (fun2): 8.5 km, v0 = 1, vN = 100 km/h
     from oracle import oracle
