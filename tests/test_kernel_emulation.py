@@ -75,3 +75,42 @@ def test_emulated_warm_start_matches_oracle(emu):
     assert st[0, ST['STATUS']] == 0
     assert int(st[0, ST['ITERS']]) == int(warm['stats']['ITERS'])
     assert np.max(np.abs(z[0] - warm['z'])/np.maximum(1, np.abs(warm['z']))) < 1e-8
+
+
+@pytest.mark.parametrize('variant', ['dynamic_losses', 'no_pneumatic_brake_time_optimal'])
+def test_emulated_kernel_other_stage_systems(emu, variant):
+    "The two stage-system variants the static both-brakes cases do not reach: dynamic loss rows (couplings folded in assemble) and no Fpb."
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from mseetc.train import Train
+    from mseetc.track import computeDiscretizationPoints
+    from oracle import oracle
+    N = 30
+    track = cases.track_00(8500)
+    if variant == 'dynamic_losses':
+        from mseetc.efficiency import totalLossesFunction
+        train = Train(config={'id': 'NL_Intercity_VIRM6'})
+        train.forceMinPn = 0
+        train.powerLosses = totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+        eo, T = True, 272.4726*1.2
+        oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+        pts = computeDiscretizationPoints(track, N)
+        prob = oracle.pack_problem(train, pts, dict(numIntervals=N, maxIterations=300, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1),
+                                   2, 0.0, 0.0, track.length)
+    else:
+        train = cases.train_fig5()
+        eo, T = False, 400.0
+        prob = cases.oracle_problem(train, track, N, energyOptimal=False, losses='none', maxIterations=300)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, energyOptimal=eo, integrationOptions=dict(numSteps=1, numApproxSteps=1)),
+                          startingPoint='profile')
+    scen = solver._scenarios(T, 0, 100/3.6, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    rows = solver.problem_rows if hasattr(solver, 'problem_rows') else (2 + 3 + (2 if eo else 0))
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, rows*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    ref = oracle.solve(prob, prob.scenario(T, 0.0, 100/3.6, 1.0), start='profile')
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert abs(int(st[0, ST['ITERS']]) - int(ref['stats']['ITERS'])) <= 1
+    assert abs(st[0, ST['OBJ']] - ref['stats']['OBJ']) <= 1e-9*abs(ref['stats']['OBJ'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
