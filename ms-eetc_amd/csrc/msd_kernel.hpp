@@ -319,19 +319,46 @@ struct Ctx {
 };
 enum { PH_EVAL = 0, PH_KKT, PH_ASSEMBLE, PH_RICCATI, PH_READBACK, PH_GPHID, PH_STEPLEN, PH_MERIT, PH_UPDATE, PH_OTHER, PH_COUNT };
 
-struct OpMax { __device__ double operator()(double a, double b) const { return fmax(a, b); } };
-struct OpMin { __device__ double operator()(double a, double b) const { return fmin(a, b); } };
-struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { __device__ double operator()(double a, double b) const { return fmax(a, b); } __device__ static double identity() { return -INFINITY; } };
+struct OpMin { __device__ double operator()(double a, double b) const { return fmin(a, b); } __device__ static double identity() { return INFINITY; } };
+struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } __device__ static double identity() { return 0.0; } };
+
+/*
+ * Reduction over the 64 lanes of a wave, result in every lane.  On the GPU: DPP moves (row_shr 1/2/4/8 inside the rows of 16 lanes,
+ * row_bcast 15 and 31 across them) leave the total in lane 63, v_readlane broadcasts it -- 6 dependent steps of 3 VALU instructions
+ * instead of 6 round trips through the LDS crossbar (__shfl_xor = ds_bpermute), and the iteration has some forty of these.
+ */
+#ifndef MSD_HOST_EMULATION
+template <int CTRL, int ROW_MASK, class Op> __device__ __forceinline__ double dpp_combine(double x, Op op)
+{
+    const double id = Op::identity();
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(id), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(id), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return op(x, __hiloint2double(hi, lo));
+}
+template <class Op> __device__ __forceinline__ double wave_reduce(double x, Op op)
+{
+    x = dpp_combine<0x111, 0xf>(x, op);      /* row_shr:1 */
+    x = dpp_combine<0x112, 0xf>(x, op);      /* row_shr:2 */
+    x = dpp_combine<0x114, 0xf>(x, op);      /* row_shr:4 */
+    x = dpp_combine<0x118, 0xf>(x, op);      /* row_shr:8 */
+    x = dpp_combine<0x142, 0xa>(x, op);      /* row_bcast:15 into rows 1 and 3 */
+    x = dpp_combine<0x143, 0xc>(x, op);      /* row_bcast:31 into rows 2 and 3 */
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+#else
+template <class Op> __device__ __forceinline__ double wave_reduce(double x, Op op)
+{
+    for (int off = 32; off >= 1; off >>= 1) x = op(x, __shfl_xor(x, off));
+    return x;
+}
+#endif
 
 template <int K, class Op> __device__ __forceinline__ void block_reduce(double (&v)[K], Op op, Ctx &c)
 {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        double x = v[k];
-        for (int off = 32; off >= 1; off >>= 1) x = op(x, __shfl_xor(x, off));
-        v[k] = x;
-    }
-    if (c.nw == 1) return;         /* one wave per workgroup: the butterfly already left the result in every lane */
+    for (int k = 0; k < K; k++) v[k] = wave_reduce(v[k], op);
+    if (c.nw == 1) return;         /* one wave per workgroup: the wave reduction already left the result in every lane */
     double *buf = c.red + (c.red_slot & (RED_SLOTS - 1))*(MAX_WAVES*RED_K);
     c.red_slot++;
     if (c.lane == 0) {

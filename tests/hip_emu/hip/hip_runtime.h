@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstring>
 
+#define MSD_HOST_EMULATION 1
 #define __global__
 #define __device__
 #define __host__
