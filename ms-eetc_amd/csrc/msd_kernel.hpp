@@ -436,7 +436,7 @@ __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); 
 /* same, but pins the value in an accumulation register at the fence: state that the next phase does not touch stays out of the
  * 256 architectural VGPRs (MSD_FENCE_AGPR: 0 none, 1 bound/slack multipliers, 2 all duals, steps and residuals) */
 #ifndef MSD_FENCE_AGPR
-#define MSD_FENCE_AGPR 0
+#define MSD_FENCE_AGPR 1
 #endif
 __device__ __forceinline__ void opaque_a(double &v) { asm volatile("" : "+a"(v)); }
 __device__ __forceinline__ void opaque_z(double &v) { if (MSD_FENCE_AGPR >= 1) opaque_a(v); else opaque(v); }
