@@ -32,8 +32,14 @@ def build(force=False):
     so = HERE / 'libms_oracle.so'
     src = [HERE / 'ms_oracle.c', HERE / 'ms_oracle.h']
 
-    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in src if s.exists()):
-        subprocess.run(['make', '-C', str(HERE), 'libms_oracle.so'], check=True, capture_output=True)
+    # content hash, not file times: those do not survive the copy to the GPU box in any useful order
+    import hashlib
+    digest = hashlib.sha256(b''.join(s.read_bytes() for s in src + [HERE / 'Makefile'] if s.exists())).hexdigest()
+    stamp = HERE / 'libms_oracle.so.stamp'
+
+    if force or not so.exists() or not stamp.exists() or stamp.read_text().strip() != digest:
+        subprocess.run(['make', '-B', '-C', str(HERE), 'libms_oracle.so'], check=True, capture_output=True)
+        stamp.write_text(digest)
 
     return so
 
