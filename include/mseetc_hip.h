@@ -42,7 +42,7 @@ extern "C" {
 /*
  * Starting point of a solve.  REFERENCE: the reference's cold start (ocp.py:325-339: Fel 0.5, Fpb -0.1, s 1, t linear,
  * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
- * consistent forces (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the iterations, and a
+ * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the iterations, and a
  * scenario that breaks down from it (any failure
  * but the iteration limit) is solved again from the reference's point inside the same launch.
  */

@@ -46,6 +46,9 @@
 #ifndef MSD_FENCE_DUALS
 #define MSD_FENCE_DUALS 1           /* also fence multipliers and residuals, not only the primal point */
 #endif
+#ifndef MSD_PROFILE_SKIP_LSQ
+#define MSD_PROFILE_SKIP_LSQ 1      /* profile start begins with zero constraint multipliers: the least-squares estimate costs a KKT solve and buys no iterations there */
+#endif
 #ifndef MSD_RICCATI_INLINE
 #define MSD_RICCATI_INLINE 1
 #endif
@@ -1440,6 +1443,9 @@ struct Solver {
         double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
+#if MSD_PROFILE_SKIP_LSQ
+        if (ext || startKind != MSD_START_PROFILE)
+#endif
         {
             const bool ok = direction(e, MODE_LSQ, 0.0, 0.0);
             double lmax = 0;

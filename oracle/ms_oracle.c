@@ -1044,8 +1044,21 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
  * multipliers start on the central path of mu0 (z = mu0/slack) and the barrier parameter starts at mu0.
  * Scaling factors are still computed at the (warm) starting point like IPOPT does.
  */
+static int solve_core(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, const double *guess, double mu0, double push, int skip_lsq,
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+
 int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                       const double *bmax, const double *guess, double mu0, double push,
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+{
+    return solve_core(ip, dp, ds, grad, curv, bmax, guess, mu0, push, 0, z_out, lam_out, stats, hist, hist_cap);
+}
+
+/* skip_lsq: start with zero constraint multipliers instead of the least-squares estimate (profile start: the estimate costs a
+ * KKT solve and buys no iterations there) */
+static int solve_core(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, const double *guess, double mu0, double push, int skip_lsq,
                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
 {
     const int warm = guess != NULL;
@@ -1135,7 +1148,9 @@ int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const d
     /* least-squares multiplier estimate (W&B section 3.6): solve with W = 0, Sigma = I, no barrier terms.
      * Realised with the same machinery: a temporary iterate whose Sigma are 1 and whose gradient is
      * grad f - zL + zU; constraint residuals zero. */
-    {
+    if (skip_lsq) {
+        for (int i = 0; i < N; i++) { W->it[i].lam[0] = W->it[i].lam[1] = 0; for (int r = 0; r < NR; r++) W->it[i].nu[r] = 0; }
+    } else {
         /* build h = grad f - zL + zU by tricking bar_terms: use a private assembly */
         StageIt *save = malloc((N + 1)*sizeof(StageIt)); memcpy(save, W->it, (N + 1)*sizeof(StageIt));
         /* zero multipliers -> W = objective Hessian only; we want W = 0 exactly, so use a copy of ev with zero obj Hessian */
@@ -1481,7 +1496,7 @@ int oracle_solve_start(const int *ip, const double *dp, const double *ds, const 
     const int nz = (4 + (P.withPn ? 1 : 0))*P.N + 2;
     double *guess = malloc(nz*sizeof(double));
     profile_guess(&P, guess);
-    int st = oracle_solve_warm(ip, dp, ds, grad, curv, bmax, guess, K_MU_INIT, K_PUSH, z_out, lam_out, stats, hist, hist_cap);
+    int st = solve_core(ip, dp, ds, grad, curv, bmax, guess, K_MU_INIT, K_PUSH, 1, z_out, lam_out, stats, hist, hist_cap);
     free(guess);
     if (st < 0 && st != OR_STATUS_MAXITER) {
         const double spent = stats[OR_ST_ITERS];
