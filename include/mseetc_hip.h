@@ -190,6 +190,9 @@ int msd_synchronize(msd_handle h);
  */
 #define MSD_INTEGRATOR_ADAPTIVE 1
 #define MSD_INTEGRATOR_COLLOCATION 2
+/* TrainIntegrator.calcRollingResistance (train.py:416-454): params = {abstol, reltol}; t0 is ignored and t_out receives the specific
+ * energy [J/kg] dissipated by the rolling resistance over the interval */
+#define MSD_INTEGRATOR_ROLLING_RESISTANCE 3
 int msd_interval_integrate(int device, int n, const double *train5, int method, const double *params, int nparams,
                            const double *t0, const double *b0, const double *ds, const double *w, const double *grad, const double *curv,
                            double *t_out, double *b_out, int *status_out);

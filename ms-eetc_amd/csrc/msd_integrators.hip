@@ -89,6 +89,56 @@ __device__ int iv_dopri(const IvTrain &T, double ds, double w, double G, double 
     return tau >= 1.0 ? 0 : 1;
 }
 
+/*
+ * Energy dissipated by the rolling resistance over one interval (train.py:416-454): states (b, e) over the unit interval,
+ * db/dsigma as above, de/dsigma = ds (sr0 + sr1 sqrt(b) + sr2 b); the same adaptive pair, error control on both states.
+ */
+__device__ int iv_rolling(const IvTrain &T, double ds, double w, double G, double &b, double &e, double atol, double rtol)
+{
+    const double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                 a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                 a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                 b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                 e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+    double y[2] = {b, e}, k[7][2], yt[2], yn[2];
+    auto f = [&](const double (&x)[2], double (&out)[2]) {
+        const double v = sqrt(x[0]), rr = T.sr0 + T.sr1*v + T.sr2*x[0];
+        out[0] = 2*ds*(w - rr - G); out[1] = ds*rr;
+    };
+    double tau = 0, h = 0.05;
+    f(y, k[0]);
+    for (int step = 0; step < 400000 && tau < 1.0; step++) {
+        if (tau + h > 1.0) h = 1.0 - tau;
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*a21*k[0][m];
+        f(yt, k[1]);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*(a31*k[0][m] + a32*k[1][m]);
+        f(yt, k[2]);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*(a41*k[0][m] + a42*k[1][m] + a43*k[2][m]);
+        f(yt, k[3]);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*(a51*k[0][m] + a52*k[1][m] + a53*k[2][m] + a54*k[3][m]);
+        f(yt, k[4]);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*(a61*k[0][m] + a62*k[1][m] + a63*k[2][m] + a64*k[3][m] + a65*k[4][m]);
+        f(yt, k[5]);
+        for (int m = 0; m < 2; m++) yn[m] = y[m] + h*(b1*k[0][m] + b3*k[2][m] + b4*k[3][m] + b5*k[4][m] + b6*k[5][m]);
+        f(yn, k[6]);
+        double err = 0;
+        for (int m = 0; m < 2; m++) {
+            const double sc = atol + rtol*fmax(fabs(y[m]), fabs(yn[m]));
+            err = fmax(err, fabs(h*(e1*k[0][m] + e3*k[2][m] + e4*k[3][m] + e5*k[4][m] + e6*k[5][m] + e7*k[6][m])/sc));
+        }
+        const bool finite = isfinite(yn[0]) && isfinite(yn[1]) && yn[0] > 0;
+        if (finite && (err <= 1.0 || h < 1e-14)) {
+            tau += h;
+            for (int m = 0; m < 2; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-300) return 1;
+    }
+    b = y[0]; e = y[1];
+    return tau >= 1.0 ? 0 : 1;
+}
+
 /* ---- collocation ---- */
 struct Colloc { int d, numSteps, numApprox, maxIter; const double *C, *D; };     /* C[(d+1)*(d+1)] row r, column j; D[d+1] */
 
@@ -182,6 +232,17 @@ __global__ void adaptive_kernel(IvTrain T, int n, const double *t0, const double
     if (status) status[k] = st;
 }
 
+__global__ void rolling_kernel(IvTrain T, int n, const double *b0, const double *ds, const double *w, const double *grad, const double *curv,
+                               double atol, double rtol, double *e_out, double *b_out, int *status)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double b = b0[k], e = 0.0;
+    const int st = iv_rolling(T, ds[k], w[k], iv_resistance(T, grad[k], curv[k]), b, e, atol, rtol);
+    e_out[k] = e; b_out[k] = b;
+    if (status) status[k] = st;
+}
+
 __global__ void colloc_kernel(IvTrain T, Colloc K, int n, const double *t0, const double *b0, const double *ds, const double *w, const double *grad, const double *curv,
                               double *t_out, double *b_out, int *status)
 {
@@ -224,7 +285,7 @@ int msd_interval_integrate(int device, int n, const double *train5, int method, 
     for (int k = 0; k < n; k++)
         if (!(b0[k] > 0) || !(ds[k] > 0)) return iv_fail(MSD_E_INVALID, "velocitySquared and ds must be positive");
     Colloc K = {0, 0, 0, 0, nullptr, nullptr};
-    if (method == MSD_INTEGRATOR_ADAPTIVE) {
+    if (method == MSD_INTEGRATOR_ADAPTIVE || method == MSD_INTEGRATOR_ROLLING_RESISTANCE) {
         if (nparams != 2 || !(params[0] > 0) || !(params[1] > 0)) return iv_fail(MSD_E_INVALID, "adaptive integrator needs (abstol, reltol) > 0");
     } else if (method == MSD_INTEGRATOR_COLLOCATION) {
         if (nparams < 4) return iv_fail(MSD_E_INVALID, "collocation integrator needs (order, numSteps, numApproxSteps, maxIter, C, D)");
@@ -248,7 +309,11 @@ int msd_interval_integrate(int device, int n, const double *train5, int method, 
     for (int a = 0; a < 6; a++) IV_TRY(hipMemcpy(d + (size_t)a*n, src[a], sizeof(double)*n, hipMemcpyHostToDevice));
     const IvTrain T = {train5[0], train5[1], train5[2], train5[3], train5[4]};
     const dim3 grid((n + 63)/64), block(64);
-    if (method == MSD_INTEGRATOR_ADAPTIVE) {
+    if (method == MSD_INTEGRATOR_ROLLING_RESISTANCE) {
+        /* t0 is ignored, t_out receives the specific energy [J/kg] */
+        hipLaunchKernelGGL(rolling_kernel, grid, block, 0, 0, T, n, d + n, d + 2*(size_t)n, d + 3*(size_t)n, d + 4*(size_t)n, d + 5*(size_t)n,
+                           params[0], params[1], d + 6*(size_t)n, d + 7*(size_t)n, d_st);
+    } else if (method == MSD_INTEGRATOR_ADAPTIVE) {
         hipLaunchKernelGGL(adaptive_kernel, grid, block, 0, 0, T, n, d, d + n, d + 2*(size_t)n, d + 3*(size_t)n, d + 4*(size_t)n, d + 5*(size_t)n,
                            params[0], params[1], d + 6*(size_t)n, d + 7*(size_t)n, d_st);
     } else {

@@ -298,6 +298,33 @@ class TrainIntegrator():
 
         return {'time': float(out['time'][0]), 'velSquared': float(out['velSquared'][0])}
 
+    def initRollingResistance(self, solver='CVODES'):
+        "Integrator of the energy dissipated by the rolling resistance (train.py:416-442); only the adaptive one runs on the device."
+
+        if solver not in {'RK', 'CVODES'}:
+            raise ValueError("Unknown solver!")
+
+        if solver != 'CVODES':
+            raise NotImplementedError("Only the adaptive integrator of the rolling resistance runs on the device.")
+
+        self._rollingParams = np.array([1e-8, 1e-6])     # train.py:436
+
+    def calcRollingResistance(self, velocity, ds, traction=0, pnBrake=0, gradient=0, curvature=0):
+        "(specific energy [J/kg] lost to the rolling resistance over ds, velocity at the end of the interval) (train.py:445-454)."
+
+        if not hasattr(self, '_rollingParams'):
+            raise ValueError("Call initRollingResistance first!")
+
+        from . import _device
+
+        velocity = np.atleast_1d(np.asarray(velocity, dtype=float))
+        out = _device.interval_integrate(self.model, 3, self._rollingParams, 0.0, velocity**2, ds,
+                                         np.asarray(traction, dtype=float) + (np.asarray(pnBrake, dtype=float) if self.model.withPnBrake else 0.0),
+                                         gradient, curvature)
+        losses, vEnd = out['time'], np.sqrt(out['velSquared'])
+
+        return (float(losses[0]), float(vEnd[0])) if losses.size == 1 else (losses, vEnd)
+
     def solveMany(self, time, velocitySquared, ds, force, gradient=0.0, curvature=0.0):
         "Arrays of independent intervals in one launch (no counterpart in the reference); force = traction + pnBrake."
 

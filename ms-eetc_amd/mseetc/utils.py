@@ -244,11 +244,9 @@ def postProcessDataFrame(dfIn, points, train, CVODES=True, integrateLosses=False
     Adds the force / power / energy columns the reference computes after a solve (utils.py:223-336).  The two integrations
     run on the GPU (csrc/msd_post.hip): `CVODES=True` re-simulates the trajectory in the time domain with accumulated errors
     (utils.py:164-194), `integrateLosses=True` integrates the losses over every interval instead of the mid-point rule
-    (utils.py:261-289).  `integrateRollingResistance` is not available.
+    (utils.py:261-289), `integrateRollingResistance=True` adds the energy dissipated by the rolling resistance per interval
+    (utils.py:296-320; like the reference it integrates with the traction and pneumatic-brake forces only).
     """
-
-    if integrateRollingResistance:
-        raise NotImplementedError("Integrated rolling resistance is outside the device hot path.")
 
     unitScaling = 1e-6/3.6  # Nm -> kWh
     totalMass = train.mass*train.rho
@@ -313,6 +311,16 @@ def postProcessDataFrame(dfIn, points, train, CVODES=True, integrateLosses=False
     cr = np.array([curvatureResistance(c, train.g, train.rho) for c in curv])
 
     df['Acceleration [m/s^2]'] = df['Force [N]'].values/totalMass - rr - train.g*grad/train.rho - cr
+
+    if integrateRollingResistance:   # utils.py:296-320
+
+        from .train import TrainIntegrator
+
+        integ = TrainIntegrator(model, 'RK')
+        integ.initRollingResistance(solver='CVODES')
+        loss, _ = integ.calcRollingResistance(vel[:-1], np.diff(pos), facc[:-1]/totalMass, fpb[:-1]/totalMass, grad[:-1], curv[:-1])
+
+        df['Rolling resistance [kWh]'] = np.append(unitScaling*totalMass*np.atleast_1d(loss), np.nan)
 
     if CVODES:   # simulateCVODES (utils.py:164-194, 332-334)
 

@@ -167,3 +167,51 @@ def test_figure4_space_versus_time_consistency():
         pos, vel = _device.resimulate(model, [[f]], [[t]], [0.0], [0.0], [0.0], [v0/3.6])
         assert abs(pos[0, -1] - 100.0) <= 1e-8 and abs(vel[0, -1] - np.sqrt(b)) <= 1e-8
     assert abs(ends['c'][1]*3.6 - 1.0) < 2e-3 and abs(ends['d'][1]*3.6 - 10.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_rolling_resistance_integration_vs_scipy_and_post_processing():
+    # TrainIntegrator.calcRollingResistance (train.py:416-454) and the 'Rolling resistance [kWh]' column of
+    # postProcessDataFrame(integrateRollingResistance=True) (utils.py:296-320)
+    from scipy.integrate import solve_ivp
+    from mseetc.train import TrainIntegrator
+    from mseetc.ocp import casadiSolver
+    from mseetc.utils import postProcessDataFrame
+    train = cases.train_default()
+    model = train.exportModel()
+    integ = TrainIntegrator(model, 'RK')
+    with pytest.raises(ValueError):
+        integ.calcRollingResistance(10.0, 100.0)
+    with pytest.raises(ValueError):
+        integ.initRollingResistance(solver='EULER')
+    integ.initRollingResistance(solver='CVODES')
+    rng = np.random.default_rng(5)
+    n = 16
+    v0, ds, f = rng.uniform(5, 40, n), rng.uniform(20, 500, n), rng.uniform(0.0, 0.4, n)
+    grad = rng.uniform(-0.01, 0.01, n)
+    loss, vEnd = integ.calcRollingResistance(v0, ds, f, 0.0, grad, 0.0)
+    for k in range(n):
+        G = model.resistance(grad[k], 0.0)
+        def rhs(s, y):
+            v = np.sqrt(y[0]); rr = model.sr0 + model.sr1*v + model.sr2*y[0]
+            return [2*ds[k]*(f[k] - rr - G), ds[k]*rr]
+        if v0[k]**2 + 2*ds[k]*(f[k] - 0.05 - abs(G)) < 9.0:
+            continue
+        ref = solve_ivp(rhs, (0, 1), [v0[k]**2, 0.0], method='DOP853', rtol=1e-12, atol=1e-12)
+        assert abs(loss[k] - ref.y[1, -1]) <= 2e-6*ref.y[1, -1] + 1e-7      # integrated at abstol 1e-8 / reltol 1e-6 (train.py:436)
+        assert abs(vEnd[k] - np.sqrt(ref.y[0, -1])) <= 1e-5*vEnd[k]
+    one = integ.calcRollingResistance(float(v0[0]), float(ds[0]), float(f[0]), 0.0, float(grad[0]), 0.0)
+    assert one[0] == loss[0] and one[1] == vEnd[0]
+    # post-processing column: present, NaN in the last row, close to the mid-point estimate on a solved trajectory
+    solver = casadiSolver(train, cases.track_00(), dict(numIntervals=100, maxIterations=500, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
+    df, stats = solver.solve(1600.0)
+    full = postProcessDataFrame(df[['Position [m]', 'Velocity [m/s]', 'Force (el) [N]', 'Force (pnb) [N]', 'Slacks']], solver.points, train,
+                                CVODES=False, integrateRollingResistance=True)
+    col = full['Rolling resistance [kWh]'].values
+    assert np.isnan(col[-1]) and np.all(col[:-1] > 0)
+    accel = full['Force (el) [N]'].values[:-1] >= 0      # where the reference's force convention equals the real one
+    vel, pos = full['Velocity [m/s]'].values, full['Position [m]'].values
+    vm = 0.5*(vel[:-1] + vel[1:])
+    mid = (1e-6/3.6)*(train.r0 + train.r1*vm + train.r2*vm**2)*np.diff(pos)
+    coast = accel & (np.abs(full['Force (pnb) [N]'].values[:-1]) < 1.0) & (vel[:-1] > 10)
+    assert coast.sum() > 20 and np.allclose(col[:-1][coast], mid[coast], rtol=0.05)
