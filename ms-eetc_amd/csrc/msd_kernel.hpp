@@ -393,6 +393,13 @@ __device__ __forceinline__ void bar_terms(double x, double lb, double ub, bool h
     Sg = S; gphi = g;
 }
 
+/* keep z within [mu/(kappa_Sigma s), kappa_Sigma mu/s] (W&B eq. (16)); one reciprocal for both ends */
+__device__ __forceinline__ double sigma_clamp(double z, double mu, double s)
+{
+    const double r = mu/s;
+    return fmax(fmin(z, K_SIGMA*r), r*(1.0/K_SIGMA));
+}
+
 /* kp: bound_push = bound_frac (1e-2) for a cold start, the caller's push for a warm one */
 __device__ __forceinline__ double push_in(double x, double lb, double ub, bool hasL, bool hasU, double kp)
 {
@@ -1757,8 +1764,8 @@ struct Solver {
                     nd.zL[k] += alpha_du*dzl;
                     if (hasU(k)) nd.zU[k] += alpha_du*dzu;
                     /* keep Sigma within [mu/(kappa_Sigma s), kappa_Sigma mu/s] (W&B eq. (16)) */
-                    { const double s = nd.x[k] - lbv(k); nd.zL[k] = fmax(fmin(nd.zL[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                    if (hasU(k)) { const double s = ubv(j, k) - nd.x[k]; nd.zU[k] = fmax(fmin(nd.zU[k], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                    { const double s = nd.x[k] - lbv(k); nd.zL[k] = sigma_clamp(nd.zL[k], mu, s); }
+                    if (hasU(k)) { const double s = ubv(j, k) - nd.x[k]; nd.zU[k] = sigma_clamp(nd.zU[k], mu, s); }
                 }
                 if (nd.ival()) {
 #pragma unroll
@@ -1770,8 +1777,8 @@ struct Solver {
                         const double dnu = (Sg + dw)*nd.dsg[r] + gphi - nd.nu[r];
                         nd.sg[r] += alpha_pr*nd.dsg[r];
                         nd.nu[r] += alpha_pr*dnu;
-                        if (U.rL[r]) { nd.zLs[r] += alpha_du*dzl; const double s = nd.sg[r] - U.dL[r]; nd.zLs[r] = fmax(fmin(nd.zLs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
-                        if (U.rU[r]) { nd.zUs[r] += alpha_du*dzu; const double s = U.dU[r] - nd.sg[r]; nd.zUs[r] = fmax(fmin(nd.zUs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                        if (U.rL[r]) { nd.zLs[r] += alpha_du*dzl; const double s = nd.sg[r] - U.dL[r]; nd.zLs[r] = sigma_clamp(nd.zLs[r], mu, s); }
+                        if (U.rU[r]) { nd.zUs[r] += alpha_du*dzu; const double s = U.dU[r] - nd.sg[r]; nd.zUs[r] = sigma_clamp(nd.zUs[r], mu, s); }
                     }
                     nd.lam[0] += alpha_pr*(dd.lt - nd.lam[0]); nd.lam[1] += alpha_pr*(dd.lb - nd.lam[1]);
                 }
