@@ -1627,9 +1627,10 @@ struct Solver {
             if (dw > 0) delta_last = dw;
 
             /* directional derivative of the barrier function, step norms */
-            double gphid, rel_step;
+            double gphid, amax;
+            bool tiny_step;
             {
-                double gd = 0, dn = 0, rel = 0;
+                double gd = 0, dn = 0, rel = -1.0, rp = 0, rd = 0;
                 double og[SPT][NV];
 #pragma unroll
                 for (int j = 0; j < SPT; j++) {
@@ -1648,34 +1649,59 @@ struct Solver {
                     if (!nd.node()) continue;
                     if (nd.i + 1 < N) og[j][VF] += c.o1[nd.i + 1];
                     Dir dd; load_dir(j, dd);
+                    /* per bound: one reciprocal of the slack serves the barrier gradient, the primal ratio -d/s and the dual step
+                     * dz = (mu -+ z d)/s - z; fraction to the boundary: alpha = min(1, tau/max ratio) */
 #pragma unroll
                     for (int k = 0; k < NV; k++) {
                         if (!nd.on(k)) continue;
-                        double Sg, gp; var_terms(j, k, mu, Sg, gp);
-                        gd += (og[j][k] + gp)*dd.dx[k];
-                        dn = fmax(dn, fabs(dd.dx[k])); rel = fmax(rel, fabs(dd.dx[k])/(1 + fabs(nd.x[k])));
+                        const double d = dd.dx[k];
+                        double gp;
+                        {
+                            const double r = 1.0/(nd.x[k] - lbv(k)), z = nd.zL[k];
+                            gp = -mu*r; rp = fmax(rp, -d*r);
+                            rd = fmax(rd, -(r*(mu - z*d) - z)/z);
+                        }
+                        if (hasU(k)) {
+                            const double r = 1.0/(ubv(j, k) - nd.x[k]), z = nd.zU[k];
+                            gp += mu*r; rp = fmax(rp, d*r);
+                            rd = fmax(rd, -(r*(mu + z*d) - z)/z);
+                        } else gp += K_D*mu;
+                        gd += (og[j][k] + gp)*d;
+                        dn = fmax(dn, fabs(d)); rel = fmax(rel, fabs(d) - 10*DBL_EPSILON*(1 + fabs(nd.x[k])));
                     }
                     if (nd.ival()) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++) {
-                            if (!U.rowOn[r]) continue;
-                            double Sg, gp; row_terms(j, r, mu, Sg, gp);
-                            gd += gp*nd.dsg[r];
-                            dn = fmax(dn, fabs(nd.dsg[r])); rel = fmax(rel, fabs(nd.dsg[r])/(1 + fabs(nd.sg[r])));
+                        for (int r_ = 0; r_ < NR; r_++) {
+                            if (!U.rowOn[r_]) continue;
+                            const double d = nd.dsg[r_];
+                            double gp = 0;
+                            if (U.rL[r_]) {
+                                const double r = 1.0/(nd.sg[r_] - U.dL[r_]), z = nd.zLs[r_];
+                                gp -= mu*r; rp = fmax(rp, -d*r);
+                                rd = fmax(rd, -(r*(mu - z*d) - z)/z);
+                            }
+                            if (U.rU[r_]) {
+                                const double r = 1.0/(U.dU[r_] - nd.sg[r_]), z = nd.zUs[r_];
+                                gp += mu*r; rp = fmax(rp, d*r);
+                                rd = fmax(rd, -(r*(mu + z*d) - z)/z);
+                            }
+                            if (U.rL[r_] && !U.rU[r_]) gp += K_D*mu;
+                            if (!U.rL[r_] && U.rU[r_]) gp -= K_D*mu;
+                            gd += gp*d;
+                            dn = fmax(dn, fabs(d)); rel = fmax(rel, fabs(d) - 10*DBL_EPSILON*(1 + fabs(nd.sg[r_])));
                         }
                     }
                 }
                 double v1[1] = {gd}; block_reduce<1>(v1, OpSum(), c);
-                double v2[2] = {dn, rel}; block_reduce<2>(v2, OpMax(), c);
-                gphid = uni(v1[0]); dnorm = uni(v2[0]); rel_step = uni(v2[1]);
+                double v2[4] = {dn, rel, rp, rd}; block_reduce<4>(v2, OpMax(), c);
+                gphid = uni(v1[0]); dnorm = uni(v2[0]); tiny_step = uni(v2[1]) < 0;
+                const double rpm = uni(v2[2]), rdm = uni(v2[3]);
+                amax = (rpm > tau) ? tau/rpm : 1.0;
+                alpha_du = (rdm > tau) ? tau/rdm : 1.0;
             }
             c.mark(PH_GPHID); phase_fence(PH_GPHID);
 
-            double amax;
-            step_lengths(mu, tau, amax, alpha_du);
-            c.mark(PH_STEPLEN); phase_fence(PH_STEPLEN);
-
-            const bool tiny = rel_step < 10*DBL_EPSILON;
+            const bool tiny = tiny_step;
             double alpha = amax;
             bool accepted = false, ftype_armijo = false;
             if (tiny) {
