@@ -1392,7 +1392,15 @@ struct Solver {
             const double f = (bs1 - bs0)/(2*nd.ds) + P.sr0 + P.sr1*vm + P.sr2*vm*vm + nd.G;
             double fel = fmin(fmax(f, P.fmin), P.fmax);
             if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
-            const double fpb = P.withPn ? fmin(fmax(f - fel, P.fminPn), 0.0) : 0.0;
+            double fpb = 0.0;
+            if (P.withPn) {
+                /* the interior push will move Fpb at least this far below its upper bound 0: start there and let Fel make up for
+                 * it, so that the pushed point still has the acceleration the profile needs (a start from standstill must not stall) */
+                const double pb = K_PUSH*fmin(1.0, fabs(P.fminPn));
+                fpb = fmin(fmin(fmax(f - fel, P.fminPn), 0.0), -pb);
+                fel = fmin(fmax(f - fpb, P.fmin), P.fmax);
+                if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
+            }
             double sl;
             if (DYN) { const DynLoss D(P.loss); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
             else sl = fmax(P.ct*fel, -P.cr*fel) + S0;

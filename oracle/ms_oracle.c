@@ -1475,7 +1475,15 @@ static void profile_guess(const Prob *P, double *z)
         const double f = (bs1 - bs0)/(2*P->ds[i]) + P->sr0 + P->sr1*vm + P->sr2*vm*vm + track_resistance(P, P->grad[i], P->curv[i]);
         double fel = fmin(fmax(f, P->fmin), P->fmax);
         if (P->hasPower) { const double vmx = fmax(v[i], v[i + 1]); fel = fmin(fmax(fel, -fabs(P->pwL)/vmx), fabs(P->pwU)/vmx); }
-        const double fpb = P->withPn ? fmin(fmax(f - fel, P->fminPn), 0.0) : 0.0;
+        double fpb = 0.0;
+        if (P->withPn) {
+            /* the interior push will move Fpb at least this far below its upper bound 0: start there and let Fel make up for it,
+             * so that the pushed point still has the acceleration the profile needs (a start from standstill must not stall) */
+            const double pb = K_PUSH*fmin(1.0, fabs(P->fminPn));
+            fpb = fmin(fmin(fmax(f - fel, P->fminPn), 0.0), -pb);
+            fel = fmin(fmax(f - fpb, P->fmin), P->fmax);
+            if (P->hasPower) { const double vmx = fmax(v[i], v[i + 1]); fel = fmin(fmax(fel, -fabs(P->pwL)/vmx), fabs(P->pwU)/vmx); }
+        }
         double sl;
         if (P->lossKind == 2) { double lr[2][6]; loss_rows(&P->dyn, fel, 0.5*(v[i] + v[i + 1]), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
         else sl = fmax(P->ct*fel, -P->cr*fel) + S0;

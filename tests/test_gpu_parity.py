@@ -267,6 +267,25 @@ def test_profile_start_falls_back_to_the_reference_point():
     assert mid['status'][0] == 0 and late['status'][0] == -1
 
 
+def test_profile_start_very_loose_schedules():
+    # running times many times the minimum (the train crawls at 2-4 m/s): the profile start keeps the start from standstill moving
+    # (it starts Fpb where the interior push would put it and lets Fel make up for it) and converges where the reference's
+    # starting point runs into a line-search failure
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00()
+    prob = cases.oracle_problem(train, track, 100)
+    T = [8000.0, 12000.0, 20000.0]
+    fast = _solver(train, track, 100, start='profile').solveBatch(T)
+    assert np.all(fast['status'] == 0)
+    for k, t in enumerate(T):
+        ref = oracle.solve(prob, prob.scenario(t), start='profile')
+        assert ref['stats']['STATUS'] == 0 and abs(fast['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+        assert abs(int(fast['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2
+    assert np.all(np.diff(fast['cost']) < 0)      # more time, less energy
+    cold = _solver(train, track, 100, start='reference').solveBatch(T)
+    assert cold['status'][0] == 0 and abs(cold['cost'][0] - fast['cost'][0]) <= 1e-7*fast['cost'][0]
+
+
 def test_warm_start_vs_oracle():
     # msd_solve_batch_warm: same iterates as the oracle's warm start (iteration counts equal), same optimum as a cold solve
     from oracle import oracle
