@@ -34,6 +34,27 @@ BYTES_PER_STAGE_ITER = 904.0   # SURVEY.md section 8d, streaming model S (nu = 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
+def usable_cores():
+    "Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a 256-thread box may grant 16)."
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]                      # cgroup v2
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota)/float(period))))
+    except Exception:
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())                      # cgroup v1
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, quota//period))
+        except Exception:
+            pass
+
+    return n
+
+
 def main():
 
     ap = argparse.ArgumentParser()
@@ -172,7 +193,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
             oprob = cases.oracle_problem(train, track, N)
-            ncores = os.cpu_count() or 1
+            ncores = usable_cores()
             # bounded sample of the same workload, sized from a first pass to about 12 s of wall time on all host cores
             t1 = time.perf_counter()
             oracle.solve_batch(oprob, scen, nthreads=ncores, start=args.start)
