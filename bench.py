@@ -64,10 +64,19 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU')
     ap.add_argument('--intervals', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-build', action='store_true', help='never compile (profiled runs): exit non-zero when the library is stale')
     ap.add_argument('--start', default='profile', choices=['profile', 'reference'],
                     help="starting point of every solve: 'profile' (library default, built on the device from the scenario) or 'reference' (cold start of ocp.py:325-339)")
     ap.add_argument('--workload', default='c1', choices=['c1', 'c2'], help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil (extra measurement)')
     args = ap.parse_args()
+
+    # build (or check) the native library before anything touches the GPU: hipcc must never run in a process that has initialised it
+    import __graft_entry__ as entry
+    if args.no_build:
+        if entry.stale() and not os.environ.get('MSD_LIB'):       # MSD_LIB: a tuning build (tools/build_variant.py) is being measured
+            raise SystemExit("bench.py --no-build: ms-eetc_amd/lib/libmseetc_hip.so is missing or stale; run `python3 __graft_entry__.py` first")
+    else:
+        entry.build()
 
     import torch
 
@@ -87,9 +96,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-
-    import __graft_entry__ as entry
-    entry.build()
 
     import cases
     from mseetc.ocp import casadiSolver

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 2
+#define MSD_ABI_VERSION 3
 
 /* error codes */
 #define MSD_OK 0
@@ -59,7 +59,8 @@ enum {
     MSD_ST_DUAL_INF, MSD_ST_CONSTR_VIOL, MSD_ST_COMPL,
     MSD_ST_N_REG, MSD_ST_N_SOC, MSD_ST_N_BACKTRACK,
     MSD_ST_CYC_TOTAL,    /* shader clock cycles the scenario's workgroup spent in the solve (telemetry)       */
-    MSD_ST_CYC_KKT,      /* ... of which inside the serial stage recursion of the KKT solves                 */
+    MSD_ST_CYC_KKT,      /* ... of which inside the serial stage recursion of the KKT solves (fallback path)  */
+    MSD_ST_N_FALLBACK,   /* KKT solves that fell back from the stage-parallel scan to the serial sweep        */
     MSD_ST_COUNT
 };
 

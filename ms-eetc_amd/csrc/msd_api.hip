@@ -43,6 +43,9 @@ struct msd_problem {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
+    double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
+    size_t cap_work = 0;
+    int SPT = 0;
     int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
     /* grow-only scratch of the host-buffer entry point */
     double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
@@ -134,7 +137,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         HIP_TRY(hipMemcpy(h->d_loss, d->loss_table, sizeof(double)*d->loss_table_len, hipMemcpyHostToDevice));
     }
 
-    h->NT = geo.NT; h->lds_bytes = lds; h->kernel = geo.fn;
+    h->NT = geo.NT; h->SPT = geo.SPT; h->lds_bytes = lds; h->kernel = geo.fn;
     msd::DevProb &P = h->P;
     P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
@@ -151,6 +154,14 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     int rc = cu_count(h->device, &cus);
     if (rc != MSD_OK) return rc;
     h->max_grid = per_cu*cus;
+    {
+        const size_t need = msd::work_doubles(geo.NT*geo.SPT)*(size_t)h->max_grid;
+        if (need > h->cap_work) {
+            hipFree(h->d_work); h->d_work = nullptr; h->cap_work = 0;
+            HIP_TRY(hipMalloc((void **)&h->d_work, sizeof(double)*need));
+            h->cap_work = need;
+        }
+    }
     /* the scenario buffers are sized by nz: a different layout invalidates them */
     const int nz = (4 + P.withPn)*N + 2, nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
     if (nz > h->cap_nz || nl > h->cap_nl) {
@@ -194,7 +205,7 @@ int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_prof); hipFree(h->d_loss);
+    hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -214,7 +225,7 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
     const int grid = nscen < h->max_grid ? nscen : h->max_grid;
     msd::DevProb P = h->P;
     P.guess = ws.d_guess; P.warmMu = ws.mu; P.warmPush = ws.push;
-    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap);
+    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, h->d_work);
     HIP_TRY(hipGetLastError());
     return MSD_OK;
 }

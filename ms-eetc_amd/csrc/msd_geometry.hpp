@@ -8,7 +8,7 @@
 
 namespace msd {
 
-using KernelFn = void (*)(DevProb, int, const double *, const double *, double *, double *, double *, double *, int);
+using KernelFn = void (*)(DevProb, int, const double *, const double *, double *, double *, double *, double *, int, double *);
 
 /* NT threads per workgroup, SPT shooting nodes per thread (NT*SPT >= N + 1) */
 struct Geometry { int NT, SPT; KernelFn fn; };
@@ -22,9 +22,15 @@ template <bool DYN> inline Geometry pick_geometry_t(int N)
     /* MSD_GEOMETRY=128x1 selects the one-node-per-thread variant (tuning experiments only) */
     const char *g = getenv("MSD_GEOMETRY");
     if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, solve_kernel<128, 1, 2, DYN>};
+#ifdef MSD_ONLY_192X2              /* debugging builds */
+    return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN>} : Geometry{0, 0, nullptr};
+#endif
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, DYN>};
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, DYN>};     /* one wave per scenario, one wave per SIMD */
     if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, DYN>};
+#ifdef MSD_MINIMAL_GEOMETRIES      /* tuning builds (tools/build_variant.py) */
+    return {0, 0, nullptr};
+#endif
     if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, DYN>};
     if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, DYN>};
     if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN>};

@@ -35,6 +35,7 @@
 #include <math.h>
 
 #include "../../include/mseetc_hip.h"
+#include "msd_scan.hpp"
 
 /* build-time tuning switches (defaults = what measured fastest on MI355X) */
 #ifndef MSD_PHASE_FENCE
@@ -54,6 +55,41 @@
 #endif
 #ifndef MSD_RICCATI_INLINE
 #define MSD_RICCATI_INLINE 1
+#endif
+/* where the iterate of a shooting node lives between the phases of an iteration: 0 = registers, 1 = the workgroup's private work
+ * area in device memory (structure of arrays over the node slots: coalesced, L2-resident), loaded by the phases that need it */
+#ifndef MSD_MEM_X
+#define MSD_MEM_X 0
+#endif
+#ifndef MSD_MEM_SG
+#define MSD_MEM_SG 0
+#endif
+#ifndef MSD_MEM_LAM
+#define MSD_MEM_LAM 0
+#endif
+#ifndef MSD_MEM_NU
+#define MSD_MEM_NU 0
+#endif
+#ifndef MSD_MEM_Z
+#define MSD_MEM_Z 0
+#endif
+#ifndef MSD_MEM_DSG
+#define MSD_MEM_DSG 0
+#endif
+#ifndef MSD_MEM_RES
+#define MSD_MEM_RES 0
+#endif
+#ifndef MSD_MEM_EV
+#define MSD_MEM_EV 0
+#endif
+#ifndef MSD_STASH_KKT
+#define MSD_STASH_KKT 0             /* the register-resident iterate is written to the work area before the stage-parallel KKT solve and read back after it */
+#endif
+#ifndef MSD_PARK_STATE
+#define MSD_PARK_STATE 0            /* pin the iterate in accumulation registers across the stage-parallel KKT solve */
+#endif
+#ifndef MSD_PARALLEL_RICCATI
+#define MSD_PARALLEL_RICCATI 1      /* stage-parallel KKT solve (scan over the lanes, msd_scan.hpp); 0: serial sweep on one lane */
 #endif
 #if MSD_RICCATI_INLINE
 #define MSD_RICCATI_ATTR __forceinline__
@@ -98,9 +134,11 @@ constexpr int S_STRIDE_STATIC = 27, S_STRIDE_DYN = 31;
 __host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE_DYN : S_STRIDE_STATIC; }
 constexpr int FILT_CAP = 64;
 constexpr int RED_K = 8, RED_SLOTS = 4, MAX_WAVES = 16;
+constexpr int MISC_FALLBACKS = 24;  /* misc[24]: KKT solves of this scenario that fell back from the scan to the serial sweep */
 constexpr int MISC_LG = 16;        /* misc[16..22]: last interval's Fel row for the multiplier of its eliminated b row (forward_chunked) */
 static_assert(12*MSD_FORWARD_CHUNKS + 3*MSD_FORWARD_CHUNKS <= RED_SLOTS*MAX_WAVES*RED_K, "chunk maps live in the reduction scratch");
 constexpr int HIST_COLS = 8;
+constexpr int CONST_DOUBLES = 96, UNI_OFF = 48;    /* LDS copies of the problem record (DevProb) and of the scenario's uniform data (Uni), behind misc */
 
 /* stage block slots.  Written by the owning thread in assemble(): the dynamics (0..5, never overwritten), the condensed
  * Hessian/gradient of (t, b, q | f, p) with the slack variable s already eliminated (6..22), and what the elimination needs
@@ -119,7 +157,7 @@ constexpr int S_EB = 28, S_ES = 29;
 
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NT, bool dyn)
 {
-    return stage_stride(dyn)*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32;
+    return stage_stride(dyn)*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32 + CONST_DOUBLES;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -382,6 +420,25 @@ template <int K, class Op> __device__ __forceinline__ void block_reduce(double (
     }
 }
 
+/* x of lane `src` (0..63) of the caller's wave, for K doubles at once; the result is unspecified when src is outside 0..63 */
+#ifndef MSD_HOST_EMULATION
+template <int K> __device__ __forceinline__ void wave_fetch(const double (&x)[K], double (&y)[K], int src)
+{
+    const int addr = (src & 63) << 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x[k]));
+        const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x[k]));
+        y[k] = __hiloint2double(hi, lo);
+    }
+}
+#else
+template <int K> __device__ __forceinline__ void wave_fetch(const double (&x)[K], double (&y)[K], int src)
+{
+    emu_wave_fetch(x, y, K, src);
+}
+#endif
+
 /* Sigma and barrier gradient of one bounded scalar */
 __device__ __forceinline__ void bar_terms(double x, double lb, double ub, bool hasL, bool hasU, double zL, double zU, double mu, double &Sg, double &gphi)
 {
@@ -422,14 +479,46 @@ __device__ __forceinline__ bool cmp_le(double lhs, double rhs, double basval) { 
  * ---------------------------------------------------------------------------------------- */
 constexpr unsigned F_ON_T = 1u, F_ON_B = 2u, F_ON_F = 4u, F_ON_P = 8u, F_ON_S = 16u, F_IVAL = 32u, F_NODE = 64u;
 
+/* one field of a node's iterate: CNT doubles, in registers or in the work area (stride NS = node slots of the workgroup) */
+template <int CNT, int NS, bool MEM> struct Field;
+template <int CNT, int NS> struct Field<CNT, NS, false> {
+    static constexpr bool in_memory = false;
+    double v[CNT];
+    __device__ __forceinline__ void bind(double *) {}
+    __device__ __forceinline__ double &operator[](int k) { return v[k]; }
+    __device__ __forceinline__ const double &operator[](int k) const { return v[k]; }
+};
+template <int CNT, int NS> struct Field<CNT, NS, true> {
+    static constexpr bool in_memory = true;
+    double *p;
+    __device__ __forceinline__ void bind(double *q) { p = q; }
+    __device__ __forceinline__ double &operator[](int k) const { return p[k*NS]; }
+};
+
+/* layout of the work area, in fields of NS doubles */
+constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_ZLS = 27, W_ZUS = 32, W_DSG = 37, W_RESC = 42, W_RESD = 44,
+              W_EV = 49, W_LG = 62, W_FIELDS = 72;
+__host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
+
+template <int NS>
 struct Node {
     int i;
     unsigned flags;
     double ds, G, sct, scb, ubB;
     /* iterate */
-    double x[NV], sg[NR], lam[2], nu[NR], zL[NV], zU[NV], zLs[NR], zUs[NR];
+    Field<NV, NS, MSD_MEM_X != 0> x;
+    Field<NR, NS, MSD_MEM_SG != 0> sg;
+    Field<2, NS, MSD_MEM_LAM != 0> lam;
+    Field<NR, NS, MSD_MEM_NU != 0> nu;
+    Field<NV, NS, MSD_MEM_Z != 0> zL, zU;
+    Field<NR, NS, MSD_MEM_Z != 0> zLs, zUs;
     /* slack part of the direction; (dx, new dynamics multipliers) stay in the node's LDS stage block */
-    double dsg[NR];
+    Field<NR, NS, MSD_MEM_DSG != 0> dsg;
+    __device__ __forceinline__ void bind(double *w)      /* w: work area of the workgroup + node slot */
+    {
+        x.bind(w + W_X*NS); sg.bind(w + W_SG*NS); lam.bind(w + W_LAM*NS); nu.bind(w + W_NU*NS); zL.bind(w + W_ZL*NS); zU.bind(w + W_ZU*NS);
+        zLs.bind(w + W_ZLS*NS); zUs.bind(w + W_ZUS*NS); dsg.bind(w + W_DSG*NS);
+    }
     __device__ __forceinline__ bool ival() const { return (flags & F_IVAL) != 0; }
     __device__ __forceinline__ bool node() const { return (flags & F_NODE) != 0; }
     __device__ __forceinline__ bool on(int k) const { return (flags >> k) & 1u; }
@@ -451,7 +540,7 @@ __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); 
 /* same, but pins the value in an accumulation register at the fence: state that the next phase does not touch stays out of the
  * 256 architectural VGPRs (MSD_FENCE_AGPR: 0 none, 1 bound/slack multipliers, 2 all duals, steps and residuals) */
 #ifndef MSD_FENCE_AGPR
-#define MSD_FENCE_AGPR 1
+#define MSD_FENCE_AGPR 0
 #endif
 __device__ __forceinline__ void opaque_a(double &v) { asm volatile("" : "+a"(v)); }
 __device__ __forceinline__ void opaque_z(double &v) { if (MSD_FENCE_AGPR >= 1) opaque_a(v); else opaque(v); }
@@ -473,28 +562,28 @@ struct Ev {
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
-template <bool DERIV>
-__device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const Node &n, const double (&x)[NV], double t1, double b1,
+template <bool DERIV, bool DYN>
+__device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
                                               double (&cv)[2], double (&dv)[NR], Ev &e)
 {
     const double b = x[VB], f = x[VF], p = P.withPn ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
-        interval_map<Jet>(P, b, f + p, n.G, n.ds, tau, bp);
+        interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau.v); cv[1] = b1 - bp.v;
         e.tb = tau.g0; e.tw = tau.g1; e.tbb = tau.h00; e.tbw = tau.h01; e.tww = tau.h11;
         e.Bb = bp.g0; e.Bw = bp.g1; e.Bbb = bp.h00; e.Bbw = bp.h01; e.Bww = bp.h11;
     } else {
         double tau, bp;
-        interval_map<double>(P, b, f + p, n.G, n.ds, tau, bp);
+        interval_map<double>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau); cv[1] = b1 - bp;
     }
     const double sb = sqrt(b), sb1 = sqrt(b1);
     if (DERIV) { e.sb = sb; e.sb1 = sb1; e.b1 = b1; }
     dv[RPW0] = U.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
     dv[RPW1] = U.rs[RPW1]*f*sb1;
-    dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - n.G);     /* ocp.py:199 */
-    if (P.lossKind == 2) {
+    dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nG);     /* ocp.py:199 */
+    if (DYN) {
         const DynLoss D(P.loss);
         double lr[2][6];
         loss_rows(D, f, 0.5*(sb + sb1), lr);                                 /* ocp.py:221: mid-point speed of the interval */
@@ -513,7 +602,8 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
-__device__ __forceinline__ double objective_term(const DevProb &P, const Node &n, const double (&x)[NV], double q, double sf)
+template <class NodeT>
+__device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &n, const double (&x)[NV], double q, double sf)
 {
     double J = 0;
     if (n.ival()) {
@@ -672,6 +762,450 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S, doub
     return true;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+#ifndef MSD_PARALLEL_NOINLINE
+#define MSD_PARALLEL_NOINLINE 0     /* the stage-parallel KKT solve as a real function: one copy of its code, its own register allocation */
+#endif
+#if MSD_PARALLEL_NOINLINE
+#define MSD_PARALLEL_ATTR __noinline__
+#else
+#define MSD_PARALLEL_ATTR __forceinline__
+#endif
+
+template <int SPT, bool DYN>
+struct ParallelRiccati {
+    /* ------------------------------------------------------------------------------------------
+     * stage-parallel KKT solve (all threads; msd_scan.hpp).  Thread l owns the consecutive regular stages l*SPT .. l*SPT+SPT-1
+     * (i < N-1; the last interval, which eliminates df through b_N, is the terminal piece every thread evaluates for itself).
+     *   1  control-eliminated triples (A, C, J) of the own stages, composed to the chunk's triple
+     *   2  suffix scan of the triples over the lanes (and waves): value-function matrix at every chunk end
+     *   3  ordinary recursion over the own stages from there: pivots (inertia), feedback, value function stash; the chunk's
+     *      affine map of the value-function gradient
+     *   4  suffix scan of those maps: gradient at every chunk end;  5  feed-forward of the own stages, closed-loop chunk map
+     *   6  prefix scan of the closed-loop maps: state at every chunk start;  7  roll-out of the own stages
+     * Returns 1 (direction left in the stage blocks like riccati_solve + forward sweep), 0 (a pivot is not positive: wrong
+     * inertia) or -1 (a scan step broke down numerically: the caller assembles again and takes the serial sweep).
+     * ---------------------------------------------------------------------------------------- */
+    static constexpr int S_STRIDE = stage_stride(DYN);
+    static constexpr int RED_MAT = 0, RED_AFB = 21*8, RED_AFF = 21*8 + 12*8;
+    static_assert(21*8 + 12*8 + 12*8 <= RED_SLOTS*MAX_WAVES*RED_K, "wave totals of the scans live in the reduction scratch");
+
+    __device__ static __forceinline__ void pack_elem(const Elem &e, double (&a)[21])
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) a[3*i + j] = e.A[i][j];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { a[9 + k] = e.C[k]; a[15 + k] = e.J[k]; }
+    }
+    __device__ static __forceinline__ void unpack_elem(const double (&a)[21], Elem &e)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) e.A[i][j] = a[3*i + j];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { e.C[k] = a[9 + k]; e.J[k] = a[15 + k]; }
+    }
+    __device__ static __forceinline__ void pack_aff(const Aff &f, double (&a)[12])
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            a[9 + i] = f.v[i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) a[3*i + j] = f.M[i][j];
+        }
+    }
+    __device__ static __forceinline__ void unpack_aff(const double (&a)[12], Aff &f)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            f.v[i] = a[9 + i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) f.M[i][j] = a[3*i + j];
+        }
+    }
+
+    /* triple of one regular stage from its block; returns det R */
+    __device__ static __forceinline__ double stage_elem(const double *s, const bool pn, Elem &e)
+    {
+        const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW];
+        const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
+                     Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
+        double rff, rfp, rpp, det;
+        if (pn) { det = Hff*Hpp - Hfp*Hfp; const double id = 1.0/det; rff = Hpp*id; rfp = -Hfp*id; rpp = Hff*id; }
+        else { det = Hff; rff = 1.0/Hff; rfp = 0; rpp = 0; }
+        const double sf = rff + rfp, sp = rfp + rpp, sw = sf + sp;
+        e.C[sy(0, 0)] = Tw*Tw*sw; e.C[sy(0, 1)] = Tw*Bw*sw; e.C[sy(1, 1)] = Bw*Bw*sw;
+        e.C[sy(0, 2)] = Tw*sf; e.C[sy(1, 2)] = Bw*sf; e.C[sy(2, 2)] = rff;
+        const double ub = sf*Hbf + sp*Hbp, uq = sf*Hqf, vb = rff*Hbf + rfp*Hbp;
+        e.A[0][0] = 1; e.A[0][1] = Tb - Tw*ub; e.A[0][2] = -Tw*uq;
+        e.A[1][0] = 0; e.A[1][1] = Bb - Bw*ub; e.A[1][2] = -Bw*uq;
+        e.A[2][0] = 0; e.A[2][1] = -vb;        e.A[2][2] = -rff*Hqf;
+        e.J[sy(0, 0)] = Htt; e.J[sy(0, 1)] = 0; e.J[sy(0, 2)] = 0;
+        e.J[sy(1, 1)] = Hbb - (Hbf*vb + Hbp*(rfp*Hbf + rpp*Hbp));
+        e.J[sy(1, 2)] = Hbq - Hqf*vb;
+        e.J[sy(2, 2)] = Hqq - Hqf*rff*Hqf;
+        return det;
+    }
+
+    __device__ static __forceinline__ bool finite6(const double (&a)[6])
+    {
+        return isfinite(a[0] + a[1] + a[2] + a[3] + a[4] + a[5]);
+    }
+
+    __device__ static MSD_PARALLEL_ATTR int solve(const int N, const bool pn, Ctx c)
+    {
+        double *S = c.S;
+        bool ok = true, bad = false;
+
+        /* ---- last interval on top of the terminal value function (only t_N is free): every thread, redundantly ---- */
+        double Pn[6], pvn[3];          /* value function of stage N-1 */
+        double LG[7];
+        double lastK[8], lastKS[4];
+        {
+            const double *s = S + (N - 1)*S_STRIDE;
+            const double Ptt = S[N*S_STRIDE + S_HTT], pt = S[N*S_STRIDE + S_HT];
+            const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+            const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
+                         Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
+            const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+            const double Prt = Ptt*rt + pt;
+            const double Mbt = Tb*Ptt, Mpt = Tw*Ptt, Mft = Mpt;
+            double Gtt = Htt + Ptt, Gtb = Mbt, Gtf = Mft, Gtp = Mpt;
+            double Gbb = Hbb + Tb*Mbt, Gbq = Hbq, Gbf = Hbf + Tb*Mft, Gbp = Hbp + Tb*Mpt;
+            double Gqq = Hqq, Gqf = Hqf;
+            double Gff = Hff + Tw*Mft, Gfp = Hfp + Tw*Mpt;
+            double Gpp = Hpp + Tw*Mpt;
+            double gt = ht + Prt, gb = hb + Tb*Prt, gq = hq;
+            double gf = hf + Tw*Prt, gp = hp + Tw*Prt;
+            if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; }
+            const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0;
+            const double eb = -Bb/Bw, e0 = -rb/Bw;
+            LG[0] = Gtf; LG[1] = Gbf; LG[2] = Gqf; LG[3] = Gff; LG[4] = Gfp; LG[5] = Gfs; LG[6] = gf;
+            const double gfe = gf + Gff*e0;
+            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs;
+            double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
+            double Hsb = Gfs*eb + Gbs;
+            double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
+            double Xtt = Gtt, Xtb = Gtb + Gtf*eb, Xbb = Gbb + 2*eb*Gbf + eb*eb*Gff, Xbq = Gbq + eb*Gqf, Xqq = Gqq;
+            double xt = gt + Gtf*e0, xb = gb + Gbf*e0 + eb*gfe, xq = gq + Gqf*e0;
+            if (!pn) { Hpp2 = 1; Hps2 = 0; Hpt = 0; Hpb = 0; Hpq = 0; gp2 = 0; }
+            const double lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
+            if (!(dp_ > 0)) ok = false;
+            const double ip = 1.0/dp_;
+            double Kp2t = -(Hpt)*ip, Ks2t = -(Hps2*Kp2t)*is;
+            double Kp2b = -(Hpb - lps*Hsb)*ip, Ks2b = -(Hsb + Hps2*Kp2b)*is;
+            double Kp2q = -(Hpq)*ip, Ks2q = -(Hps2*Kp2q)*is;
+            double kp2 = -(gp2 - lps*gs2)*ip, ks2 = -(gs2 + Hps2*kp2)*is;
+            Pn[sy(0, 0)] = Xtt + Hpt*Kp2t;
+            Pn[sy(0, 1)] = Xtb + Hpt*Kp2b;
+            Pn[sy(0, 2)] = Hpt*Kp2q;
+            Pn[sy(1, 1)] = Xbb + Hpb*Kp2b + Hsb*Ks2b;
+            Pn[sy(1, 2)] = Xbq + Hpb*Kp2q + Hsb*Ks2q;
+            Pn[sy(2, 2)] = Xqq + Hpq*Kp2q;
+            pvn[0] = xt + Hpt*kp2; pvn[1] = xb + Hpb*kp2 + Hsb*ks2; pvn[2] = xq + Hpq*kp2;
+            /* uniform feedback form: df = eb db - dp + e0 */
+            lastK[0] = -Kp2t; lastK[1] = eb - Kp2b; lastK[2] = -Kp2q; lastK[3] = Kp2t; lastK[4] = Kp2b; lastK[5] = Kp2q;
+            lastK[6] = e0 - kp2; lastK[7] = kp2;
+            if (!pn) { lastK[3] = 0; lastK[4] = 0; lastK[5] = 0; lastK[7] = 0; }
+            lastKS[0] = Ks2t; lastKS[1] = Ks2b; lastKS[2] = Ks2q; lastKS[3] = ks2;
+        }
+        __syncthreads();       /* every thread has read block N-1 before thread 0 overwrites it */
+        if (c.tid == 0) {
+            double *s = S + (N - 1)*S_STRIDE;
+            /* value function of stage N (for the multipliers of the last interval) */
+            const double Ptt = S[N*S_STRIDE + S_HTT], pt = S[N*S_STRIDE + S_HT];
+            s[S_PN + 0] = Ptt; s[S_PN + 1] = 0; s[S_PN + 2] = 0; s[S_PN + 3] = 0; s[S_PN + 4] = 0; s[S_PN + 5] = 0;
+            s[S_PV + 0] = pt; s[S_PV + 1] = 0; s[S_PV + 2] = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[S_K + k] = lastK[k];
+            s[S_KV + 0] = lastK[6]; s[S_KV + 1] = lastK[7];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[S_KS + k] = lastKS[k];
+#pragma unroll
+            for (int k = 0; k < 7; k++) c.misc[MISC_LG + k] = LG[k];
+        }
+
+        /* ---- 1: triples of the own stages ---- */
+        const int lo = c.tid*SPT;
+        const int cnt = (N - 1 - lo < 0) ? 0 : (N - 1 - lo > SPT ? SPT : N - 1 - lo);
+        Elem agg;
+        elem_identity(agg);
+        {
+            bool have = false;
+#pragma unroll
+            for (int j = SPT - 1; j >= 0; j--) {
+                if (j >= cnt) continue;
+                Elem e;
+                const double det = stage_elem(S + (lo + j)*S_STRIDE, pn, e);
+                if (!(fabs(det) > 0) || !isfinite(det)) bad = true;
+                if (have) { const double dm = combine(e, agg, agg); if (!(fabs(dm) > 0)) bad = true; }
+                else agg = e;
+                have = true;
+            }
+        }
+        /* ---- 2: suffix scan over the lanes of the wave, then over the waves ---- */
+#pragma unroll 1
+        for (int d = 1; d < 64; d <<= 1) {
+            double mine[21], theirs[21];
+            pack_elem(agg, mine);
+            wave_fetch<21>(mine, theirs, c.lane + d);
+            if (c.lane + d < 64 && (c.tid + d)*SPT < N - 1 && cnt > 0) {
+                Elem o;
+                unpack_elem(theirs, o);
+                const double dm = combine(agg, o, agg);
+                if (!(fabs(dm) > 0)) bad = true;
+            }
+        }
+        double Pb[6];                  /* value function at the first stage behind this wave's range */
+#pragma unroll
+        for (int k = 0; k < 6; k++) Pb[k] = Pn[k];
+        if (c.nw > 1) {
+            if (c.lane == 0) {
+                double a[21];
+                pack_elem(agg, a);
+#pragma unroll
+                for (int k = 0; k < 21; k++) c.red[RED_MAT + 21*c.wave + k] = a[k];
+            }
+            __syncthreads();
+            for (int w = c.nw - 1; w > c.wave; w--) {
+                if (w*64*SPT >= N - 1) continue;      /* that wave has no stages */
+                double a[21];
+#pragma unroll
+                for (int k = 0; k < 21; k++) a[k] = c.red[RED_MAT + 21*w + k];
+                Elem t;
+                unpack_elem(a, t);
+                const double dm = combine_value(t, Pb, Pb);
+                if (!(fabs(dm) > 0)) bad = true;
+            }
+        }
+        double Ps[6];                  /* value function at the chunk start (by the scan), Pe at the chunk end */
+        if (cnt > 0) { const double dm = combine_value(agg, Pb, Ps); if (!(fabs(dm) > 0)) bad = true; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Ps[k] = Pb[k];
+        }
+        double Pe[6];
+        wave_fetch<6>(Ps, Pe, c.lane + 1);
+        if (c.lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Pe[k] = Pb[k];
+        }
+        if (cnt > 0 && !finite6(Pe)) bad = true;
+
+        /* ---- 3: ordinary recursion over the own stages (matrix part), chunk map of the value-function gradient ---- */
+        double gam[SPT][3], gf0[SPT], gp0[SPT], lfpv[SPT], iffv[SPT], ipv[SPT], Gfpv[SPT];
+        Aff bmap;
+        aff_identity(bmap);
+        {
+            double Ptt = Pe[0], Ptb = Pe[1], Ptq = Pe[2], Pbb = Pe[3], Pbq = Pe[4], Pqq = Pe[5];
+#pragma unroll
+            for (int j = SPT - 1; j >= 0; j--) {
+                gam[j][0] = gam[j][1] = gam[j][2] = 0; gf0[j] = gp0[j] = lfpv[j] = iffv[j] = ipv[j] = Gfpv[j] = 0;
+                if (j >= cnt) continue;
+                double *s = S + (lo + j)*S_STRIDE;
+                const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+                const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
+                             Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
+                const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+                s[S_PN + 0] = Ptt; s[S_PN + 1] = Ptb; s[S_PN + 2] = Ptq; s[S_PN + 3] = Pbb; s[S_PN + 4] = Pbq; s[S_PN + 5] = Pqq;
+                const double Mbt = Tb*Ptt + Bb*Ptb, Mbb = Tb*Ptb + Bb*Pbb;
+                const double Mpt = Tw*Ptt + Bw*Ptb, Mpb = Tw*Ptb + Bw*Pbb, Mpq = Tw*Ptq + Bw*Pbq;
+                const double Mft = Mpt + Ptq, Mfb = Mpb + Pbq, Mfq = Mpq + Pqq;
+                double Gtt = Htt + Ptt, Gtb = Mbt, Gtf = Mft, Gtp = Mpt;
+                double Gbb = Hbb + Tb*Mbt + Bb*Mbb, Gbq = Hbq, Gbf = Hbf + Tb*Mft + Bb*Mfb, Gbp = Hbp + Tb*Mpt + Bb*Mpb;
+                double Gqq = Hqq, Gqf = Hqf;
+                double Gff = Hff + Tw*Mft + Bw*Mfb + Mfq, Gfp = Hfp + Tw*Mpt + Bw*Mpb + Mpq;
+                double Gpp = Hpp + Tw*Mpt + Bw*Mpb;
+                if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; }
+                const double ip = 1.0/Gpp, lfp = Gfp*ip;
+                const double df_ = Gff - Gfp*lfp;
+                if (!(Gpp > 0) || !(df_ > 0)) ok = false;
+                const double iff = 1.0/df_;
+                double Kft = -(Gtf - lfp*Gtp)*iff, Kpt = -(Gtp + Gfp*Kft)*ip;
+                double Kfb = -(Gbf - lfp*Gbp)*iff, Kpb = -(Gbp + Gfp*Kfb)*ip;
+                double Kfq = -(Gqf)*iff,           Kpq = -(Gfp*Kfq)*ip;
+                if (!pn) { Kpt = 0; Kpb = 0; Kpq = 0; }
+                const double nPtt = Gtt + Gtf*Kft + Gtp*Kpt;
+                const double nPtb = Gtb + Gtf*Kfb + Gtp*Kpb;
+                const double nPtq = Gtf*Kfq + Gtp*Kpq;
+                const double nPbb = Gbb + Gbf*Kfb + Gbp*Kpb;
+                const double nPbq = Gbq + Gbf*Kfq + Gbp*Kpq;
+                const double nPqq = Gqq + Gqf*Kfq;
+                /* affine part with p+ = 0: w = P+ r */
+                const double wt = Ptt*rt + Ptb*rb, wb = Ptb*rt + Pbb*rb, wq = Ptq*rt + Pbq*rb;
+                const double gt = ht + wt, gb = hb + Tb*wt + Bb*wb, gq = hq;
+                const double gfz = hf + Tw*wt + Bw*wb + wq, gpz = pn ? hp + Tw*wt + Bw*wb : 0.0;
+                const double kfz = -(gfz - lfp*gpz)*iff, kpz = pn ? -(gpz + Gfp*kfz)*ip : 0.0;
+                gam[j][0] = gt + Gtf*kfz + Gtp*kpz; gam[j][1] = gb + Gbf*kfz + Gbp*kpz; gam[j][2] = gq + Gqf*kfz;
+                gf0[j] = gfz; gp0[j] = gpz; lfpv[j] = lfp; iffv[j] = iff; ipv[j] = ip; Gfpv[j] = Gfp;
+                /* p_j = Phi^T p+ + gamma, Phi = Fx + Fu K (closed loop) */
+                const double kt = Kft + Kpt, kb = Kfb + Kpb, kq = Kfq + Kpq;
+                Aff st;
+                st.M[0][0] = 1 + Tw*kt;  st.M[0][1] = Bw*kt;      st.M[0][2] = Kft;
+                st.M[1][0] = Tb + Tw*kb; st.M[1][1] = Bb + Bw*kb; st.M[1][2] = Kfb;
+                st.M[2][0] = Tw*kq;      st.M[2][1] = Bw*kq;      st.M[2][2] = Kfq;
+                st.v[0] = gam[j][0]; st.v[1] = gam[j][1]; st.v[2] = gam[j][2];
+                aff_compose(st, bmap, bmap);
+                s[S_K + 0] = Kft; s[S_K + 1] = Kfb; s[S_K + 2] = Kfq; s[S_K + 3] = Kpt; s[S_K + 4] = Kpb; s[S_K + 5] = Kpq;
+                Ptt = nPtt; Ptb = nPtb; Ptq = nPtq; Pbb = nPbb; Pbq = nPbq; Pqq = nPqq;
+            }
+        }
+        /* ---- inertia and breakdown flags (uniform from here) ---- */
+        {
+            double v[2] = {ok ? 0.0 : 1.0, bad ? 1.0 : 0.0};
+            if (c.nw > 1) __syncthreads();      /* the wave totals of the scan share the reduction scratch */
+            block_reduce<2>(v, OpMax(), c);
+            if (c.nw > 1) __syncthreads();
+            if (uni(v[1]) != 0.0) return -1;
+            if (uni(v[0]) != 0.0) return 0;
+        }
+
+        /* ---- 4: suffix scan of the gradient maps ---- */
+#pragma unroll 1
+        for (int d = 1; d < 64; d <<= 1) {
+            double mine[12], theirs[12];
+            pack_aff(bmap, mine);
+            wave_fetch<12>(mine, theirs, c.lane + d);
+            if (c.lane + d < 64 && (c.tid + d)*SPT < N - 1 && cnt > 0) {
+                Aff o;
+                unpack_aff(theirs, o);
+                aff_compose(bmap, o, bmap);
+            }
+        }
+        double pb[3] = {pvn[0], pvn[1], pvn[2]};      /* gradient at the first stage behind this wave's range */
+        if (c.nw > 1) {
+            if (c.lane == 0) {
+                double a[12];
+                pack_aff(bmap, a);
+#pragma unroll
+                for (int k = 0; k < 12; k++) c.red[RED_AFB + 12*c.wave + k] = a[k];
+            }
+            __syncthreads();
+            for (int w = c.nw - 1; w > c.wave; w--) {
+                if (w*64*SPT >= N - 1) continue;
+                double a[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) a[k] = c.red[RED_AFB + 12*w + k];
+                Aff t;
+                unpack_aff(a, t);
+                aff_apply(t, pb, pb);
+            }
+        }
+        double ps[3], pe[3];
+        if (cnt > 0) aff_apply(bmap, pb, ps);
+        else { ps[0] = pb[0]; ps[1] = pb[1]; ps[2] = pb[2]; }
+        wave_fetch<3>(ps, pe, c.lane + 1);
+        if (c.lane == 63) { pe[0] = pb[0]; pe[1] = pb[1]; pe[2] = pb[2]; }
+
+        /* ---- 5: feed-forward of the own stages, closed-loop chunk map ---- */
+        Aff fmap;
+        aff_identity(fmap);
+        {
+            double pt = pe[0], pbv = pe[1], pq = pe[2];
+#pragma unroll
+            for (int j = SPT - 1; j >= 0; j--) {
+                if (j >= cnt) continue;
+                double *s = S + (lo + j)*S_STRIDE;
+                const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+                const double Kft = s[S_K + 0], Kfb = s[S_K + 1], Kfq = s[S_K + 2], Kpt = s[S_K + 3], Kpb = s[S_K + 4], Kpq = s[S_K + 5];
+                s[S_PV + 0] = pt; s[S_PV + 1] = pbv; s[S_PV + 2] = pq;
+                const double a = Tw*pt + Bw*pbv;
+                const double gf = gf0[j] + a + pq, gp = pn ? gp0[j] + a : 0.0;
+                const double kf = -(gf - lfpv[j]*gp)*iffv[j], kp = pn ? -(gp + Gfpv[j]*kf)*ipv[j] : 0.0;
+                s[S_KV + 0] = kf; s[S_KV + 1] = kp;
+                const double kt = Kft + Kpt, kb = Kfb + Kpb, kq = Kfq + Kpq, k0 = kf + kp;
+                /* gradient of stage j: Phi^T p+ + gamma */
+                const double npt = (1 + Tw*kt)*pt + Bw*kt*pbv + Kft*pq + gam[j][0];
+                const double npb = (Tb + Tw*kb)*pt + (Bb + Bw*kb)*pbv + Kfb*pq + gam[j][1];
+                const double npq = Tw*kq*pt + Bw*kq*pbv + Kfq*pq + gam[j][2];
+                pt = npt; pbv = npb; pq = npq;
+                /* x+ = Phi x + (Fu k + r); fmap = (later stages) o (stage j) */
+                Aff st;
+                st.M[0][0] = 1 + Tw*kt; st.M[0][1] = Tb + Tw*kb; st.M[0][2] = Tw*kq;
+                st.M[1][0] = Bw*kt;     st.M[1][1] = Bb + Bw*kb; st.M[1][2] = Bw*kq;
+                st.M[2][0] = Kft;       st.M[2][1] = Kfb;        st.M[2][2] = Kfq;
+                st.v[0] = Tw*k0 + rt; st.v[1] = Bw*k0 + rb; st.v[2] = kf;
+                aff_compose(fmap, st, fmap);
+            }
+        }
+        /* ---- 6: prefix scan of the closed-loop maps ---- */
+#pragma unroll 1
+        for (int d = 1; d < 64; d <<= 1) {
+            double mine[12], theirs[12];
+            pack_aff(fmap, mine);
+            wave_fetch<12>(mine, theirs, c.lane - d);
+            if (c.lane - d >= 0 && cnt > 0) {
+                Aff o;
+                unpack_aff(theirs, o);
+                aff_compose(fmap, o, fmap);
+            }
+        }
+        double xb[3] = {0, 0, 0};      /* state at the first stage of this wave's range; x_0 is a parameter of the NLP */
+        if (c.nw > 1) {
+            /* the wave total sits in the wave's last lane with stages; lanes behind it hold their own (identity) map */
+            const int lastLane = ((N - 2)/SPT) - 64*c.wave;      /* lane of the thread that owns stage N-2, relative to this wave */
+            const int src = lastLane < 0 ? 0 : (lastLane > 63 ? 63 : lastLane);
+            double mine[12], tot[12];
+            pack_aff(fmap, mine);
+            wave_fetch<12>(mine, tot, src);
+            if (c.lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) c.red[RED_AFF + 12*c.wave + k] = tot[k];
+            }
+            __syncthreads();
+            for (int w = 0; w < c.wave; w++) {
+                double a[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) a[k] = c.red[RED_AFF + 12*w + k];
+                Aff t;
+                unpack_aff(a, t);
+                aff_apply(t, xb, xb);
+            }
+        }
+        double xe[3], xs[3];
+        aff_apply(fmap, xb, xe);      /* state behind the own chunk */
+        wave_fetch<3>(xe, xs, c.lane - 1);
+        if (c.lane == 0) { xs[0] = xb[0]; xs[1] = xb[1]; xs[2] = xb[2]; }
+
+        /* ---- 7: roll-out of the own stages; the owner of stage N-2 continues through the last interval ---- */
+        {
+            double dt = xs[0], db = xs[1], dq = xs[2];
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (j >= cnt) continue;
+                double *s = S + (lo + j)*S_STRIDE;
+                const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+                const double df = s[S_K + 0]*dt + s[S_K + 1]*db + s[S_K + 2]*dq + s[S_KV + 0];
+                const double dp = pn ? s[S_K + 3]*dt + s[S_K + 4]*db + s[S_K + 5]*dq + s[S_KV + 1] : 0.0;
+                const double dw = df + dp;
+                const double nt = dt + Tb*db + Tw*dw + rt, nb = Bb*db + Bw*dw + rb;
+                s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp;
+                dt = nt; db = nb; dq = df;
+            }
+            const bool ownsLast = (N == 1) ? (c.tid == 0) : (cnt > 0 && lo + cnt == N - 1);
+            if (ownsLast) {
+                double *s = S + (N - 1)*S_STRIDE;
+                const double Tb = s[S_TB], Tw = s[S_TW], Bw = s[S_BW], rt = s[S_RT];
+                const double df = lastK[0]*dt + lastK[1]*db + lastK[2]*dq + lastK[6];
+                const double dp = pn ? lastK[3]*dt + lastK[4]*db + lastK[5]*dq + lastK[7] : 0.0;
+                const double dw = df + dp;
+                const double nt = dt + Tb*db + Tw*dw + rt;
+                const double dsl = lastKS[0]*dt + lastKS[1]*db + lastKS[2]*dq + lastKS[3];
+                s[S_DS] = dsl;
+                s[S_LB] = (LG[0]*dt + LG[1]*db + LG[2]*dq + LG[3]*df + LG[4]*dp + LG[5]*dsl + LG[6])/Bw;
+                s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp;
+                double *sN = S + N*S_STRIDE;
+                sN[S_DT] = nt; sN[S_DB] = 0.0; sN[S_DF] = 0.0;
+            }
+        }
+        __syncthreads();
+        return 1;
+    }
+};
+
 /* ------------------------------------------------------------------------------------------
  * the solver.  SPT = shooting nodes per thread: node j of thread `tid` is node tid + j*NT.
  * The benchmark geometry is one wave per scenario (NT = 64) with SPT = 2: four single-wave
@@ -680,16 +1214,114 @@ __device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S, doub
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int SPT, bool DYN>
+template <int NT, int SPT, bool DYN>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
+    static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
+    using NodeT = Node<NS>;
     const DevProb &P;
     Ctx &c;
-    Node n[SPT];
-    Uni U;
-    double resc[SPT][2], resd[SPT][NR];   /* right-hand sides of the linearised constraints: c and d - sigma (or their SOC accumulation) */
+    double *work;                          /* the workgroup's private work area (work_doubles(NS)) */
+    NodeT n[SPT];
+    Uni &U;                                /* workgroup-uniform data of the scenario, in LDS (like P): loaded where needed instead of held in registers */
+    /* right-hand sides of the linearised constraints: c and d - sigma (or their SOC accumulation) */
+    Field<2, NS, MSD_MEM_RES != 0> resc[SPT];
+    Field<NR, NS, MSD_MEM_RES != 0> resd[SPT];
+    /* evaluation of the current point with derivatives (evaluate_current), read back by the phases that need it */
+    Field<13, NS, MSD_MEM_EV != 0> evs[SPT];
+    Field<10, NS, MSD_MEM_EV != 0> lgs[SPT];
 
-    __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_) : P(P_), c(c_) {}
+    __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_, double *work_, Uni &U_) : P(P_), c(c_), work(work_), U(U_) {}
+
+    __device__ __forceinline__ void store_ev(int j, const Ev &e)
+    {
+        evs[j][0] = e.sb; evs[j][1] = e.sb1; evs[j][2] = e.b1; evs[j][3] = e.tb; evs[j][4] = e.tw; evs[j][5] = e.tbb; evs[j][6] = e.tbw; evs[j][7] = e.tww;
+        evs[j][8] = e.Bb; evs[j][9] = e.Bw; evs[j][10] = e.Bbb; evs[j][11] = e.Bbw; evs[j][12] = e.Bww;
+        if (DYN) {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int m = 0; m < 5; m++) lgs[j][5*k + m] = e.lg[k][m];
+        }
+    }
+    __device__ __forceinline__ void load_ev(int j, Ev &e) const
+    {
+        e.sb = evs[j][0]; e.sb1 = evs[j][1]; e.b1 = evs[j][2]; e.tb = evs[j][3]; e.tw = evs[j][4]; e.tbb = evs[j][5]; e.tbw = evs[j][6]; e.tww = evs[j][7];
+        e.Bb = evs[j][8]; e.Bw = evs[j][9]; e.Bbb = evs[j][10]; e.Bbw = evs[j][11]; e.Bww = evs[j][12];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int m = 0; m < 5; m++) e.lg[k][m] = DYN ? lgs[j][5*k + m] : 0.0;
+    }
+    /* first-order part only (sb, sb1, b1, tb, tw, Bb, Bw and the loss-row gradients): what the residual pass and the read-back need */
+    __device__ __forceinline__ void load_ev1(int j, Ev &e) const
+    {
+        e.sb = evs[j][0]; e.sb1 = evs[j][1]; e.b1 = evs[j][2]; e.tb = evs[j][3]; e.tw = evs[j][4]; e.Bb = evs[j][8]; e.Bw = evs[j][9];
+        e.tbb = e.tbw = e.tww = e.Bbb = e.Bbw = e.Bww = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int m = 0; m < 5; m++) e.lg[k][m] = DYN ? lgs[j][5*k + m] : 0.0;
+    }
+    /* explicit home of the register-resident iterate in the work area (same layout as the memory-backed fields): stash() writes the
+     * fields of node j selected by the mask, fetch() reads them back.  Between a stash and the next fetch the values are dead in
+     * registers, which is the point: the phase in between gets the register file (MSD_STASH_KKT: around the stage-parallel KKT solve) */
+    static constexpr unsigned H_X = 1u, H_SG = 2u, H_LAM = 4u, H_NU = 8u, H_Z = 16u, H_ZS = 32u, H_DSG = 64u, H_RES = 128u, H_EV = 256u, H_ALL = 511u;
+    template <int CNT, class F> __device__ __forceinline__ void put(const F &f, int off, int slot)
+    {
+        if constexpr (!F::in_memory) {
+#pragma unroll
+            for (int k = 0; k < CNT; k++) work[(off + k)*NS + slot] = f.v[k];
+        }
+    }
+    template <int CNT, class F> __device__ __forceinline__ void get(F &f, int off, int slot)
+    {
+        if constexpr (!F::in_memory) {
+#pragma unroll
+            for (int k = 0; k < CNT; k++) f.v[k] = work[(off + k)*NS + slot];
+        }
+    }
+    template <unsigned M> __device__ __forceinline__ void stash()
+    {
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            NodeT &nd = n[j];
+            const int sl = nd.i;
+            if (M & H_X) put<NV>(nd.x, W_X, sl);
+            if (M & H_SG) put<NR>(nd.sg, W_SG, sl);
+            if (M & H_LAM) put<2>(nd.lam, W_LAM, sl);
+            if (M & H_NU) put<NR>(nd.nu, W_NU, sl);
+            if (M & H_Z) { put<NV>(nd.zL, W_ZL, sl); put<NV>(nd.zU, W_ZU, sl); }
+            if (M & H_ZS) { put<NR>(nd.zLs, W_ZLS, sl); put<NR>(nd.zUs, W_ZUS, sl); }
+            if (M & H_DSG) put<NR>(nd.dsg, W_DSG, sl);
+            if (M & H_RES) { put<2>(resc[j], W_RESC, sl); put<NR>(resd[j], W_RESD, sl); }
+            if (M & H_EV) { put<13>(evs[j], W_EV, sl); if (DYN) put<10>(lgs[j], W_LG, sl); }
+        }
+        asm volatile("" ::: "memory");
+    }
+    template <unsigned M> __device__ __forceinline__ void fetch()
+    {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            NodeT &nd = n[j];
+            const int sl = nd.i;
+            if (M & H_X) get<NV>(nd.x, W_X, sl);
+            if (M & H_SG) get<NR>(nd.sg, W_SG, sl);
+            if (M & H_LAM) get<2>(nd.lam, W_LAM, sl);
+            if (M & H_NU) get<NR>(nd.nu, W_NU, sl);
+            if (M & H_Z) { get<NV>(nd.zL, W_ZL, sl); get<NV>(nd.zU, W_ZU, sl); }
+            if (M & H_ZS) { get<NR>(nd.zLs, W_ZLS, sl); get<NR>(nd.zUs, W_ZUS, sl); }
+            if (M & H_DSG) get<NR>(nd.dsg, W_DSG, sl);
+            if (M & H_RES) { get<2>(resc[j], W_RESC, sl); get<NR>(resd[j], W_RESD, sl); }
+            if (M & H_EV) { get<13>(evs[j], W_EV, sl); if (DYN) get<10>(lgs[j], W_LG, sl); }
+        }
+    }
+
+    template <class F> __device__ static __forceinline__ void fence_v(F &f, int k) { if constexpr (!F::in_memory) opaque(f.v[k]); }
+    template <class F> __device__ static __forceinline__ void fence_z(F &f, int k) { if constexpr (!F::in_memory) opaque_z(f.v[k]); }
+    template <class F> __device__ static __forceinline__ void fence_d(F &f, int k) { if constexpr (!F::in_memory) opaque_d(f.v[k]); }
+    template <class F> __device__ static __forceinline__ void fence_a(F &f, int k) { if constexpr (!F::in_memory) opaque_a(f.v[k]); }
 
     /* every free variable has a lower bound; all but the loss slack have an upper bound (ocp.py:175-181, 263-272) */
     __device__ __forceinline__ double lbv(int k) const { return k == VT ? U.tlo : k == VB ? U.blo : k == VF ? U.flo : k == VP ? U.plo : U.slo; }
@@ -702,16 +1334,44 @@ struct Solver {
     {
 #if MSD_PHASE_FENCE
         if (!((MSD_FENCE_PHASES >> phase) & 1)) return;
+        /* single-wave workgroups only: that is the geometry the fences were tuned on (N <= 127, BASELINE config 1).  With several
+         * waves per workgroup hipcc (ROCm 7.2, iterative-ilp scheduling) has produced wrong code around the fenced multipliers
+         * (192 x 2: iterate of the last wave corrupted; reproduced with tools/debug_history.py), and there the fences buy nothing */
+        if (NT != 64) return;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            Node &nd = n[j];
+            NodeT &nd = n[j];
 #pragma unroll
-            for (int k = 0; k < NV; k++) { opaque(nd.x[k]); if (MSD_FENCE_DUALS) { opaque_z(nd.zL[k]); opaque_z(nd.zU[k]); } }
+            for (int k = 0; k < NV; k++) { fence_v(nd.x, k); if (MSD_FENCE_DUALS) { fence_z(nd.zL, k); fence_z(nd.zU, k); } }
 #pragma unroll
-            for (int r = 0; r < NR; r++) { opaque(nd.sg[r]); if (MSD_FENCE_DUALS) { opaque_d(nd.nu[r]); opaque_z(nd.zLs[r]); opaque_z(nd.zUs[r]); opaque_d(nd.dsg[r]); opaque_d(resd[j][r]); } }
-            if (MSD_FENCE_DUALS) { opaque_d(nd.lam[0]); opaque_d(nd.lam[1]); opaque_d(resc[j][0]); opaque_d(resc[j][1]); }
+            for (int r = 0; r < NR; r++) { fence_v(nd.sg, r); if (MSD_FENCE_DUALS) { fence_d(nd.nu, r); fence_z(nd.zLs, r); fence_z(nd.zUs, r); fence_d(nd.dsg, r); fence_d(resd[j], r); } }
+            if (MSD_FENCE_DUALS) { fence_d(nd.lam, 0); fence_d(nd.lam, 1); fence_d(resc[j], 0); fence_d(resc[j], 1); }
         }
 #endif
+    }
+
+    /* the whole iterate into accumulation registers: the stage-parallel KKT solve touches none of it and needs the architectural
+     * registers for its scan (MSD_PARK_STATE) */
+    __device__ __forceinline__ void park_state()
+    {
+#if MSD_PARK_STATE
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            NodeT &nd = n[j];
+#pragma unroll
+            for (int k = 0; k < NV; k++) { fence_a(nd.x, k); fence_a(nd.zL, k); fence_a(nd.zU, k); }
+#pragma unroll
+            for (int r = 0; r < NR; r++) { fence_a(nd.sg, r); fence_a(nd.nu, r); fence_a(nd.zLs, r); fence_a(nd.zUs, r); fence_a(nd.dsg, r); fence_a(resd[j], r); }
+            fence_a(nd.lam, 0); fence_a(nd.lam, 1); fence_a(resc[j], 0); fence_a(resc[j], 1);
+        }
+#endif
+    }
+
+    __device__ __forceinline__ void commit_uniforms(const Uni &u)
+    {
+        __syncthreads();
+        if (c.tid == 0) U = u;
+        __syncthreads();
     }
 
     /* publish (t, b, f) of a point so that neighbours can read them */
@@ -749,7 +1409,7 @@ struct Solver {
         gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
         gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
         gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
-        if (P.lossKind == 2) {
+        if (DYN) {
             /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
             const double vb = 0.25/ev.sb, vb1 = 0.25/ev.sb1;
             gs[RLTR] = 1; gf[RLTR] = -ev.lg[0][0]; gb[RLTR] = -ev.lg[0][1]*vb; gb1[RLTR] = -ev.lg[0][1]*vb1;
@@ -782,7 +1442,7 @@ struct Solver {
     struct Dir { double dx[NV], lt, lb; };
     __device__ __forceinline__ void load_dir(int j, Dir &d) const
     {
-        const Node &nd = n[j];
+        const NodeT &nd = n[j];
 #pragma unroll
         for (int k = 0; k < NV; k++) d.dx[k] = 0;
         d.lt = d.lb = 0;
@@ -804,15 +1464,18 @@ struct Solver {
      */
     struct Err { double dual, primal, primal_u, cmax, cmin, sd, sc, theta, L, D, obj; };
 
-    __device__ __forceinline__ void kkt_pass(const Ev (&e)[SPT], Err &E)
+    __device__ __forceinline__ void kkt_pass(Err &E)
     {
+        Ev e[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) load_ev1(j, e[j]);
         double gl[SPT][NV];
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;
         double th = 0, logs = 0, damp = 0, obj = 0;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             const double q = nb_q(j);
             double out_q = 0, out_t1 = 0, out_b1 = 0, prod = 1.0;
 #pragma unroll
@@ -860,7 +1523,10 @@ struct Solver {
                     if (hasU(k)) prod *= ubv(j, k) - nd.x[k];
                     else damp += nd.x[k] - lbv(k);
                 }
-                obj += objective_term(P, nd, nd.x, q, U.sf);
+                { double xl[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
+                    obj += objective_term(P, nd, xl, q, U.sf); }
             }
             logs += log(prod);
             /* the contributions that belong to the neighbours' variables */
@@ -870,7 +1536,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             if (!nd.node()) continue;
             if (nd.i > 0) { gl[j][VT] += c.o2[nd.i - 1]; gl[j][VB] += c.o3[nd.i - 1]; }
             if (nd.i + 1 < P.N) gl[j][VF] += c.o1[nd.i + 1];
@@ -899,12 +1565,15 @@ struct Solver {
      * Condensed stage block of every node into LDS (W&B eq. (13) with slacks and bound multipliers eliminated).
      * MODE_LSQ: least-squares multiplier system (W = 0, Sigma = I, gradient = grad f - zL + zU).
      */
-    __device__ __forceinline__ void assemble(const Ev (&e)[SPT], const int mode, double mu_, double dw)
+    __device__ __forceinline__ void assemble(const int mode, double mu_, double dw)
     {
+        Ev e[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) load_ev(j, e[j]);
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             const double q = nb_q(j);
             double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
             double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
@@ -1011,7 +1680,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             if (nd.node() && nd.i > 0) {
                 double *s = c.S + nd.i*S_STRIDE;
                 s[S_HBB] += c.o1[nd.i - 1]; s[S_HBQ] += c.o2[nd.i - 1]; s[S_HB] += c.o3[nd.i - 1];
@@ -1111,7 +1780,7 @@ struct Solver {
         const int N = P.N;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             if (!nd.ival()) continue;
             double *s = c.S + nd.i*S_STRIDE;
             const double *s1 = s + S_STRIDE;
@@ -1132,33 +1801,52 @@ struct Solver {
     }
 
     /* KKT solve: assemble, serial Riccati, read the direction back.  Returns the inertia flag (uniform). */
-    __device__ __forceinline__ bool direction(const Ev (&e)[SPT], const int mode, double mu_, double dw)
+    __device__ __forceinline__ bool direction(const int mode, double mu_, double dw)
     {
         c.mark(PH_OTHER); phase_fence(PH_OTHER);
-        assemble(e, mode, mu_, dw);
+        assemble(mode, mu_, dw);
         c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
-        if (c.tid == 0) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            c.misc[0] = riccati_solve<DYN>(P, c.S, MSD_FORWARD_CHUNKS ? c.misc + MISC_LG : nullptr) ? 1.0 : 0.0;
-            c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
+        int par = -1;
+#if MSD_PARALLEL_RICCATI
+        park_state();
+#if MSD_STASH_KKT
+        stash<H_ALL & ~H_DSG>();
+#endif
+        par = ParallelRiccati<SPT, DYN>::solve(P.N, P.withPn != 0, c);
+        c.red_slot++;        /* one block reduction inside */
+#if MSD_STASH_KKT
+        fetch<H_ALL & ~H_DSG>();
+#endif
+        if (par < 0) {       /* the scan broke down (cold path): the sweeps overwrite the blocks, so assemble again */
+            assemble(mode, mu_, dw);
+            if (c.tid == 0) c.misc[MISC_FALLBACKS] += 1.0;
         }
-        __syncthreads();
-        if (MSD_FORWARD_CHUNKS) forward_chunked();
+#endif
+        if (par < 0) {
+            if (c.tid == 0) {
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                c.misc[0] = riccati_solve<DYN>(P, c.S, MSD_FORWARD_CHUNKS ? c.misc + MISC_LG : nullptr) ? 1.0 : 0.0;
+                c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
+            }
+            __syncthreads();
+            if (MSD_FORWARD_CHUNKS) forward_chunked();
+        }
         c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
-        const bool ok = uni(c.misc[0]) != 0.0;
+        const bool ok = (par >= 0) ? (par == 1) : (uni(c.misc[0]) != 0.0);
         if (ok) finish_direction();
         if (ok) {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
                 node_fence();
-                Node &nd = n[j];
+                NodeT &nd = n[j];
 #pragma unroll
                 for (int r = 0; r < NR; r++) nd.dsg[r] = 0;
                 if (!nd.ival()) continue;
                 Dir d; load_dir(j, d);
                 const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
                 double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                Ev ej; load_ev1(j, ej);
+                row_grads(j, ej, gb, gf, gp, gs, gb1);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     if (!U.rowOn[r]) continue;
@@ -1185,7 +1873,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             if (nd.node()) {
                 Dir dd; load_dir(j, dd);
 #pragma unroll
@@ -1235,11 +1923,11 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             double prod = 1.0;
             if (nd.ival()) {
                 double cv[2], dv[NR]; Ev dummy;
-                eval_interval<false>(P, U, nd, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
+                eval_interval<false, DYN>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
                 th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
@@ -1283,7 +1971,7 @@ struct Solver {
             for (int r = 0; r < NR; r++) td[j][r] = 0;
             if (n[j].ival()) {
                 double dv[NR]; Ev dummy;
-                eval_interval<false>(P, U, n[j], xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
+                eval_interval<false, DYN>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
 #pragma unroll
                 for (int r = 0; r < NR; r++) td[j][r] = U.rowOn[r] ? dv[r] - st[j][r] : 0.0;
             }
@@ -1291,7 +1979,7 @@ struct Solver {
     }
 
     /* evaluate the current point with derivatives; residuals of the Newton system into resc/resd */
-    __device__ __forceinline__ void evaluate_current(Ev (&e)[SPT])
+    __device__ __forceinline__ void evaluate_current()
     {
         publish_current();
 #pragma unroll
@@ -1301,10 +1989,15 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < NR; r++) resd[j][r] = 0;
             if (n[j].ival()) {
-                double dv[NR];
-                eval_interval<true>(P, U, n[j], n[j].x, c.xt[n[j].i + 1], c.xb[n[j].i + 1], resc[j], dv, e[j]);
+                double dv[NR], cv[2], xl[NV];
+                Ev ej;
+#pragma unroll
+                for (int k = 0; k < NV; k++) xl[k] = n[j].x[k];
+                eval_interval<true, DYN>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
+                resc[j][0] = cv[0]; resc[j][1] = cv[1];
 #pragma unroll
                 for (int r = 0; r < NR; r++) resd[j][r] = U.rowOn[r] ? dv[r] - n[j].sg[r] : 0.0;
+                store_ev(j, ej);
             }
         }
     }
@@ -1381,7 +2074,7 @@ struct Solver {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            Node &nd = n[j];
+            NodeT &nd = n[j];
             const int i = nd.i;
             if (!nd.node()) continue;
             nd.x[VT] = c.xt[i];
@@ -1419,7 +2112,7 @@ struct Solver {
         const double kp = ext ? P.warmPush : K_PUSH;
         const double mu_start = ext ? P.warmMu : K_MU_INIT;
         const unsigned long long cyc0 = __builtin_readcyclecounter();
-        if (c.tid == 0) { c.misc[1] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
+        if (c.tid == 0) { c.misc[1] = 0.0; c.misc[MISC_FALLBACKS] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
         c.tmark = cyc0;
         const double t0 = scen[MSD_SC_T0], tEnd = scen[MSD_SC_TEND], v0sq = scen[MSD_SC_V0SQ], vNsq = scen[MSD_SC_VNSQ];
 
@@ -1427,8 +2120,11 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            Node &nd = n[j];
+            NodeT &nd = n[j];
             nd.i = c.tid + j*c.nt;
+            nd.bind(work + nd.i);
+            resc[j].bind(work + W_RESC*NS + nd.i); resd[j].bind(work + W_RESD*NS + nd.i);
+            evs[j].bind(work + W_EV*NS + nd.i); lgs[j].bind(work + W_LG*NS + nd.i);
             const bool ival = nd.i < N, node = nd.i <= N;
             nd.ds = ival ? P.ds[nd.i] : 0.0;
             nd.G = ival ? track_resistance(P, P.grad[nd.i], P.curv[nd.i]) : 0.0;
@@ -1462,27 +2158,32 @@ struct Solver {
             nd.sct = nd.scb = 1;
         }
         if (!ext && startKind == MSD_START_PROFILE) profile_start(t0, tEnd, v0sq, vNsq);
-        U.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); U.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
-        U.blo = P.vminSq - K_BOUND_RELAX*fmax(1.0, fabs(P.vminSq));
-        U.flo = P.fmin - K_BOUND_RELAX*fmax(1.0, fabs(P.fmin)); U.fhi = P.fmax + K_BOUND_RELAX*fmax(1.0, fabs(P.fmax));
-        U.plo = P.fminPn - K_BOUND_RELAX*fmax(1.0, fabs(P.fminPn)); U.phi = K_BOUND_RELAX;
-        U.slo = -K_BOUND_RELAX;
+        Uni u;     /* built in registers (uniform), published to the LDS copy every phase reads */
+        u.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); u.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
+        u.blo = P.vminSq - K_BOUND_RELAX*fmax(1.0, fabs(P.vminSq));
+        u.flo = P.fmin - K_BOUND_RELAX*fmax(1.0, fabs(P.fmin)); u.fhi = P.fmax + K_BOUND_RELAX*fmax(1.0, fabs(P.fmax));
+        u.plo = P.fminPn - K_BOUND_RELAX*fmax(1.0, fabs(P.fminPn)); u.phi = K_BOUND_RELAX;
+        u.slo = -K_BOUND_RELAX;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { U.rowOn[r] = false; U.dL[r] = -INFINITY; U.dU[r] = INFINITY; U.rs[r] = 1.0; U.rL[r] = U.rU[r] = false; }
-        if (P.hasPower) { U.rowOn[RPW0] = U.rowOn[RPW1] = true; U.dL[RPW0] = U.dL[RPW1] = -fabs(P.pwL); U.dU[RPW0] = U.dU[RPW1] = fabs(P.pwU); }
-        U.rowOn[RACC] = true; U.dL[RACC] = P.accMin; U.dU[RACC] = P.accMax;
-        if (P.energyOpt) { U.rowOn[RLTR] = U.rowOn[RLRG] = true; U.dL[RLTR] = U.dL[RLRG] = 0; }
-        U.sf = 1;
+        for (int r = 0; r < NR; r++) { u.rowOn[r] = false; u.dL[r] = -INFINITY; u.dU[r] = INFINITY; u.rs[r] = 1.0; u.rL[r] = u.rU[r] = false; }
+        if (P.hasPower) { u.rowOn[RPW0] = u.rowOn[RPW1] = true; u.dL[RPW0] = u.dL[RPW1] = -fabs(P.pwL); u.dU[RPW0] = u.dU[RPW1] = fabs(P.pwU); }
+        u.rowOn[RACC] = true; u.dL[RACC] = P.accMin; u.dU[RACC] = P.accMax;
+        if (P.energyOpt) { u.rowOn[RLTR] = u.rowOn[RLRG] = true; u.dL[RLTR] = u.dL[RLRG] = 0; }
+        u.sf = 1;
+
+        commit_uniforms(u);
 
         /* ---- gradient-based scaling at the starting point (nlp_scaling_max_gradient = 100) ---- */
+        evaluate_current();
         Ev e[SPT];
-        evaluate_current(e);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) load_ev1(j, e[j]);
         {
             double gmax = 0, rmax[NR] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
                 node_fence();
-                Node &nd = n[j];
+                NodeT &nd = n[j];
                 if (nd.ival()) {
                     double of, op, os, oq, off, opp;
                     obj_grads(j, nb_q(j), of, op, os, oq, off, opp);
@@ -1508,18 +2209,19 @@ struct Solver {
             }
             double v[6] = {gmax, rmax[0], rmax[1], rmax[2], rmax[3], rmax[4]};
             block_reduce<6>(v, OpMax(), c);
-            if (uni(v[0]) > 100) U.sf = uni(100/v[0]);
+            if (uni(v[0]) > 100) u.sf = uni(100/v[0]);
 #pragma unroll
-            for (int r = 0; r < NR; r++) if (U.rowOn[r] && uni(v[1 + r]) > 100) U.rs[r] = uni(100/v[1 + r]);
+            for (int r = 0; r < NR; r++) if (u.rowOn[r] && uni(v[1 + r]) > 100) u.rs[r] = uni(100/v[1 + r]);
         }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            if (!U.rowOn[r]) continue;
-            U.dL[r] *= U.rs[r]; U.dU[r] *= U.rs[r];
-            U.rL[r] = isfinite(U.dL[r]); U.rU[r] = isfinite(U.dU[r]);
-            if (U.rL[r]) U.dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(U.dL[r]));
-            if (U.rU[r]) U.dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(U.dU[r]));
+            if (!u.rowOn[r]) continue;
+            u.dL[r] *= u.rs[r]; u.dU[r] *= u.rs[r];
+            u.rL[r] = isfinite(u.dL[r]); u.rU[r] = isfinite(u.dU[r]);
+            if (u.rL[r]) u.dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(u.dL[r]));
+            if (u.rU[r]) u.dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(u.dU[r]));
         }
+        commit_uniforms(u);
 
         /* ---- push into the interior, slacks, bound multipliers ---- */
 #pragma unroll
@@ -1533,7 +2235,7 @@ struct Solver {
                 n[j].zU[k] = hasU(k) ? (warm ? mu_start/(ubv(j, k) - n[j].x[k]) : 1.0) : 0.0;
             }
         }
-        evaluate_current(e);     /* resd = d(x) since the slacks are still zero */
+        evaluate_current();     /* resd = d(x) since the slacks are still zero */
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
@@ -1555,7 +2257,7 @@ struct Solver {
         if (ext || startKind != MSD_START_PROFILE)
 #endif
         {
-            const bool ok = direction(e, MODE_LSQ, 0.0, 0.0);
+            const bool ok = direction(MODE_LSQ, 0.0, 0.0);
             double lmax = 0;
             Dir dd[SPT];
 #pragma unroll
@@ -1573,7 +2275,7 @@ struct Solver {
             const bool use = ok && lm <= LAM_INIT_MAX && isfinite(lm);
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                Node &nd = n[j];
+                NodeT &nd = n[j];
                 const bool tk = use && nd.ival();
                 nd.lam[0] = tk ? dd[j].lt : 0.0; nd.lam[1] = tk ? dd[j].lb : 0.0;
 #pragma unroll
@@ -1591,9 +2293,9 @@ struct Solver {
 
         for (iter = 0;; iter++) {
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
-            if (iter > 0) evaluate_current(e);
+            if (iter > 0) evaluate_current();
             c.mark(PH_EVAL); phase_fence(PH_EVAL);
-            kkt_pass(e, E);
+            kkt_pass(E);
             c.mark(PH_KKT); phase_fence(PH_KKT);
             objv = E.obj/U.sf;
             if (iter == 0) { theta_max = 1e4*fmax(1.0, E.theta); theta_min = 1e-4*fmax(1.0, E.theta); }
@@ -1625,7 +2327,7 @@ struct Solver {
             double dw = 0;
             bool ok;
             for (bool first = true;; first = false) {
-                ok = direction(e, MODE_NEWTON, mu, dw);
+                ok = direction(MODE_NEWTON, mu, dw);
                 if (ok) break;
                 if (first) { n_reg++; dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last); }
                 else dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
@@ -1653,7 +2355,7 @@ struct Solver {
 #pragma unroll
                 for (int j = 0; j < SPT; j++) {
                     node_fence();
-                    const Node &nd = n[j];
+                    const NodeT &nd = n[j];
                     if (!nd.node()) continue;
                     if (nd.i + 1 < N) og[j][VF] += c.o1[nd.i + 1];
                     Dir dd; load_dir(j, dd);
@@ -1747,7 +2449,7 @@ struct Solver {
                             for (int r = 0; r < NR; r++) resd[j][r] = alpha_soc*resd[j][r] + td[j][r];
                         }
                         publish_current();     /* the neighbours' Fel in LDS are those of the trial point */
-                        if (!direction(e, MODE_NEWTON, mu, dw)) break;
+                        if (!direction(MODE_NEWTON, mu, dw)) break;
                         double adu_soc;
                         step_lengths(mu, tau, alpha_soc, adu_soc);
                         double th_s, ph_s; bool oks;
@@ -1763,8 +2465,8 @@ struct Solver {
                     }
                     if (accepted) break;
                     /* back to the Newton step: recompute it */
-                    evaluate_current(e);
-                    direction(e, MODE_NEWTON, mu, dw);
+                    evaluate_current();
+                    direction(MODE_NEWTON, mu, dw);
                     double apr_dummy;
                     step_lengths(mu, tau, apr_dummy, alpha_du);
                 }
@@ -1787,7 +2489,7 @@ struct Solver {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
                 node_fence();
-                Node &nd = n[j];
+                NodeT &nd = n[j];
                 if (!nd.node()) continue;
                 Dir dd; load_dir(j, dd);
 #pragma unroll
@@ -1825,7 +2527,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
-            const Node &nd = n[j];
+            const NodeT &nd = n[j];
             if (nd.ival()) {
                 double *zi = z_out + stp*nd.i; int k = 0;
                 zi[k++] = nd.x[VF]; if (P.withPn) zi[k++] = nd.x[VP];
@@ -1845,7 +2547,7 @@ struct Solver {
             stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/U.sf;
             stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/U.sf;
             stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back;
-            stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1];
+            stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1]; stats[MSD_ST_N_FALLBACK] = c.misc[MISC_FALLBACKS];
             /* phase telemetry of the logged scenario: the last two rows of the history buffer */
             if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
         }
@@ -1857,11 +2559,12 @@ struct Solver {
 
 /*
  * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64), NT*SPT >= N + 1.
- * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  WPS = minimum waves per SIMD the register budget is planned for.
+ * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
+ * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
  */
 template <int NT, int SPT, int WPS, bool DYN>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
-                                                       double *stats, double *hist, int hist_cap)
+                                                       double *stats, double *hist, int hist_cap, double *work)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     constexpr int NS = NT*SPT;     /* node slots */
@@ -1871,6 +2574,11 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     c.xt = c.S + stage_stride(DYN)*(P.N + 1); c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
     c.filt = c.o3 + NS; c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
+    /* the problem record and the scenario's uniform data live in LDS: phases read what they need (broadcast reads) instead of
+     * carrying some eighty uniform values through the whole solve in registers */
+    DevProb *Pl = reinterpret_cast<DevProb *>(c.misc + 32);
+    Uni *Ul = reinterpret_cast<Uni *>(c.misc + 32 + UNI_OFF);
+    static_assert(sizeof(DevProb) <= 8*UNI_OFF && sizeof(Uni) <= 8*(CONST_DOUBLES - UNI_OFF), "LDS room for the uniform records");
     const int nz = (4 + P.withPn)*P.N + 2;
     const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
     for (int sidx = blockIdx.x; sidx < nscen; sidx += gridDim.x) {
@@ -1882,7 +2590,10 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             Ps.fmax = o[MSD_OV_F_MAX]; Ps.fmin = o[MSD_OV_F_MIN]; Ps.fminPn = o[MSD_OV_F_MIN_PN];
             Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
         }
-        Solver<SPT, DYN> s(Ps, c);
+        __syncthreads();
+        if (c.tid == 0) *Pl = Ps;
+        __syncthreads();
+        Solver<NT, SPT, DYN> s(*Pl, c, work + work_doubles(NS)*blockIdx.x, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)nz*sidx : nullptr;
         int startKind = guess ? MSD_START_REFERENCE : P.start, spent = 0;
         /* a profile start that breaks down (not: runs out of iterations) is repeated from the reference's starting point */

@@ -14,8 +14,8 @@ import numpy as np
 
 LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
-ABI_VERSION = 2
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, COUNT=13)
+ABI_VERSION = 3
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, COUNT=14)
 SC_COUNT = 4
 OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, COUNT=9)
 HIST_COLS = 8

@@ -22,14 +22,15 @@ static void run_blocks(msd::DevProb P, int nscen, const double *scen, const doub
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), lds(msd::lds_doubles(P.N, NT*SPT, DYN));
-        blk.shfl = shfl.data(); blk.lds = lds.data();
+        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(msd::lds_doubles(P.N, NT*SPT, DYN));
+        blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
+        std::vector<double> work(msd::work_doubles(NT*SPT)*(size_t)nscen);
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+                msd::solve_kernel<NT, SPT, 1, DYN>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);

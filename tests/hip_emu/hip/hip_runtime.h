@@ -28,6 +28,7 @@ struct emu_block {
     pthread_barrier_t bar;
     unsigned nthreads;
     double *shfl;          /* nthreads doubles */
+    double *xch;           /* nthreads * EMU_XCH doubles: wave_fetch exchange */
     void *lds;
 };
 
@@ -46,6 +47,18 @@ static inline double __shfl_xor(double v, int mask)
     double r = emu_blk->shfl[threadIdx.x ^ (unsigned)mask];
     pthread_barrier_wait(&emu_blk->bar);
     return r;
+}
+
+/* every thread of the block calls it (uniform control flow around the wave exchanges of the kernel) */
+#define EMU_XCH 32
+static inline void emu_wave_fetch(const double *x, double *y, int K, int src)
+{
+    double *mine = emu_blk->xch + (size_t)threadIdx.x*EMU_XCH;
+    for (int k = 0; k < K; k++) mine[k] = x[k];
+    pthread_barrier_wait(&emu_blk->bar);
+    const double *from = emu_blk->xch + (size_t)((threadIdx.x & ~63u) | ((unsigned)src & 63u))*EMU_XCH;
+    for (int k = 0; k < K; k++) y[k] = from[k];
+    pthread_barrier_wait(&emu_blk->bar);
 }
 
 using std::isfinite;

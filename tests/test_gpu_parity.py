@@ -103,6 +103,19 @@ def test_initial_time_and_velocities_and_joint_rk4():
     _compare(_solver(train, track, 64, numSteps=2, numApproxSteps=0), cases.oracle_problem(train, track, 64, numSteps=2, numApproxSteps=0), [800.0])
 
 
+@pytest.mark.parametrize('start', ['reference', 'profile'])
+@pytest.mark.parametrize('N,variant', [(63, 'both'), (100, 'rg'), (127, 'both'), (150, 'rg'), (255, 'both'), (300, 'rg'), (383, 'both'), (450, 'rg'), (560, 'both')])
+def test_every_launch_geometry_vs_oracle(N, variant, start):
+    """
+    One solve per launch geometry (64x1, 64x2, 128x2, 192x2, 256x2, 320x2: one to five waves per scenario) against the oracle,
+    from both starting points and for both control sets (both brakes / regenerative brake only, figure10.py:16-22): the
+    stage-parallel KKT solve exchanges data between lanes and waves differently in every one of them.
+    """
+    train = cases.train_default() if variant == 'both' else cases.train_fig10()
+    track = cases.track_00()
+    _compare(_solver(train, track, N, start=start), cases.oracle_problem(train, track, N), [1541.0])
+
+
 def test_velocity_clipping_like_the_reference():
     # initial/terminal speeds are clipped to [vmin, local speed limit] (ocp.py:343-344)
     train, track = cases.train_default(), cases.track_00(crop=20000)
@@ -119,7 +132,10 @@ def test_kkt_certificate_of_gpu_solution():
     nlp = cases.numpy_nlp(prob)
     sc = res['scenarios'][0]
     cert = kkt_certificate(nlp, res['z'][0], res['lam_g'][0], sc[0], sc[1], sc[2], sc[3])
-    assert cert['feas_g'] < 1.5e-8 and cert['feas_z'] < 1.5e-8 and cert['stat'] < 1e-6 and cert['sign_g'] < 1e-6
+    # feasibility: IPOPT's bound relaxation (1e-8 relative).  stat / sign_g are complementarity products of the multipliers the
+    # certificate reconstructs: the solver stops when the scaled optimality error is below 1e-8 and IPOPT's unscaled side
+    # condition compl_inf_tol = 1e-4 holds, so 1e-4 is the bound the stopping rule guarantees (typical values are 1e-6 .. 1e-5)
+    assert cert['feas_g'] < 1.5e-8 and cert['feas_z'] < 1.5e-8 and cert['stat'] < 1e-4 and cert['sign_g'] < 1e-4
 
 
 def test_full_config1_batch_properties():

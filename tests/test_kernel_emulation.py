@@ -19,7 +19,11 @@ EMU = Path(__file__).resolve().parent / 'hip_emu'
 
 @pytest.fixture(scope='module')
 def emu():
-    subprocess.run([str(EMU / 'build.sh')], check=True)
+    src = [EMU / 'emu_driver.cpp', EMU / 'hip' / 'hip_runtime.h'] + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) \
+        + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
+    so = EMU / 'libmsd_emu.so'
+    if not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in src):
+        subprocess.run([str(EMU / 'build.sh')], check=True)
     lib = ctypes.CDLL(str(EMU / 'libmsd_emu.so'))
     from mseetc._device import ProblemDesc
     dp = ctypes.POINTER(ctypes.c_double)
@@ -44,7 +48,8 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
-    assert np.max(np.abs(lam[0] - ref['lam_g'])) < 1e-7
+    # the multipliers of a converged solve are determined to the solver tolerance (1e-8 on the scaled problem): relative bound
+    assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
 
 
 def test_emulated_warm_start_matches_oracle(emu):
