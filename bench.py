@@ -1,5 +1,5 @@
 """
-Benchmark of the hot path: full cold-start solves of a batch of independent train-control OCPs on MI355X.
+Benchmark of the hot path: full solves of a batch of independent train-control OCPs on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -7,26 +7,31 @@ A "step" is one pass of the HIP solver over one batch of synthetic scenarios tha
 Workload = BASELINE.json configs[1]: B = 1024 scenarios per GPU, N = 100 shooting
 intervals, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 with the JSON defaults (both brakes), RK4 with
 numSteps = 1 and trapezoidal time (numApproxSteps = 1), v0 = vN = 1 m/s, T_i = 1541 (1 + 0.15 u_i),
-u = default_rng(20260612 + rank).random(B).  For N > 1 the driver launches one rank per GPU with torch.distributed.run;
-scenarios are independent, so ranks share nothing but the barrier (weak scaling, no collective on the data path).
+u = default_rng(20260612 + rank).random(B).
 
-Prints ONE JSON line on rank 0 (see the field list in the task contract); `roofline` prices the solve kernel with the
-streaming model S of SURVEY.md section 8d (904 B per stage-iteration); `cpu_baseline` times the CPU oracle (a port, not the
-reference's CasADi/IPOPT, which cannot run here) on the host cores.
+Multi-GPU: one process per GPU over torch.distributed (RCCL); scenarios are independent, so the ranks share nothing but the
+barrier and the max over ranks (weak scaling, no collective on the data path).  `python bench.py --gpus N` with N > 1 and no
+RANK in the environment starts the N ranks itself (torch.distributed.run as a child process, before anything touches the GPU);
+under an external launcher (RANK set) it is one of the ranks.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the solve kernel with the streaming model S of SURVEY.md section 8d
+(904 B per stage-iteration); `cpu_baseline` times the CPU oracle (a port, not the reference's CasADi/IPOPT, which cannot run
+here) on the host cores and on one thread; `alt` (N = 1 only) carries the other workloads of SURVEY 8(d): the reference's
+starting point on config 1, config 2, config 3 and config 4 at their per-GPU sizes.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
-
 ROOT = Path(__file__).resolve().parent
 
-for p in (str(ROOT / 'ms-eetc_amd'), str(ROOT), str(ROOT / 'tests')):
+for p in (str(ROOT / 'ms-eetc_amd'), str(ROOT)):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -55,40 +60,175 @@ def usable_cores():
     return n
 
 
-def main():
-
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU')
-    ap.add_argument('--intervals', type=int, default=100)
+    ap.add_argument('--batch', type=int, default=0, help='scenarios per GPU (default: the workload\'s per-GPU size)')
+    ap.add_argument('--intervals', type=int, default=0, help='shooting intervals (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra workloads (reference start, configs 2-4)')
     ap.add_argument('--no-build', action='store_true', help='never compile (profiled runs): exit non-zero when the library is stale')
     ap.add_argument('--start', default='profile', choices=['profile', 'reference'],
                     help="starting point of every solve: 'profile' (library default, built on the device from the scenario) or 'reference' (cold start of ocp.py:325-339)")
-    ap.add_argument('--workload', default='c1', choices=['c1', 'c2'], help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil (extra measurement)')
-    args = ap.parse_args()
+    ap.add_argument('--workload', default='c1', choices=['c1', 'c2', 'c3'],
+                    help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil; c3: config 1 with per-scenario rolling stock')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def rank_command(args_list, gpus, port):
+    "The child process that runs the ranks of a multi-GPU benchmark (torch.distributed.run, one process per GPU)."
+
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), str(Path(__file__).resolve())] + list(args_list)
+
+
+def launch_ranks(args):
+    "Parent of a multi-GPU run: start the ranks as a child process and return its exit code.  Never touches the GPU."
+
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(rank_command(sys.argv[1:], args.gpus, free_port()), env=env)
+
+
+PER_GPU_BATCH = dict(c1=1024, c2=8192, c3=8192)
+
+
+def measure(solver, scen, overrides, steps, warmup, barrier=None):
+    "Timed region: `steps` launches over a batch resident in HBM.  Returns (elapsed s, kernel ms per launch, stats array)."
+
+    import numpy as np
+    from mseetc._device import ST, OV
+
+    prob = solver.problem
+    B = scen.shape[0]
+    d_scen = prob.alloc(scen.nbytes)
+    d_z = prob.alloc(8*prob.nz*B)
+    d_st = prob.alloc(8*ST['COUNT']*B)
+    prob.to_device(d_scen, scen)
+    d_ov = None
+    if overrides is not None:
+        overrides = np.ascontiguousarray(overrides, dtype=np.float64).reshape(B, OV['COUNT'])
+        d_ov = prob.alloc(overrides.nbytes)
+        prob.to_device(d_ov, overrides)
+
+    for _ in range(warmup):
+        prob.solve_batch_device(B, d_scen, d_z, None, d_st, d_overrides=d_ov)
+    prob.synchronize()
+
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    prob.timer_begin()                      # HIP events on the stream the kernel is launched on
+    for _ in range(steps):
+        prob.solve_batch_device(B, d_scen, d_z, None, d_st, d_overrides=d_ov)
+    kernel_ms_total = prob.timer_end()      # waits for the last kernel
+    prob.synchronize()
+    if barrier:
+        barrier(sync_only=True)
+    elapsed = time.perf_counter() - t0
+    if barrier:
+        barrier()
+
+    st = np.zeros((B, ST['COUNT']))
+    prob.to_host(st, d_st)
+    for d in (d_scen, d_z, d_st, d_ov):
+        if d is not None:
+            prob.free(d)
+    return elapsed, kernel_ms_total/steps, st
+
+
+def build_workload(name, B, N, rank, start, device):
+    "(solver, scenarios (B,4), overrides or None, description)"
+
+    from mseetc import workloads as wl
+    from mseetc.ocp import casadiSolver
+
+    train, track, N0 = wl.config(name)
+    N = N or N0
+    solver = casadiSolver(train, track, wl.options(N), device=device, startingPoint=start)
+    overrides = None
+
+    if name == 'c1':
+        T = wl.c1_times(B, seed=20260612 + rank)
+        text = "config 1: B={} scenarios per GPU, N={}, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 (JSON defaults, both brakes), RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1541(1+0.15u_i) seed 20260612+rank".format(B, N)
+    elif name == 'c2':
+        T = wl.c2_times(B, seed=20260613 + rank)
+        text = "config 2: B={} scenarios per GPU, N={}, track CH_StGallen_Wil, train NL_Intercity_VIRM6, RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1242(1+0.15u_i) seed 20260613+rank".format(B, N)
+    else:
+        T, pert = wl.c3_scenarios(B, train, seed=20260614 + rank)
+        overrides = solver._overrides(B, pert['mass'], pert['r0'], pert['r1'], pert['r2'])
+        text = "config 3: B={} scenarios per GPU, N={}, as config 1 (seed 20260614+rank) with mass, r0, r1, r2 perturbed per scenario by 5 % (clipped normal)".format(B, N)
+
+    return solver, solver._scenarios(T, 0, 1, 1), overrides, text
+
+
+def summarize(B, N, steps, elapsed, launch_ms, st):
+    import numpy as np
+    from mseetc._device import ST
+    iters = st[:, ST['ITERS']]
+    return {"solves_per_s": B*steps/elapsed, "launch_ms": launch_ms, "batch": B, "num_intervals": N, "converged": int(np.sum(st[:, ST['STATUS']] >= 0)),
+            "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)),
+            "kkt_fallbacks": int(np.sum(st[:, ST['N_FALLBACK']]))}
+
+
+def hbm_traffic(entry):
+    "Measured HBM bytes per launch of the headline kernel, if the committed measurement belongs to the library that is running."
+
+    tf = ROOT / 'profiles' / 'hbm_traffic.json'
+    if not tf.exists():
+        return None, "no profiles/hbm_traffic.json"
+    try:
+        rec = json.loads(tf.read_text())
+    except Exception:
+        return None, "unreadable profiles/hbm_traffic.json"
+    if rec.get('kernel_digest') != entry.hip_digest():
+        return None, "profiles/hbm_traffic.json was measured on another build of the kernel (digest mismatch): re-run tools/profile_round.sh"
+    return rec.get('bytes_per_launch'), rec.get('source')
+
+
+def main():
+
+    args = parse_args()
 
     # build (or check) the native library before anything touches the GPU: hipcc must never run in a process that has initialised it
     import __graft_entry__ as entry
-    if args.no_build:
-        if entry.stale() and not os.environ.get('MSD_LIB'):       # MSD_LIB: a tuning build (tools/build_variant.py) is being measured
-            raise SystemExit("bench.py --no-build: ms-eetc_amd/lib/libmseetc_hip.so is missing or stale; run `python3 __graft_entry__.py` first")
-    else:
-        entry.build()
 
-    import torch
+    child = 'RANK' in os.environ
+
+    if not child:
+        if args.no_build:
+            if entry.stale() and not os.environ.get('MSD_LIB'):       # MSD_LIB: a tuning build (tools/build_variant.py) is being measured
+                raise SystemExit("bench.py --no-build: ms-eetc_amd/lib/libmseetc_hip.so is missing or stale; run `python3 __graft_entry__.py` first")
+        else:
+            entry.build()
+
+    import torch      # importing torch and counting devices does not initialise the GPU
+
+    ndev = torch.cuda.device_count()
+
+    if ndev < max(1, args.gpus) and not child:
+        print("bench.py: {} HIP device(s) visible, {} requested -- nothing to measure here (the solver has no CPU fallback)".format(ndev, args.gpus), file=sys.stderr)
+        return 0
+
+    if args.gpus > 1 and not child:
+        return launch_ranks(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
 
     if world != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE {}: launch with torch.distributed.run --nproc-per-node {}".format(args.gpus, world, args.gpus))
+        raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    import numpy as np
 
     torch.cuda.set_device(local_rank)
 
@@ -97,58 +237,25 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    import cases
-    from mseetc.ocp import casadiSolver
+    def barrier(sync_only=False):
+        torch.cuda.synchronize()
+        if world > 1 and not sync_only:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     from mseetc._device import ST
 
-    B, N = args.batch, args.intervals
+    B = args.batch or PER_GPU_BATCH[args.workload]
+    solver, scen, overrides, text = build_workload(args.workload, B, args.intervals, rank, args.start, local_rank)
+    N = solver.numIntervals
 
-    if args.workload == 'c2':
-        N = 200 if args.intervals == 100 else args.intervals
-
-    train, track = cases.train_default(), (cases.track_00() if args.workload == 'c1' else cases.track_CH())
-    opts = dict(numIntervals=N, maxIterations=500, integrationOptions=dict(numSteps=1, numApproxSteps=1))
-    solver = casadiSolver(train, track, opts, device=local_rank, startingPoint=args.start)
-    prob = solver.problem
-
-    T = cases.c1_times(B, seed=20260612 + rank) if args.workload == 'c1' else cases.c2_times(B, seed=20260613 + rank)
-    scen = solver._scenarios(T, 0, 1, 1)
-
-    # inputs resident in HBM before the timed region
-    nz = prob.nz
-    d_scen = prob.alloc(scen.nbytes)
-    d_z = prob.alloc(8*nz*B)
-    d_st = prob.alloc(8*ST['COUNT']*B)
-    prob.to_device(d_scen, scen)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        prob.solve_batch_device(B, d_scen, d_z, None, d_st)
-    prob.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    prob.timer_begin()                      # HIP events on the stream the kernel is launched on
-    for _ in range(args.steps):
-        prob.solve_batch_device(B, d_scen, d_z, None, d_st)
-    kernel_ms_total = prob.timer_end()      # waits for the last kernel
-    prob.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    elapsed, launch_ms, st = measure(solver, scen, overrides, args.steps, args.warmup, barrier)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    st = np.zeros((B, ST['COUNT']))
-    prob.to_host(st, d_st)
     n_ok = int(np.sum(st[:, ST['STATUS']] >= 0))
     iters = st[:, ST['ITERS']]
 
@@ -164,17 +271,10 @@ def main():
         total_solves = B*world*args.steps
         value = total_solves/elapsed
 
-        launch_ms = kernel_ms_total/args.steps
         stage_iters = float(N*np.sum(iters))                 # units one launch processes (this rank)
         achieved = BYTES_PER_STAGE_ITER*stage_iters/(launch_ms*1e-3)/1e9
-
-        traffic = None
-        tf = ROOT / 'profiles' / 'hbm_traffic.json'
-        if tf.exists():
-            try:
-                traffic = json.loads(tf.read_text()).get('bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_source = hbm_traffic(entry)
+        geo = solver.problem.geometry()
 
         start_text = ("every solve starts from the device-built speed profile (no information from earlier solves; same optimum as the reference's cold start)"
                       if args.start == 'profile' else "every solve cold-starts from the reference's point (ocp.py:325-339)")
@@ -184,42 +284,109 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("config 1: B={} scenarios per GPU, N={}, track 00_var_speed_limit_100, train NL_Intercity_VIRM6 (JSON defaults, both brakes), "
-                                    "RK4 numSteps=1 numApproxSteps=1, v0=vN=1, T_i=1541(1+0.15u_i) seed 20260612+rank, {}, KKT<=1e-8" if args.workload == 'c1' else
-                                    "config 2 (extra): B={} scenarios per GPU, N={}, track CH_StGallen_Wil, train NL_Intercity_VIRM6, RK4 numSteps=1 numApproxSteps=1, "
-                                    "v0=vN=1, T_i=1242(1+0.15u_i) seed 20260613+rank, {}, KKT<=1e-8").format(B, N, start_text),
+            "config": {"workload": text + ", " + start_text + ", KKT<=1e-8",
                        "batch_per_gpu": B, "num_intervals": N, "start": args.start, "converged": n_ok_all, "scenarios": B*world,
-                       "kkt_cycle_share": float(np.sum(st[:, ST['CYC_KKT']])/max(1.0, np.sum(st[:, ST['CYC_TOTAL']]))), "cycles_per_solve_mean": float(np.mean(st[:, ST['CYC_TOTAL']])),
+                       "kkt_fallbacks": int(np.sum(st[:, ST['N_FALLBACK']])), "cycles_per_solve_mean": float(np.mean(st[:, ST['CYC_TOTAL']])),
                        "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)), "parallelism": "scenarios sharded, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d); iterate is LDS/register resident, so real HBM traffic is far below S",
-                         "kernel": "msd::solve_kernel<64,2,1> (one wave per scenario, two shooting nodes per lane)", "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters},
+                         "kernel": "msd::solve_kernel<{},{}> (one workgroup of {} threads per scenario, {} shooting nodes per lane)".format(geo[0], geo[1], geo[0], geo[1]),
+                         "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters},
         }
 
+        solver.close()
+
+        if world == 1 and not args.no_alt and args.workload == 'c1':
+            line["alt"] = alt_workloads(args, local_rank)
+
         if not args.no_cpu_baseline and world == 1:
-            from oracle import oracle
-            oprob = cases.oracle_problem(train, track, N)
-            ncores = usable_cores()
-            # bounded sample of the same workload, sized from a first pass to about 12 s of wall time on all host cores
-            t1 = time.perf_counter()
-            oracle.solve_batch(oprob, scen, nthreads=ncores, start=args.start)
-            first = time.perf_counter() - t1
-            reps = int(min(64, max(1, np.ceil(12.0/max(first, 1e-3)))))
-            sc = np.tile(scen, (reps, 1))
-            sample = sc.shape[0]
-            t1 = time.perf_counter()
-            zc, stc, nfail = oracle.solve_batch(oprob, sc, nthreads=ncores, start=args.start)
-            dt = time.perf_counter() - t1
-            line["cpu_baseline"] = {"value": sample/dt, "unit": "solves/s", "cores": ncores, "kind": "port",
-                                    "sample": "{} solves (the same batch, repeated), CPU oracle (oracle/ms_oracle.c, same algorithm and starting point, gcc -O2, OpenMP over scenarios), {:.1f} s wall, {} failed".format(sample, dt, nfail)}
+            line["cpu_baseline"] = cpu_baseline(solver, scen, args.start, overrides is not None)
 
         print(json.dumps(line), flush=True)
-
-    prob.free(d_scen); prob.free(d_z); prob.free(d_st)
 
     if world > 1:
         dist.destroy_process_group()
 
+    return 0
+
+
+def alt_workloads(args, device):
+    "The other workloads of SURVEY 8(d) at their per-GPU sizes, a few launches each (N = 1 runs only)."
+
+    import numpy as np
+    from mseetc import workloads as wl
+    from mseetc.mpc import shrinkingHorizon
+
+    alt = {}
+    k = max(3, args.steps//4)
+    solver, scen, ov, text = build_workload('c1', PER_GPU_BATCH['c1'], 0, 0, 'reference', device)
+    e, ms, st = measure(solver, scen, ov, k, 1)
+    alt["reference_start"] = dict(summarize(scen.shape[0], solver.numIntervals, k, e, ms, st), workload=text + ", cold start of ocp.py:325-339")
+    solver.close()
+
+    solver, scen, ov, text = build_workload('c1', 8192, 0, 0, 'profile', device)
+    e, ms, st = measure(solver, scen, ov, 3, 1)
+    alt["c1_batch8192"] = dict(summarize(scen.shape[0], solver.numIntervals, 3, e, ms, st), workload=text)
+    solver.close()
+
+    for name in ('c2', 'c3'):
+        solver, scen, ov, text = build_workload(name, PER_GPU_BATCH[name], 0, 0, 'profile', device)
+        e, ms, st = measure(solver, scen, ov, 3, 1)
+        alt[name] = dict(summarize(scen.shape[0], solver.numIntervals, 3, e, ms, st), workload=text)
+        solver.close()
+
+    # config 4: shrinking-horizon MPC, 512 scenarios per GPU (4096 over 8), 50 re-solves each: wall time of the whole loop
+    train, track, N = wl.config('c4')
+    T = wl.c1_times(512, seed=20260615)
+    shrinkingHorizon(train, track, wl.options(N), T[:64], numResolves=2, noise=0.01, seed=1, device=device)      # warm up
+    c4 = {}
+    for warm in (False, True):
+        t0 = time.perf_counter()
+        log = shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm, device=device)
+        wall = time.perf_counter() - t0
+        n = sum(len(l['status']) for l in log)
+        c4["warm" if warm else "cold"] = {"resolves_per_s": n/wall, "wall_s": wall, "resolves": len(log), "scenarios": 512,
+                                          "ip_iterations_mean": float(np.mean([l['iterations'].mean() for l in log])),
+                                          "failed": int(sum(int((l['status'] < 0).sum()) for l in log))}
+    c4["workload"] = "config 4: 512 scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals, 1 % measurement noise), wall time of the host loop including transfers"
+    alt["c4"] = c4
+    return alt
+
+
+def cpu_baseline(solver, scen, start, with_overrides):
+    "The CPU oracle on the same workload: all usable host cores (bounded sample sized to about 12 s) and one thread."
+
+    import numpy as np
+    from oracle import oracle                      # the checker, timed here as the CPU baseline (kind: port)
+    from mseetc.track import computeDiscretizationPoints
+
+    train, track = solver.train, solver.track
+    N = solver.numIntervals
+    pts = computeDiscretizationPoints(track, N)
+    opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1)
+    oprob = oracle.pack_problem(train, pts, opts, 1, (1 - train.etaTraction)/train.etaTraction, 1 - train.etaRgBrake, track.length)
+
+    ncores = usable_cores()
+    base = scen[:min(len(scen), 1024)]
+    t1 = time.perf_counter()
+    oracle.solve_batch(oprob, base, nthreads=ncores, start=start)
+    first = time.perf_counter() - t1
+    reps = int(min(64, max(1, np.ceil(12.0/max(first, 1e-3)))))
+    sc = np.tile(base, (reps, 1))
+    t1 = time.perf_counter()
+    zc, stc, nfail = oracle.solve_batch(oprob, sc, nthreads=ncores, start=start)
+    dt = time.perf_counter() - t1
+    # single thread: a short sample of the same batch
+    m = min(len(base), 256)
+    t1 = time.perf_counter()
+    oracle.solve_batch(oprob, base[:m], nthreads=1, start=start)
+    dt1 = time.perf_counter() - t1
+    note = " (rolling-stock perturbations of config 3 not applied: nominal train)" if with_overrides else ""
+    return {"value": sc.shape[0]/dt, "unit": "solves/s", "cores": ncores, "kind": "port",
+            "sample": "{} solves (the first {} scenarios of the batch, repeated), CPU oracle (oracle/ms_oracle.c, same algorithm and starting point, gcc -O2, OpenMP over scenarios), {:.1f} s wall, {} failed{}".format(sc.shape[0], len(base), dt, nfail, note),
+            "single_thread": {"value": m/dt1, "unit": "solves/s", "cores": 1, "sample": "{} solves, {:.1f} s".format(m, dt1)}}
+
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

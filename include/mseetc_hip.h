@@ -160,6 +160,11 @@ int msd_solve_batch(msd_handle h, int nscen, const double *scen, double *z_out, 
  * enqueued on the handle's stream; msd_synchronize() waits.  Used to time throughput with inputs in HBM.
  */
 int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats);
+/* ... with per-scenario rolling-stock overrides resident in device memory (d_overrides[nscen][MSD_OV_COUNT], NULL = none) */
+int msd_solve_batch_device_ex(msd_handle h, int nscen, const double *d_scen, const double *d_overrides, double *d_z, double *d_lam, double *d_stats);
+
+/* launch geometry the handle's problem runs with: threads per workgroup (= per scenario) and shooting nodes per thread */
+int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per_thread);
 
 /* msd_solve_batch with per-scenario rolling-stock overrides: overrides[nscen][MSD_OV_COUNT] (host), NULL = none */
 int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats,

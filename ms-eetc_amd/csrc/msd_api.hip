@@ -232,9 +232,21 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
 
 int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats)
 {
+    return msd_solve_batch_device_ex(h, nscen, d_scen, nullptr, d_z, d_lam, d_stats);
+}
+
+int msd_solve_batch_device_ex(msd_handle h, int nscen, const double *d_scen, const double *d_overrides, double *d_z, double *d_lam, double *d_stats)
+{
     if (!h || nscen < 1 || !d_scen || !d_z || !d_stats) return fail(MSD_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    return launch(h, nscen, d_scen, nullptr, d_z, d_lam, d_stats, nullptr, 0);
+    return launch(h, nscen, d_scen, d_overrides, d_z, d_lam, d_stats, nullptr, 0);
+}
+
+int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per_thread)
+{
+    if (!h || !threads_per_scenario || !nodes_per_thread) return fail(MSD_E_INVALID, "bad argument");
+    *threads_per_scenario = h->NT; *nodes_per_thread = h->SPT;
+    return MSD_OK;
 }
 
 int msd_synchronize(msd_handle h)

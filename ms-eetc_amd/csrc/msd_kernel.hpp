@@ -50,9 +50,6 @@
 #ifndef MSD_PROFILE_SKIP_LSQ
 #define MSD_PROFILE_SKIP_LSQ 1      /* profile start begins with zero constraint multipliers: the least-squares estimate costs a KKT solve and buys no iterations there */
 #endif
-#ifndef MSD_FORWARD_CHUNKS
-#define MSD_FORWARD_CHUNKS 32       /* lanes that share the forward sweep of the stage recursion (0: one lane, serial) */
-#endif
 #ifndef MSD_RICCATI_INLINE
 #define MSD_RICCATI_INLINE 1
 #endif
@@ -90,11 +87,6 @@
 #endif
 #ifndef MSD_PARALLEL_RICCATI
 #define MSD_PARALLEL_RICCATI 1      /* stage-parallel KKT solve (scan over the lanes, msd_scan.hpp); 0: serial sweep on one lane */
-#endif
-#if MSD_RICCATI_INLINE
-#define MSD_RICCATI_ATTR __forceinline__
-#else
-#define MSD_RICCATI_ATTR __noinline__
 #endif
 
 namespace msd {
@@ -135,8 +127,7 @@ __host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE
 constexpr int FILT_CAP = 64;
 constexpr int RED_K = 8, RED_SLOTS = 4, MAX_WAVES = 16;
 constexpr int MISC_FALLBACKS = 24;  /* misc[24]: KKT solves of this scenario that fell back from the scan to the serial sweep */
-constexpr int MISC_LG = 16;        /* misc[16..22]: last interval's Fel row for the multiplier of its eliminated b row (forward_chunked) */
-static_assert(12*MSD_FORWARD_CHUNKS + 3*MSD_FORWARD_CHUNKS <= RED_SLOTS*MAX_WAVES*RED_K, "chunk maps live in the reduction scratch");
+constexpr int MISC_LG = 16;        /* misc[16..22]: last interval's Fel row for the multiplier of its eliminated b row */
 constexpr int HIST_COLS = 8;
 constexpr int CONST_DOUBLES = 96, UNI_OFF = 48;    /* LDS copies of the problem record (DevProb) and of the scenario's uniform data (Uni), behind misc */
 
@@ -624,14 +615,12 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &
  * The last interval eliminates df through db_N = 0 (b_N is a parameter of the NLP).
  * Returns false when a pivot is not positive (wrong inertia of the KKT matrix).
  * ---------------------------------------------------------------------------------------- */
-/* lg_out: when not null the forward sweep is left to Solver::forward_chunked and the seven numbers it needs for the multiplier
+/* lg_out: when not null only the backward sweep runs and the seven numbers the forward sweep needs for the multiplier
  * of the last interval's eliminated row are written there */
 template <bool DYN>
-__device__ MSD_RICCATI_ATTR bool riccati_solve(const DevProb &P, double *S, double *lg_out)
+__device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S, double *lg_out)
 {
     constexpr int S_STRIDE = stage_stride(DYN);
-    const int N = P.N;
-    const bool pn = P.withPn != 0;
     /* terminal value function: only t_N is a free variable of the NLP */
     double Ptt = S[N*S_STRIDE + S_HTT], Ptb = 0, Ptq = 0, Pbb = 0, Pbq = 0, Pqq = 0;
     double pt = S[N*S_STRIDE + S_HT], pb = 0, pq = 0;
@@ -1690,87 +1679,6 @@ struct Solver {
     }
 
     /*
-     * Forward sweep of the stage recursion shared by MSD_FORWARD_CHUNKS lanes of the first wave.  The closed loop is affine,
-     * x_{i+1} = A_i x_i + c_i with A_i = Fx + Fu K_i (3x3) and c_i = Fu k_i + r_i, so (1) every lane composes the map of its own
-     * run of consecutive stages, (2) one lane chains the chunk maps to the states at the chunk boundaries, (3) every lane rolls
-     * its stages out from its boundary state -- the same arithmetic per stage as the serial sweep, in 2 N/chunks + chunks steps.
-     */
-    __device__ __forceinline__ void forward_chunked()
-    {
-        constexpr int L = MSD_FORWARD_CHUNKS > 0 ? MSD_FORWARD_CHUNKS : 1;
-        const int N = P.N;
-        const bool pn = P.withPn != 0;
-        if (uni(c.misc[0]) == 0.0) return;            /* wrong inertia: nothing to roll out (uniform) */
-        const int m = (N + L - 1)/L;                   /* stages per chunk */
-        const int lo = c.tid*m, hi = (lo + m < N) ? lo + m : N;
-        const bool mine = c.tid < L && lo < N;
-        double *cm = c.red;                            /* chunk maps: 12 doubles per chunk, then 3 per boundary state */
-        double *xs = c.red + 12*L;
-        if (mine) {
-            double A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, cv[3] = {0, 0, 0};
-            for (int i = lo; i < hi; i++) {
-                const double *s = c.S + i*S_STRIDE;
-                const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
-                const double kt = s[S_K + 0] + (pn ? s[S_K + 3] : 0.0), kb = s[S_K + 1] + (pn ? s[S_K + 4] : 0.0), kq = s[S_K + 2] + (pn ? s[S_K + 5] : 0.0);
-                const double k0 = s[S_KV + 0] + (pn ? s[S_KV + 1] : 0.0);
-                const bool last = i == N - 1;
-                /* rows of A_i: t, b, q */
-                const double a[3][3] = {{1 + Tw*kt, Tb + Tw*kb, Tw*kq},
-                                        {last ? 0.0 : Bw*kt, last ? 0.0 : Bb + Bw*kb, last ? 0.0 : Bw*kq},
-                                        {s[S_K + 0], s[S_K + 1], s[S_K + 2]}};
-                const double ci[3] = {Tw*k0 + rt, last ? 0.0 : Bw*k0 + rb, s[S_KV + 0]};
-                double nA[3][3], nc[3];
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-#pragma unroll
-                    for (int q = 0; q < 3; q++) nA[r][q] = a[r][0]*A[0][q] + a[r][1]*A[1][q] + a[r][2]*A[2][q];
-                    nc[r] = a[r][0]*cv[0] + a[r][1]*cv[1] + a[r][2]*cv[2] + ci[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 3; r++) { cv[r] = nc[r]; for (int q = 0; q < 3; q++) A[r][q] = nA[r][q]; }
-            }
-            double *o = cm + 12*c.tid;
-#pragma unroll
-            for (int r = 0; r < 3; r++) { o[4*r + 0] = A[r][0]; o[4*r + 1] = A[r][1]; o[4*r + 2] = A[r][2]; o[4*r + 3] = cv[r]; }
-        }
-        __syncthreads();
-        if (c.tid == 0) {
-            double x0 = 0, x1 = 0, x2 = 0;            /* x_0 is a parameter of the NLP */
-            for (int l = 0; l < L && l*m < N; l++) {
-                xs[3*l + 0] = x0; xs[3*l + 1] = x1; xs[3*l + 2] = x2;
-                const double *o = cm + 12*l;
-                const double y0 = o[0]*x0 + o[1]*x1 + o[2]*x2 + o[3], y1 = o[4]*x0 + o[5]*x1 + o[6]*x2 + o[7], y2 = o[8]*x0 + o[9]*x1 + o[10]*x2 + o[11];
-                x0 = y0; x1 = y1; x2 = y2;
-            }
-        }
-        __syncthreads();
-        if (mine) {
-            double dt = xs[3*c.tid + 0], db = xs[3*c.tid + 1], dq = xs[3*c.tid + 2];
-            for (int i = lo; i < hi; i++) {
-                double *s = c.S + i*S_STRIDE;
-                const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
-                const double df = s[S_K + 0]*dt + s[S_K + 1]*db + s[S_K + 2]*dq + s[S_KV + 0];
-                const double dp = pn ? s[S_K + 3]*dt + s[S_K + 4]*db + s[S_K + 5]*dq + s[S_KV + 1] : 0.0;
-                const double dw = df + dp;
-                const double nt = dt + Tb*db + Tw*dw + rt;
-                const bool last = i == N - 1;
-                const double nb = last ? 0.0 : Bb*db + Bw*dw + rb;
-                if (last) {
-                    const double *lg = c.misc + MISC_LG;
-                    const double dsl = s[S_KS + 0]*dt + s[S_KS + 1]*db + s[S_KS + 2]*dq + s[S_KS + 3];
-                    s[S_DS] = dsl;
-                    s[S_LB] = (lg[0]*dt + lg[1]*db + lg[2]*dq + lg[3]*df + lg[4]*dp + lg[5]*dsl + lg[6])/Bw;
-                    double *sN = c.S + N*S_STRIDE;
-                    sN[S_DT] = nt; sN[S_DB] = 0.0; sN[S_DF] = 0.0;
-                }
-                s[S_DT] = dt; s[S_DB] = db; s[S_DF] = df; s[S_DP] = dp;
-                dt = nt; db = nb; dq = df;
-            }
-        }
-        __syncthreads();
-    }
-
-    /*
      * What the serial sweeps leave to the nodes: the step of the slack variable s (eliminated in assemble()) and the new
      * multipliers of the dynamics, lam+ = -(P+ x+ + p+ + E^T y), from the value function stashed in the node's own block and
      * the step of the next node.  The last interval's ds and lam_b come from the sweep itself.
@@ -1822,14 +1730,13 @@ struct Solver {
             if (c.tid == 0) c.misc[MISC_FALLBACKS] += 1.0;
         }
 #endif
-        if (par < 0) {
+        if (par < 0) {       /* serial sweeps on one lane: the fallback of the scan (cold) or, with MSD_PARALLEL_RICCATI = 0, the only path */
             if (c.tid == 0) {
                 const unsigned long long t0 = __builtin_readcyclecounter();
-                c.misc[0] = riccati_solve<DYN>(P, c.S, MSD_FORWARD_CHUNKS ? c.misc + MISC_LG : nullptr) ? 1.0 : 0.0;
+                c.misc[0] = riccati_solve<DYN>(P.N, P.withPn != 0, c.S, nullptr) ? 1.0 : 0.0;
                 c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
             }
             __syncthreads();
-            if (MSD_FORWARD_CHUNKS) forward_chunked();
         }
         c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
         const bool ok = (par >= 0) ? (par == 1) : (uni(c.misc[0]) != 0.0);

@@ -78,6 +78,8 @@ def lib():
         L.msd_interval_integrate.argtypes = [ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, _dptr, ctypes.c_int] + [_dptr]*8 + [ctypes.POINTER(ctypes.c_int)]
         L.msd_interval_last_error.restype = ctypes.c_char_p
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
+        L.msd_solve_batch_device_ex.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
+        L.msd_problem_geometry.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.msd_synchronize.argtypes = [vp]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
         L.msd_device_free.argtypes = [vp, vp]
@@ -230,8 +232,14 @@ class DeviceProblem():
     def to_host(self, arr, dptr):
         _check(lib().msd_copy_to_host(self._h, arr.ctypes.data_as(ctypes.c_void_p), dptr, arr.nbytes))
 
-    def solve_batch_device(self, B, d_scen, d_z, d_lam, d_stats):
-        _check(lib().msd_solve_batch_device(self._h, int(B), d_scen, d_z, d_lam, d_stats))
+    def solve_batch_device(self, B, d_scen, d_z, d_lam, d_stats, d_overrides=None):
+        _check(lib().msd_solve_batch_device_ex(self._h, int(B), d_scen, d_overrides, d_z, d_lam, d_stats))
+
+    def geometry(self):
+        "(threads per scenario, shooting nodes per thread) of the launch"
+        nt, spt = ctypes.c_int(0), ctypes.c_int(0)
+        _check(lib().msd_problem_geometry(self._h, ctypes.byref(nt), ctypes.byref(spt)))
+        return nt.value, spt.value
 
     def synchronize(self):
         _check(lib().msd_synchronize(self._h))

@@ -166,6 +166,7 @@ class casadiSolver():
         self.withRgBrake = withRgBrake
         self.withPnBrake = withPnBrake
         self.train = train
+        self.track = track
         self.energyOptimal = opts.energyOptimal
         self.scalingFactorObjective = scaling
         self.opts = opts

@@ -17,8 +17,7 @@ CONFIG_JSON = dict(maxIterations=500, numIntervals=300, integrationMethod='RK',
                    integrationOptions=dict(order=4, numSteps=1, numApproxSteps=1))   # simulations/config.json
 
 
-def train_default():
-    return Train(config={'id': 'NL_Intercity_VIRM6'})
+from mseetc.workloads import train_default, track_00, track_CH, c1_times, c2_times      # the benchmark's definitions
 
 
 def train_fig10():
@@ -46,17 +45,6 @@ def train_fig5():
     return train
 
 
-def track_00(crop=None):
-    track = Track(config={'id': '00_var_speed_limit_100'})
-    if crop is not None:
-        track.updateLimits(positionEnd=crop)
-    return track
-
-
-def track_CH():
-    return Track(config={'id': 'CH_StGallen_Wil'})
-
-
 def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1):
     pts = computeDiscretizationPoints(track, N)
     opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal, minimumVelocity=vmin,
@@ -78,10 +66,3 @@ def numpy_nlp(prob):
                          ct=dp[DP['LOSS_CT']], cr=dp[DP['LOSS_CR']], vminSq=dp[DP['VMIN_SQ']], objDen=dp[DP['OBJ_DEN']], bmax=prob.bmax)
 
 
-def c1_times(B, seed=20260612):
-    "Config 1 running times (SURVEY.md section 8d): T_i = 1541 (1 + 0.15 u_i)"
-    return 1541*(1 + 0.15*np.random.default_rng(seed).random(B))
-
-
-def c2_times(B, seed=20260613):
-    return 1242*(1 + 0.15*np.random.default_rng(seed).random(B))

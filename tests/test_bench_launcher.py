@@ -1,0 +1,67 @@
+"""
+bench.py's launch logic on a machine without a GPU: `--gpus N` never fails on WORLD_SIZE, it reports that there is no device;
+the command it would start the ranks with is the torch.distributed.run line the driver uses; and that launcher really runs
+the given script as N ranks over 127.0.0.1 (checked with a gloo group on CPU).
+"""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import bench      # noqa: E402
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize('gpus', [1, 2, 8])
+def test_no_device_is_reported_not_raised(gpus):
+    import torch
+    if torch.cuda.device_count() >= gpus:
+        pytest.skip("this machine has the devices")
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(gpus), '--no-build'], capture_output=True, text=True, env=_clean_env(), timeout=600)
+    # --no-build exits with a message of its own when the library is stale: both are clean, explicit exits
+    assert r.returncode == 0 or 'stale' in r.stderr, r.stderr
+    assert 'WORLD_SIZE' not in r.stderr
+    if r.returncode == 0:
+        assert 'HIP device' in r.stderr and r.stdout.strip() == ''
+
+
+def test_rank_command_is_the_drivers_launch_line():
+    cmd = bench.rank_command(['--gpus', '4', '--steps', '5'], 4, 29511)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29511'
+    assert cmd[-5].endswith('bench.py') and cmd[-4:] == ['--gpus', '4', '--steps', '5']
+
+
+def test_launcher_runs_the_ranks(tmp_path):
+    "The same launcher line with a stand-in script: two ranks form a gloo group, reduce MAX like bench.py's timing, rank 0 prints one JSON line."
+    script = tmp_path / 'ranks.py'
+    script.write_text(
+        "import json, os, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "t = torch.tensor([1.0 + r], dtype=torch.float64)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "n = torch.tensor([10 + r]); dist.all_reduce(n, op=dist.ReduceOp.SUM)\n"
+        "dist.barrier()\n"
+        "if r == 0: print(json.dumps({'world': w, 'max': float(t.item()), 'sum': int(n.item())}), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    cmd = bench.rank_command([], 2, bench.free_port())
+    cmd[cmd.index(str(ROOT / 'bench.py'))] = str(script)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_clean_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    assert json.loads(line) == {'world': 2, 'max': 2.0, 'sum': 21}

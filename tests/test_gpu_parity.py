@@ -62,6 +62,93 @@ def test_stage_eval_matches_oracle():
         assert np.allclose(out[k], ref, rtol=1e-12, atol=1e-15)
 
 
+def test_stage_eval_independent_of_the_oracle_source():
+    """
+    The device's interval map checked WITHOUT the oracle (whose stage functions share their derivation with the kernel's):
+    values against the numpy restatement of tests/nlp_numpy.py, first derivatives against complex-step differentiation of
+    that restatement, second derivatives against central differences of the device's own first derivatives, and the
+    integrated ODE against scipy's DOP853 on the figure-4 braking cases (simulations/figure4.py:22-23: 100 m of braking
+    with f = -0.5 N/kg end at 1 and 10 km/h) with the reference's high-resolution setting numSteps = 50.
+    """
+    from scipy.integrate import solve_ivp
+    from oracle.oracle import DP
+    for numSteps, numApprox in ((1, 1), (2, 2), (2, 0)):
+        solver = _solver(cases.train_default(), cases.track_00(), 100, numSteps=numSteps, numApproxSteps=numApprox)
+        nlp = cases.numpy_nlp(cases.oracle_problem(cases.train_default(), cases.track_00(), 100, numSteps=numSteps, numApproxSteps=numApprox))
+        rng = np.random.default_rng(17)
+        n = 64
+        b, w, ds = rng.uniform(300, 1500, n), rng.uniform(-0.4, 0.5, n), rng.uniform(5, 300, n)
+        grad, curv = rng.uniform(-0.015, 0.015, n), rng.uniform(-1/320, 1/320, n)
+        out = solver.problem.stage_eval(b, w, ds, grad, curv)
+        c = np.abs(curv)
+        crv = np.where(c <= 1/300, nlp.g*0.5*c/(1 - 30*c), nlp.g*0.65*c/(1 - 55*c))           # train.py:252-253
+        nlp.ds, nlp.G = ds, nlp.g*grad/nlp.rho + crv/nlp.rho
+        tau, bp = nlp.interval(b, w)
+        assert np.allclose(out[:, 0], tau, rtol=1e-12, atol=0) and np.allclose(out[:, 1], bp, rtol=1e-12, atol=0)
+        h = 1e-30
+        tb, bb = nlp.interval(b + 1j*h, w + 0j)
+        tw, bw = nlp.interval(b + 0j, w + 1j*h)
+        for col, ref in ((2, tb.imag/h), (3, tw.imag/h), (4, bb.imag/h), (5, bw.imag/h)):
+            assert np.all(np.abs(out[:, col] - ref) <= 1e-10*np.maximum(1e-6, np.abs(ref)))
+        e = 1e-5
+        up, dn = solver.problem.stage_eval(b*(1 + e), w, ds, grad, curv), solver.problem.stage_eval(b*(1 - e), w, ds, grad, curv)
+        uw, dw = solver.problem.stage_eval(b, w + e, ds, grad, curv), solver.problem.stage_eval(b, w - e, ds, grad, curv)
+        db, dww = (up[:, 2:6] - dn[:, 2:6])/(2*e*b[:, None]), (uw[:, 2:6] - dw[:, 2:6])/(2*e)
+        # columns: 6 tau_bb 7 tau_bw 8 tau_ww 9 b+_bb 10 b+_bw 11 b+_ww
+        for col, ref in ((6, db[:, 0]), (7, dww[:, 0]), (7, db[:, 1]), (8, dww[:, 1]), (9, db[:, 2]), (10, dww[:, 2]), (10, db[:, 3]), (11, dww[:, 3])):
+            # (differences of first derivatives that carry the 1-2 ulp of the device's division: absolute floor 5e-9)
+            assert np.all(np.abs(out[:, col] - ref) <= 2e-4*np.abs(ref) + 5e-9)
+    # figure 4: 100 pieces of 1 m with the joint RK4 (numSteps = 50, numApproxSteps = 0) against the ODE itself
+    solver = _solver(cases.train_default(), cases.track_00(), 100, numSteps=50, numApproxSteps=0)
+    prob = cases.oracle_problem(cases.train_default(), cases.track_00(), 100)
+    dp = prob.dp
+    for v0kmh, expect in ((36.61894, 1.0), (37.95880, 10.0)):
+        bcur, tcur = (v0kmh/3.6)**2, 0.0
+        for _ in range(100):
+            o = solver.problem.stage_eval([bcur], [-0.5], [1.0], [0.0], [0.0])[0]
+            tcur, bcur = tcur + o[0], o[1]
+        assert abs(np.sqrt(bcur)*3.6 - expect) < 2e-3
+        rhs = lambda s_, y: [1/np.sqrt(y[1]), 2*(-0.5 - (dp[DP['SR0']] + dp[DP['SR1']]*np.sqrt(y[1]) + dp[DP['SR2']]*y[1]))]
+        sol = solve_ivp(rhs, [0, 100.0], [0.0, (v0kmh/3.6)**2], rtol=1e-13, atol=1e-13, method='DOP853')
+        assert abs(bcur - sol.y[1, -1]) < 1e-8*max(1, sol.y[1, -1]) and abs(tcur - sol.y[0, -1]) < 1e-6*sol.y[0, -1]
+
+
+@pytest.mark.parametrize('name,B', [('c1', 1024), ('c2', 8192)])
+def test_full_batches_both_starts_same_optimum(name, B):
+    """
+    The library's default starting point (device-built profile) against the reference's cold start (ocp.py:325-339) on the FULL
+    batches of BASELINE configs 1 and 2: every scenario converges from both, to the same optimum (objective within 1e-8
+    relative for 99.9 % of the scenarios and within 1e-6 for all: both solves stop at a scaled KKT error of 1e-8, which pins the
+    objective of a flat problem to about 1e-7), terminal constraints hold; and a random sample of 256 scenarios of each batch
+    agrees with the oracle solving the same NLPs.
+    """
+    from mseetc import workloads as wl
+    from oracle import oracle
+    train, track, N = wl.config(name)
+    T = wl.c1_times(B) if name == 'c1' else wl.c2_times(B)
+    res = {}
+    for start in ('profile', 'reference'):
+        s = _solver(train, track, N, start=start)
+        res[start] = s.solveBatch(T)
+        assert np.all(res[start]['status'] == 0), (start, np.flatnonzero(res[start]['status'] != 0)[:10])
+        z = res[start]['z']
+        assert np.all(z[:, -1] == 1.0) and np.all(z[:, -2] <= T*(1 + 1.01e-8))
+        s.close()
+    cp, cr = res['profile']['cost'], res['reference']['cost']
+    rel = np.abs(cp - cr)/np.abs(cr)
+    assert rel.max() <= 1e-6 and np.quantile(rel, 0.999) <= 1e-8, (rel.max(), int(np.argmax(rel)), np.quantile(rel, 0.999))
+    assert np.max(np.abs(res['profile']['z'] - res['reference']['z'])/np.maximum(1.0, np.abs(res['reference']['z']))) <= 1e-5
+    assert res['profile']['iterations'].mean() < 0.6*res['reference']['iterations'].mean()
+    prob = cases.oracle_problem(train, track, N)
+    pick = np.random.default_rng(99).choice(B, 256, replace=False)
+    scen = np.stack([np.zeros(256), T[pick], np.ones(256), np.ones(256)], axis=1)
+    zo, sto, nfail = oracle.solve_batch(prob, scen, nthreads=0, start='profile')
+    assert nfail == 0
+    from oracle.oracle import ST as OST
+    assert np.max(np.abs(cp[pick] - sto[:, OST['OBJ']])/np.abs(sto[:, OST['OBJ']])) <= OBJ_RTOL
+    assert np.max(np.abs(res['profile']['z'][pick] - zo)/np.maximum(1.0, np.abs(zo))) <= 10*Z_RTOL      # 128 000 variables: the tail of the 1e-6 the small batches meet
+
+
 def test_config1_small_batch_vs_oracle():
     # BASELINE config 1 shape (N=100, VIRM6 defaults, both brakes), first 16 of the seeded running times
     train, track = cases.train_default(), cases.track_00()
