@@ -38,13 +38,16 @@ extern "C" {
 #define MSD_STATUS_REGULARIZATION (-3)
 #define MSD_STATUS_NUMERIC (-4)
 #define MSD_STATUS_TINY_STEP (-5)
+/* set by the host layer only (mseetc/ocp.py: _classify_failures), from the minimum-running-time certificate of a failed scenario:
+ * IPOPT's 'Infeasible_Problem_Detected' */
+#define MSD_STATUS_INFEASIBLE (-6)
 
 /*
  * Starting point of a solve.  REFERENCE: the reference's cold start (ocp.py:325-339: Fel 0.5, Fpb -0.1, s 1, t linear,
  * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
- * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the iterations, and a
- * scenario that breaks down from it (any failure
- * but the iteration limit) is solved again from the reference's point inside the same launch.
+ * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the
+ * iterations.  A scenario that breaks down from its starting point (any failure but the iteration limit) is solved again from the
+ * other one inside the same launch: where IPOPT would enter its restoration phase, the solver restarts.
  */
 #define MSD_START_REFERENCE 0
 #define MSD_START_PROFILE 1
@@ -81,6 +84,7 @@ enum {
     MSD_OV_F_MAX, MSD_OV_F_MIN, MSD_OV_F_MIN_PN,
     MSD_OV_PW_UPPER, MSD_OV_PW_LOWER,
     MSD_OV_OBJ_DEN,
+    MSD_OV_TOTAL_MASS,   /* mass * rho [kg]: what the dynamic loss model turns specific forces into newtons with (efficiency.py:108); 0 = the problem's */
     MSD_OV_COUNT
 };
 
@@ -181,7 +185,26 @@ int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double
  */
 int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init,
                          double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms);
+/*
+ * Warm start from the handle's own previous solve, kept on the device: the batch that msd_solve_batch* solved last on this handle
+ * (same scenarios in the same order), `shift_intervals` intervals further down the horizon -- the shrinking-horizon re-solve of
+ * BASELINE config 4, where the new grid is the tail of the old one (Track.updateLimits(positionStart), track.py:420-450, then
+ * msd_problem_reconfigure with num_intervals smaller by shift_intervals).  The guess of a scenario is the tail of its stored z;
+ * nothing is uploaded.  A scenario whose previous solve failed, or whose warm-started solve breaks down, is solved from the
+ * problem's own starting point inside the same launch.
+ */
+int msd_solve_batch_shifted(msd_handle h, int nscen, const double *scen, const double *overrides, int shift_intervals, double mu_init,
+                            double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms);
 int msd_synchronize(msd_handle h);
+
+/*
+ * The same batch over several handles -- one per device, created from the same msd_problem_desc (`devices[]`;
+ * 8e: one stream per device from a single process).  Handle k solves the contiguous slice [k nscen / n, (k + 1) nscen / n);
+ * every slice is enqueued on its device before any is waited for; no data moves between devices.  kernel_ms receives the
+ * longest of the per-device kernel times.  Buffers are host buffers laid out as for msd_solve_batch_warm (z_guess may be NULL).
+ */
+int msd_solve_batch_multi(const msd_handle *handles, int nhandles, int nscen, const double *scen, const double *overrides, const double *z_guess,
+                          double mu_init, double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms);
 
 /*
  * The other two interval integrators of TrainIntegrator (mseetc/train.py:303-322) for n independent intervals -- what

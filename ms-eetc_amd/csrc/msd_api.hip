@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "msd_kernel.hpp"
@@ -49,6 +50,9 @@ struct msd_problem {
     int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
     /* grow-only scratch of the host-buffer entry point */
     double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
+    /* second result buffers: a solve that warm-starts from the previous solve of the handle reads one pair while it writes the other */
+    double *d_z2 = nullptr, *d_stats2 = nullptr;
+    int prev_nscen = 0, prev_nz = 0, prev_stp = 0;      /* what d_z / d_stats hold (prev_nscen = 0: nothing) */
     int cap_scen = 0, cap_guess = 0;
     double *h_hist = nullptr;
     int hist_cap = 0;
@@ -107,11 +111,17 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
 {
     const int N = d->num_intervals;
     const msd::Geometry geo = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
-    if (!geo.fn) return fail(MSD_E_UNSUPPORTED, "numIntervals > 639 is not supported by the LDS-resident kernel");
-    const size_t lds = sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2);
-    if (lds > 160*1024) return fail(MSD_E_UNSUPPORTED, "problem does not fit the 160 KB of LDS of a compute unit");
+    int nmax = 0;      /* largest horizon whose stage blocks fit the 160 KB of LDS of a compute unit with the widest geometry */
+    for (int n = 1; n < 640; n++) {
+        const msd::Geometry g = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(n) : msd::pick_geometry_static(n);
+        if (g.fn && sizeof(double)*(size_t)msd::lds_doubles(n, g.NT*g.SPT, d->loss_kind == 2) <= 160*1024) nmax = n;
+    }
+    const size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2) : 0;
+    if (!geo.fn || lds > 160*1024)
+        return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " does not fit the LDS-resident kernel (limit for this loss model: " + std::to_string(nmax) + ")");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));      /* nothing of the previous problem may still be running */
+    h->kernel = nullptr;                           /* the handle holds no problem until every step below has succeeded (launch() checks) */
 
     /* ds | grad | curv | bmax | pos in one buffer */
     if (N > h->cap_N) {
@@ -137,14 +147,14 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         HIP_TRY(hipMemcpy(h->d_loss, d->loss_table, sizeof(double)*d->loss_table_len, hipMemcpyHostToDevice));
     }
 
-    h->NT = geo.NT; h->SPT = geo.SPT; h->lds_bytes = lds; h->kernel = geo.fn;
+    h->NT = geo.NT; h->SPT = geo.SPT; h->lds_bytes = lds;
     msd::DevProb &P = h->P;
     P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0;
     P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
 
@@ -165,10 +175,12 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     /* the scenario buffers are sized by nz: a different layout invalidates them */
     const int nz = (4 + P.withPn)*N + 2, nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
     if (nz > h->cap_nz || nl > h->cap_nl) {
-        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_guess);
-        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = h->d_guess = nullptr; h->cap_scen = 0; h->cap_guess = 0;
+        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_guess); hipFree(h->d_z2); hipFree(h->d_stats2);
+        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = h->d_guess = h->d_z2 = h->d_stats2 = nullptr; h->cap_scen = 0; h->cap_guess = 0;
+        h->prev_nscen = 0;
         h->cap_nz = nz; h->cap_nl = nl;
     }
+    h->kernel = geo.fn;
     return MSD_OK;
 }
 
@@ -207,6 +219,7 @@ int msd_problem_destroy(msd_handle h)
     hipSetDevice(h->device);
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
+    hipFree(h->d_z2); hipFree(h->d_stats2);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -217,14 +230,15 @@ int msd_problem_destroy(msd_handle h)
 int msd_problem_nz(msd_handle h) { return h ? (4 + h->P.withPn)*h->P.N + 2 : 0; }
 int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 : 0) + 3 + (h->P.energyOpt ? 2 : 0) : 0; }
 
-struct WarmStart { const double *d_guess = nullptr; double mu = 0, push = 0; };
+struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0; };
 
 static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
                   const WarmStart &ws = WarmStart())
 {
+    if (!h->kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
     const int grid = nscen < h->max_grid ? nscen : h->max_grid;
     msd::DevProb P = h->P;
-    P.guess = ws.d_guess; P.warmMu = ws.mu; P.warmPush = ws.push;
+    P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
     hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, h->d_work);
     HIP_TRY(hipGetLastError());
     return MSD_OK;
@@ -274,8 +288,9 @@ int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double
     return msd_solve_batch_warm(h, nscen, scen, overrides, nullptr, 0.0, 0.0, z_out, lam_out, stats, kernel_ms);
 }
 
-int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
-                         double *z_out, double *lam_out, double *stats, float *kernel_ms)
+/* argument checks of the host-buffer entry points */
+static int check_batch(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
+                       const double *z_out, const double *stats)
 {
     if (!h || nscen < 1 || !scen || !z_out || !stats) return fail(MSD_E_INVALID, "bad argument");
     if (z_guess && (!(mu_init > 0) || !(mu_init <= 1e3) || !(bound_push > 0) || !(bound_push <= 0.5)))
@@ -283,7 +298,8 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
     if (overrides)
         for (int k = 0; k < nscen; k++) {
             const double *o = overrides + (size_t)MSD_OV_COUNT*k;
-            if (!(o[MSD_OV_OBJ_DEN] > 0) || !(o[MSD_OV_F_MAX] > o[MSD_OV_F_MIN]) || !(o[MSD_OV_SR0] >= 0) || !(o[MSD_OV_SR1] >= 0) || !(o[MSD_OV_SR2] >= 0))
+            if (!(o[MSD_OV_OBJ_DEN] > 0) || !(o[MSD_OV_F_MAX] > o[MSD_OV_F_MIN]) || !(o[MSD_OV_SR0] >= 0) || !(o[MSD_OV_SR1] >= 0) || !(o[MSD_OV_SR2] >= 0) ||
+                !(o[MSD_OV_TOTAL_MASS] >= 0))
                 return fail(MSD_E_INVALID, "invalid rolling-stock override");
         }
     for (int k = 0; k < nscen; k++) {
@@ -292,11 +308,25 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
         if (!(s[MSD_SC_TEND] > 0)) return fail(MSD_E_INVALID, "Terminal time must be a strictly positive number!");
         if (!(s[MSD_SC_V0SQ] > 0) || !(s[MSD_SC_VNSQ] > 0)) return fail(MSD_E_INVALID, "velocities must be positive");
     }
+    if (z_guess) {
+        const size_t nz = msd_problem_nz(h);
+        for (size_t k = 0; k < nz*(size_t)nscen; k++)
+            if (!std::isfinite(z_guess[k])) return fail(MSD_E_INVALID, "warm start guess must be finite");
+    }
+    return MSD_OK;
+}
+
+/* uploads, launch and downloads of one batch on the handle's stream, nothing waited for: finish_batch() completes it */
+static int enqueue_batch(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
+                         double *z_out, double *lam_out, double *stats, int shift = -1)
+{
     HIP_TRY(hipSetDevice(h->device));
     const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
     if (nscen > h->cap_scen) {
-        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats);
-        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = nullptr; h->cap_scen = 0;
+        hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_z2); hipFree(h->d_stats2);
+        h->d_scen = h->d_ovr = h->d_z = h->d_lam = h->d_stats = h->d_z2 = h->d_stats2 = nullptr; h->cap_scen = 0; h->prev_nscen = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_z2, sizeof(double)*(size_t)h->cap_nz*nscen));
+        HIP_TRY(hipMalloc((void **)&h->d_stats2, sizeof(double)*MSD_ST_COUNT*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_scen, sizeof(double)*MSD_SC_COUNT*nscen));
         HIP_TRY(hipMalloc((void **)&h->d_ovr, sizeof(double)*MSD_OV_COUNT*nscen));
         /* sized for the largest layout this handle has been configured for (msd_problem_reconfigure) */
@@ -313,9 +343,16 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
         d_hist = h->d_hist;
     }
     WarmStart ws;
+    ws.stride = (long long)nz;
+    if (shift >= 0) {
+        /* guesses = the previous solutions of this handle, `shift` intervals down the horizon: a tail of each stored z */
+        const int stp = 4 + h->P.withPn;
+        if (h->prev_nscen != nscen || h->prev_stp != stp || h->prev_nz - stp*shift != (int)nz)
+            return fail(MSD_E_INVALID, "no previous solve of this handle matches the shifted warm start (same batch, horizon longer by `shift` intervals)");
+        ws.d_guess = h->d_z + (size_t)stp*shift; ws.stride = h->prev_nz; ws.d_status = h->d_stats; ws.mu = mu_init; ws.push = bound_push;
+        std::swap(h->d_z, h->d_z2); std::swap(h->d_stats, h->d_stats2);       /* results go to the other pair */
+    }
     if (z_guess) {
-        for (size_t k = 0; k < nz*(size_t)nscen; k++)
-            if (!std::isfinite(z_guess[k])) return fail(MSD_E_INVALID, "warm start guess must be finite");
         if (nscen > h->cap_guess) {
             hipFree(h->d_guess); h->d_guess = nullptr; h->cap_guess = 0;
             HIP_TRY(hipMalloc((void **)&h->d_guess, sizeof(double)*(size_t)h->cap_nz*nscen));
@@ -334,8 +371,83 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
     if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
     if (d_hist) HIP_TRY(hipMemcpyAsync(h->h_hist, d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
+    h->prev_nscen = nscen; h->prev_nz = (int)nz; h->prev_stp = 4 + h->P.withPn;
+    return MSD_OK;
+}
+
+static int finish_batch(msd_handle h, float *kernel_ms)
+{
+    HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    return MSD_OK;
+}
+
+int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
+                         double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
+    int rc = check_batch(h, nscen, scen, overrides, z_guess, mu_init, bound_push, z_out, stats);
+    if (rc != MSD_OK) return rc;
+    rc = enqueue_batch(h, nscen, scen, overrides, z_guess, mu_init, bound_push, z_out, lam_out, stats);
+    if (rc != MSD_OK) return rc;
+    return finish_batch(h, kernel_ms);
+}
+
+int msd_solve_batch_shifted(msd_handle h, int nscen, const double *scen, const double *overrides, int shift_intervals, double mu_init, double bound_push,
+                            double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
+    if (shift_intervals < 0) return fail(MSD_E_INVALID, "shift_intervals must not be negative");
+    int rc = check_batch(h, nscen, scen, overrides, nullptr, mu_init, bound_push, z_out, stats);
+    if (rc != MSD_OK) return rc;
+    if (!(mu_init > 0) || !(mu_init <= 1e3) || !(bound_push > 0) || !(bound_push <= 0.5))
+        return fail(MSD_E_INVALID, "warm start needs 0 < mu_init <= 1e3 and 0 < bound_push <= 0.5");
+    rc = enqueue_batch(h, nscen, scen, overrides, nullptr, mu_init, bound_push, z_out, lam_out, stats, shift_intervals);
+    if (rc != MSD_OK) return rc;
+    return finish_batch(h, kernel_ms);
+}
+
+/*
+ * One batch over several handles (one per device, SURVEY 8b/8e: single process, one stream per device): handle k solves the
+ * contiguous slice [k nscen / n, (k + 1) nscen / n) of the scenarios; all slices are enqueued before any is waited for.
+ */
+int msd_solve_batch_multi(const msd_handle *handles, int nhandles, int nscen, const double *scen, const double *overrides, const double *z_guess,
+                          double mu_init, double bound_push, double *z_out, double *lam_out, double *stats, float *kernel_ms)
+{
+    if (!handles || nhandles < 1 || nscen < 1) return fail(MSD_E_INVALID, "bad argument");
+    for (int k = 0; k < nhandles; k++) {
+        if (!handles[k]) return fail(MSD_E_INVALID, "null handle");
+        if (msd_problem_nz(handles[k]) != msd_problem_nz(handles[0]) || handles[k]->P.N != handles[0]->P.N ||
+            msd_problem_rows_per_interval(handles[k]) != msd_problem_rows_per_interval(handles[0]))
+            return fail(MSD_E_INVALID, "the handles of a multi-device solve must hold the same problem");
+        for (int j = 0; j < k; j++)
+            if (handles[j] == handles[k]) return fail(MSD_E_INVALID, "a handle appears twice");
+    }
+    int rc = check_batch(handles[0], nscen, scen, overrides, z_guess, mu_init, bound_push, z_out, stats);
+    if (rc != MSD_OK) return rc;
+    const size_t nz = msd_problem_nz(handles[0]), nl = (size_t)msd_problem_rows_per_interval(handles[0])*handles[0]->P.N;
+    std::vector<int> lo(nhandles + 1);
+    for (int k = 0; k <= nhandles; k++) lo[k] = (int)(((long long)nscen*k)/nhandles);
+    int first_error = MSD_OK;
+    std::string first_msg;
+    std::vector<char> started(nhandles, 0);
+    for (int k = 0; k < nhandles && first_error == MSD_OK; k++) {
+        const int n = lo[k + 1] - lo[k];
+        if (n < 1) continue;
+        rc = enqueue_batch(handles[k], n, scen + (size_t)MSD_SC_COUNT*lo[k], overrides ? overrides + (size_t)MSD_OV_COUNT*lo[k] : nullptr,
+                           z_guess ? z_guess + nz*lo[k] : nullptr, mu_init, bound_push, z_out + nz*lo[k], lam_out ? lam_out + nl*lo[k] : nullptr,
+                           stats + (size_t)MSD_ST_COUNT*lo[k]);
+        if (rc != MSD_OK) { first_error = rc; first_msg = g_err; } else started[k] = 1;
+    }
+    float worst = 0;
+    for (int k = 0; k < nhandles; k++) {
+        if (!started[k]) continue;
+        float ms = 0;
+        rc = finish_batch(handles[k], &ms);
+        if (rc != MSD_OK && first_error == MSD_OK) { first_error = rc; first_msg = g_err; }
+        if (ms > worst) worst = ms;
+    }
+    if (first_error != MSD_OK) { g_err = first_msg; return first_error; }
+    if (kernel_ms) *kernel_ms = worst;
     return MSD_OK;
 }
 

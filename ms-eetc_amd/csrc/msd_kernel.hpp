@@ -100,7 +100,10 @@ struct DevProb {
     int start;               /* MSD_START_REFERENCE: cold start of ocp.py:325-339; MSD_START_PROFILE: profile start */
     /* primal warm start (set per launch by msd_solve_batch_warm, null = none) */
     const double *guess;
+    long long guessStride;   /* doubles between the guesses of consecutive scenarios (nz, or the layout of the previous, longer horizon) */
+    const double *guessStatus;   /* not null: stats records of the solves the guesses come from; a scenario whose record says "failed" starts cold */
     double warmMu, warmPush;
+    double lossMass;         /* per-scenario override of the total mass in the dynamic loss model (0: the table's) */
 };
 
 /* IPOPT default option values */
@@ -242,8 +245,8 @@ struct DynLoss {
     double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
     int nx, ny;
     const double *xb, *yb, *coef;
-    __device__ __forceinline__ explicit DynLoss(const double *b)
-        : Fmax(b[0]), Pmax(b[1]), vTurn(b[2]), vMin(b[3]), vMax(b[4]), aux(b[5]), cgT(b[6]), cgB(b[7]), R(b[8]), V(b[9]), M(b[10]),
+    __device__ __forceinline__ DynLoss(const double *b, const double massOverride)
+        : Fmax(b[0]), Pmax(b[1]), vTurn(b[2]), vMin(b[3]), vMax(b[4]), aux(b[5]), cgT(b[6]), cgB(b[7]), R(b[8]), V(b[9]), M(massOverride > 0 ? massOverride : b[10]),
           nx((int)b[11]), ny((int)b[12]), xb(b + 13), yb(b + 13 + (int)b[11] + 1), coef(b + 13 + (int)b[11] + 1 + (int)b[12] + 1) {}
 };
 
@@ -524,7 +527,10 @@ struct Uni {
 };
 
 /* keeps the instruction scheduler from interleaving the work of a thread's nodes (which would double the live registers) */
-__device__ __forceinline__ void node_fence() { __builtin_amdgcn_sched_barrier(0); }
+#ifndef MSD_NODE_FENCE
+#define MSD_NODE_FENCE 1
+#endif
+__device__ __forceinline__ void node_fence() { if (MSD_NODE_FENCE) __builtin_amdgcn_sched_barrier(0); }
 
 /* value the optimiser must treat as redefined here (no instruction is emitted) */
 __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); }
@@ -575,7 +581,7 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
     dv[RPW1] = U.rs[RPW1]*f*sb1;
     dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nG);     /* ocp.py:199 */
     if (DYN) {
-        const DynLoss D(P.loss);
+        const DynLoss D(P.loss, P.lossMass);
         double lr[2][6];
         loss_rows(D, f, 0.5*(sb + sb1), lr);                                 /* ocp.py:221: mid-point speed of the interval */
         dv[RLTR] = U.rs[RLTR]*(s - lr[0][0]);
@@ -1323,10 +1329,11 @@ struct Solver {
     {
 #if MSD_PHASE_FENCE
         if (!((MSD_FENCE_PHASES >> phase) & 1)) return;
-        /* single-wave workgroups only: that is the geometry the fences were tuned on (N <= 127, BASELINE config 1).  With several
-         * waves per workgroup hipcc (ROCm 7.2, iterative-ilp scheduling) has produced wrong code around the fenced multipliers
-         * (192 x 2: iterate of the last wave corrupted; reproduced with tools/debug_history.py), and there the fences buy nothing */
-        if (NT != 64) return;
+        /* one or two waves per workgroup only (N <= 255: BASELINE configs 1-4; +20 % on config 2).  With three and more waves hipcc
+         * (ROCm 7.2, iterative-ilp scheduling) has produced wrong code around the fenced multipliers -- 192 x 2: the iterate of
+         * the last wave corrupted, reproduced with tools/debug_history.py -- and tests/test_gpu_parity.py::
+         * test_every_launch_geometry_vs_oracle guards every geometry against a recurrence */
+        if (NT > 128) return;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             NodeT &nd = n[j];
@@ -2002,7 +2009,7 @@ struct Solver {
                 if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             }
             double sl;
-            if (DYN) { const DynLoss D(P.loss); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
+            if (DYN) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
             else sl = fmax(P.ct*fel, -P.cr*fel) + S0;
             nd.x[VF] = fel; nd.x[VP] = fpb; nd.x[VS] = sl;
         }
@@ -2495,15 +2502,16 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             const double *o = overrides + (size_t)MSD_OV_COUNT*sidx;
             Ps.sr0 = o[MSD_OV_SR0]; Ps.sr1 = o[MSD_OV_SR1]; Ps.sr2 = o[MSD_OV_SR2];
             Ps.fmax = o[MSD_OV_F_MAX]; Ps.fmin = o[MSD_OV_F_MIN]; Ps.fminPn = o[MSD_OV_F_MIN_PN];
-            Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN];
+            Ps.pwU = o[MSD_OV_PW_UPPER]; Ps.pwL = o[MSD_OV_PW_LOWER]; Ps.objDen = o[MSD_OV_OBJ_DEN]; Ps.lossMass = o[MSD_OV_TOTAL_MASS];
         }
         __syncthreads();
         if (c.tid == 0) *Pl = Ps;
         __syncthreads();
         Solver<NT, SPT, DYN> s(*Pl, c, work + work_doubles(NS)*blockIdx.x, *Ul);
-        const double *guess = P.guess ? P.guess + (size_t)nz*sidx : nullptr;
-        int startKind = guess ? MSD_START_REFERENCE : P.start, spent = 0;
-        /* a profile start that breaks down (not: runs out of iterations) is repeated from the reference's starting point */
+        const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
+        if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
+        int startKind = P.start, spent = 0;
+        /* a solve that breaks down (not: runs out of iterations) is repeated from the other starting point */
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             int iters = 0;
@@ -2511,8 +2519,10 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                                  lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, stats + (size_t)MSD_ST_COUNT*sidx,
                                  (hist && sidx == 0) ? hist : nullptr, hist_cap);
             __syncthreads();
-            if (st >= 0 || st == MSD_STATUS_MAXITER || startKind != MSD_START_PROFILE) break;
-            spent = iters; startKind = MSD_START_REFERENCE;
+            if (st >= 0 || st == MSD_STATUS_MAXITER) break;
+            spent = iters;
+            if (guess) guess = nullptr;      /* a warm start that breaks down: once more from the problem's own starting point */
+            else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;
         }
     }
 }

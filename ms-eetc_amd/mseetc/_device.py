@@ -17,12 +17,16 @@ LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent
 ABI_VERSION = 3
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, COUNT=14)
 SC_COUNT = 4
-OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, COUNT=9)
+OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, TOTAL_MASS=9, COUNT=10)
 HIST_COLS = 8
 
+STATUS_MAXITER, STATUS_LINESEARCH, STATUS_INFEASIBLE = -1, -2, -6
+# -2: the filter line search failed from both starting points: where IPOPT would enter its restoration phase, which the device
+# solver does not have ('Restoration_Failed' is IPOPT's status for a solve that ends there).  -6 is set by the host, from the
+# minimum-running-time certificate (casadiSolver._classify_failures), never by the kernel.
 STATUS_TEXT = {0: 'Solve_Succeeded', 1: 'Solved_To_Acceptable_Level', -1: 'Maximum_Iterations_Exceeded',
                -2: 'Restoration_Failed', -3: 'Error_In_Step_Computation', -4: 'Invalid_Number_Detected',
-               -5: 'Search_Direction_Becomes_Too_Small'}
+               -5: 'Search_Direction_Becomes_Too_Small', -6: 'Infeasible_Problem_Detected'}
 
 _dptr = ctypes.POINTER(ctypes.c_double)
 
@@ -77,6 +81,10 @@ def lib():
                                            ctypes.POINTER(ctypes.c_float)]
         L.msd_interval_integrate.argtypes = [ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, _dptr, ctypes.c_int] + [_dptr]*8 + [ctypes.POINTER(ctypes.c_int)]
         L.msd_interval_last_error.restype = ctypes.c_char_p
+        L.msd_solve_batch_shifted.argtypes = [vp, ctypes.c_int, _dptr, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr,
+                                              ctypes.POINTER(ctypes.c_float)]
+        L.msd_solve_batch_multi.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr,
+                                            _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
         L.msd_solve_batch_device_ex.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
         L.msd_problem_geometry.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
@@ -178,7 +186,7 @@ class DeviceProblem():
         except Exception:
             pass
 
-    def solve_batch(self, scen, want_multipliers=False, history=0, overrides=None, guess=None, warmMu=1e-2, warmPush=1e-3):
+    def solve_batch(self, scen, want_multipliers=False, history=0, overrides=None, guess=None, warmMu=1e-2, warmPush=1e-3, shift=None):
         """
         scen: (B,4) host array (t0, T, v0sq, vNsq), overrides: optional (B, OV['COUNT']), guess: optional (B, nz) primal
         warm start (barrier parameter warmMu, interior push warmPush) -> dict(z, stats, lam_g, kernel_ms[, hist])
@@ -203,9 +211,16 @@ class DeviceProblem():
         if guess is not None:
             guess = np.ascontiguousarray(guess, dtype=np.float64).reshape(B, self.nz)
 
-        _check(L.msd_solve_batch_warm(self._h, B, _d(scen), _d(overrides) if overrides is not None else None,
-                                      _d(guess) if guess is not None else None, float(warmMu), float(warmPush), _d(z),
-                                      _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+        if shift is not None:
+            # warm start from this handle's previous solve, `shift` intervals down the horizon, without leaving the device
+            if guess is not None:
+                raise ValueError("Give either a guess or a shift!")
+            _check(L.msd_solve_batch_shifted(self._h, B, _d(scen), _d(overrides) if overrides is not None else None, int(shift), float(warmMu),
+                                             float(warmPush), _d(z), _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+        else:
+            _check(L.msd_solve_batch_warm(self._h, B, _d(scen), _d(overrides) if overrides is not None else None,
+                                          _d(guess) if guess is not None else None, float(warmMu), float(warmPush), _d(z),
+                                          _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
 
         out = dict(z=z, stats=st, lam_g=lam, kernel_ms=float(ms.value))
 
@@ -214,6 +229,33 @@ class DeviceProblem():
             out['hist'] = hist[:int(st[0, ST['ITERS']]) + 1]
 
         return out
+
+    def solve_batch_multi(self, others, scen, want_multipliers=False, overrides=None, guess=None, warmMu=1e-2, warmPush=1e-3):
+        """
+        solve_batch over this handle and `others` (DeviceProblems of the same problem, normally on other devices): contiguous
+        slices of the batch, one per handle, all in flight at once (msd_solve_batch_multi).
+        """
+
+        L = lib()
+        scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
+        B = scen.shape[0]
+        z = np.zeros((B, self.nz))
+        st = np.zeros((B, ST['COUNT']))
+        lam = np.zeros((B, self.rowsPerInterval*self.N)) if want_multipliers else None
+        ms = ctypes.c_float(0)
+
+        if overrides is not None:
+            overrides = np.ascontiguousarray(overrides, dtype=np.float64).reshape(B, OV['COUNT'])
+
+        if guess is not None:
+            guess = np.ascontiguousarray(guess, dtype=np.float64).reshape(B, self.nz)
+
+        handles = (ctypes.c_void_p*(1 + len(others)))(self._h, *[o._h for o in others])
+        _check(L.msd_solve_batch_multi(handles, len(handles), B, _d(scen), _d(overrides) if overrides is not None else None,
+                                       _d(guess) if guess is not None else None, float(warmMu), float(warmPush), _d(z),
+                                       _d(lam) if lam is not None else None, _d(st), ctypes.byref(ms)))
+
+        return dict(z=z, stats=st, lam_g=lam, kernel_ms=float(ms.value))
 
     # ---- device-resident path (benchmark) ------------------------------------------------
 

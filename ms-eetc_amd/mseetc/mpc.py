@@ -88,6 +88,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     position = 0.0
     current = copy.deepcopy(track)
     previous = None
+    onDevice = False      # the handle's last launch solved the whole batch (its solutions are what a shifted warm start reads)
     last = None
     log = []
 
@@ -108,24 +109,35 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
 
         common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 
-        if warmStart and previous is not None:
+        posNew = position + solver.points.index.values
+        tail = (warmStart and previous is not None and onDevice and hasattr(solver, 'adoptDevice') and solverFactory is None and
+                len(previous[1]) - len(posNew) == stride and np.allclose(posNew, previous[1][stride:], rtol=0, atol=1e-6))
+
+        if tail:
+            # the new grid is the tail of the old one and the previous solutions are still on the device (same handle): the re-solve
+            # warm-starts from them there -- no upload, and scenarios without a usable guess start cold inside the same launch
+            res = solver.solveBatch(T, shift=stride, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
+            onDevice = True
+        elif warmStart and previous is not None:
             zPrev, posPrev, okPrev = previous
             guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
             usable = okPrev & np.isfinite(guess).all(axis=1)
             if usable.any() and not usable.all():
                 guess[~usable] = guess[np.flatnonzero(usable)[0]]      # placeholder rows: these scenarios are re-solved cold below
             if usable.any():
-                res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, **common)
+                res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
                 redo = np.flatnonzero(~usable | (res['status'] < 0))
             else:
-                res = solver.solveBatch(T, **common)
+                res = solver.solveBatch(T, classifyFailures=False, **common)
                 redo = np.zeros(0, dtype=int)
+            onDevice = redo.size == 0
             if redo.size:
-                sub = solver.solveBatch(T[redo], initialTime=t_now[redo], terminalVelocity=terminalVelocity, initialVelocity=v_now[redo])
+                sub = solver.solveBatch(T[redo], initialTime=t_now[redo], terminalVelocity=terminalVelocity, initialVelocity=v_now[redo], classifyFailures=False)
                 for key in ('z', 'status', 'iterations', 'cost'):
                     res[key][redo] = sub[key]
         else:
-            res = solver.solveBatch(T, **common)
+            res = solver.solveBatch(T, classifyFailures=False, **common)
+            onDevice = True
 
         previous = (res['z'], position + solver.points.index.values, res['status'] >= 0)
 

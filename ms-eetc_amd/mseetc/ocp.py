@@ -22,20 +22,14 @@ from . import _device
 class OptionsCasadiSolver(Options):
 
     def __init__(self, paramsDict):
-
-        self.numIntervals = 100  # number of shooting intervals with piece-wise constant controls [-]
-
-        self.maxIterations = 1e3  # maximum number of interior-point iterations
-
-        self.energyOptimal = True  # False means time optimal, True energy optimal
-
-        self.minimumVelocity = 1  # lower bound on velocity [m/s]
-
-        self.integrationMethod = 'RK'  # 'RK', 'IRK' or 'CVODES' (only 'RK' runs on the device)
-
-        self.integrationOptions = {}  # method-dependent integration options
-
-        self.integrateLosses = False  # integrate losses or take mid-point rule
+        # option names, defaults and meanings are the reference's (mseetc/ocp.py:16-28): a drop-in keeps the configuration schema
+        self.numIntervals = 100           # N: shooting intervals = pieces of the piecewise-constant controls
+        self.maxIterations = 1e3          # interior-point iteration limit (a float in the reference, too)
+        self.energyOptimal = True         # objective: traction energy [kWh] (True) or running time [s] (False)
+        self.minimumVelocity = 1          # m/s; speeds are bounded below by it (b = v^2 stays away from 0)
+        self.integrationMethod = 'RK'     # transcription of the interval dynamics: 'RK' | 'IRK' | 'CVODES' (the device runs 'RK')
+        self.integrationOptions = {}      # options of that method (OptionsRK / OptionsIRK / OptionsCVODES)
+        self.integrateLosses = False      # loss slack from the integrated loss power instead of the mid-point rule
 
         super().__init__(paramsDict)
 
@@ -90,6 +84,7 @@ class casadiSolver():
             raise ValueError("Unknown starting point '{}'!".format(startingPoint))
 
         self.startingPoint = startingPoint
+        self._optsDict = dict(optsDict)
 
         track.checkFields()
         train.checkFields()
@@ -181,6 +176,24 @@ class casadiSolver():
 
         return self._problem
 
+    def _handles(self, devices):
+        "Device problems for a multi-device solve: the solver's own handle when its device leads the list, one more per further entry (kept)."
+
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one device!")
+        pool = self.__dict__.setdefault('_pool', [])
+        want = []
+        used = set()
+        for d in devices:
+            hit = next((k for k, (dev, _) in enumerate(pool) if dev == d and k not in used), None)
+            if hit is None:
+                pool.append((d, _device.DeviceProblem(self._desc, d)))
+                hit = len(pool) - 1
+            used.add(hit)
+            want.append(pool[hit][1])
+        return want[0], want[1:]
+
     def adoptDevice(self, other):
         """
         Take over the device handle of another solver (which becomes unusable) instead of creating a new one: the next problem of a
@@ -197,6 +210,13 @@ class casadiSolver():
         if self._problem is not None:
             self._problem.close()
             self._problem = None
+
+        for _, prob in self.__dict__.pop('_pool', []):
+            prob.close()
+
+        twin = self.__dict__.pop('_twin', None)
+        if twin is not None:
+            twin.close()
 
     # ---- scenarios --------------------------------------------------------------------------
 
@@ -228,9 +248,6 @@ class casadiSolver():
         if mass is None and r0 is None and r1 is None and r2 is None:
             return None
 
-        if self._desc.loss_kind == LOSS_DYNAMIC:
-            raise NotImplementedError("Per-scenario rolling stock is not available together with the dynamic loss model.")
-
         tr = self.train
         full = lambda a, default: np.broadcast_to(np.asarray(default if a is None else a, dtype=float), (B,)).copy()
         mass, r0, r1, r2 = full(mass, tr.mass), full(r0, tr.r0), full(r1, tr.r1), full(r2, tr.r2)
@@ -251,11 +268,12 @@ class casadiSolver():
         out[:, OV['PW_UPPER']] = d.pw_upper*ratio if (tr.powerMax is not None or tr.forceMax is not None) else d.pw_upper
         out[:, OV['PW_LOWER']] = d.pw_lower*ratio if (tr.powerMin is not None or tr.forceMin is not None) else d.pw_lower
         out[:, OV['OBJ_DEN']] = 3.6/(1e-6*M) if self.energyOptimal else d.obj_den
+        out[:, OV['TOTAL_MASS']] = M      # the dynamic loss model maps specific forces to newtons with it (efficiency.py:108)
 
         return out
 
     def solveBatch(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1, multipliers=False,
-                   mass=None, r0=None, r1=None, r2=None, guess=None, warmMu=1e-2, warmPush=1e-3):
+                   mass=None, r0=None, r1=None, r2=None, guess=None, warmMu=1e-2, warmPush=1e-3, devices=None, classifyFailures=True, shift=None):
         """
         Solve many scenarios of this problem in one launch.  Arguments broadcast against each other; `mass`, `r0`, `r1`, `r2`
         (SI units, scalars or one value per scenario) perturb the rolling stock per scenario.  `guess` (B, nz) or (nz,), in the
@@ -280,15 +298,56 @@ class casadiSolver():
                 raise ValueError("Warm-start guess must be finite!")
             guess = np.broadcast_to(guess.reshape(-1, nz), (B, nz))
 
-        out = self.problem.solve_batch(scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2),
-                                       guess=guess, warmMu=warmMu, warmPush=warmPush)
+        if devices is None:
+            out = self.problem.solve_batch(scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2),
+                                           guess=guess, warmMu=warmMu, warmPush=warmPush, shift=shift)
+        else:
+            # one handle per entry of `devices` (an index may repeat: two streams on one device), contiguous slices, no collective
+            first, others = self._handles(devices)
+            out = first.solve_batch_multi(others, scen, want_multipliers=multipliers, overrides=self._overrides(B, mass, r0, r1, r2),
+                                          guess=guess, warmMu=warmMu, warmPush=warmPush)
 
         st = out['stats']
         ST = _device.ST
+
+        if self.energyOptimal and classifyFailures:
+            self._classify_failures(scen, st)
+
         cost = st[:, ST['OBJ']]*(1.0 if self.energyOptimal else self.scalingFactorObjective)   # ocp.py:361
 
         return dict(z=out['z'], status=st[:, ST['STATUS']].astype(int), iterations=st[:, ST['ITERS']].astype(int), cost=cost,
                     stats=st, kernel_ms=out['kernel_ms'], lam_g=out['lam_g'], scenarios=scen)
+
+    def _classify_failures(self, scen, st):
+        """
+        IPOPT ends a solve whose constraints cannot be met in its restoration phase with 'Infeasible_Problem_Detected'
+        (ocp.py:362-370 prints that status).  The device solver has no restoration phase; what it has is an exact certificate
+        for the one infeasibility this problem class knows -- a running time below the minimum: the time-optimal twin of the
+        problem (same transcription, energyOptimal=False, ocp.py:146-150) is solved for the scenarios that broke down, and
+        those whose minimum running time exceeds their T are marked infeasible.  Everything else keeps its status.
+        """
+
+        ST = _device.ST
+        failed = np.flatnonzero((st[:, ST['STATUS']] < 0) & (st[:, ST['STATUS']] != _device.STATUS_MAXITER))
+
+        if failed.size == 0:
+            return
+
+        twin = self.__dict__.get('_twin')
+
+        if twin is None:
+            opts = dict(self._optsDict)
+            opts['energyOptimal'] = False
+            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile')
+
+        sub = scen[failed]
+        loose = sub.copy()
+        loose[:, 1] = sub[:, 0] + self.track.length/max(self.velocityMin, 1e-3)      # a running time every feasible train meets
+        out = twin.problem.solve_batch(loose)
+        ok = out['stats'][:, ST['STATUS']] >= 0
+        tmin = out['z'][:, -2] - sub[:, 0]
+        short = ok & (tmin > (sub[:, 1] - sub[:, 0])*(1 + 1e-8))
+        st[failed[short], ST['STATUS']] = _device.STATUS_INFEASIBLE
 
     def unpack(self, z):
         "z (reference layout, ocp.py:376-405) -> DataFrame indexed by time."

@@ -345,12 +345,10 @@ class OptionsRK(Options):
 
     def __init__(self, paramsDict):
 
-        self.order = 4  # integration order
-
-        self.numSteps = 1  # number of integration steps inside shooting interval
-
-        self.numApproxSteps = 0  # trapezoidal time update on this many sub-intervals (0: integrate time with RK4)
-
+        # defaults of the reference's OptionsRK (mseetc/train.py:461-465)
+        self.order = 4             # classic RK4 is the only explicit scheme (casadi.simpleRK)
+        self.numSteps = 1          # equal sub-steps per shooting interval
+        self.numApproxSteps = 0    # 0: (t, b) integrated jointly; k > 0: b only, time by the trapezoidal rule on k pieces
         super().__init__(paramsDict)
 
     def checkValues(self):

@@ -1494,11 +1494,10 @@ static void profile_guess(const Prob *P, double *z)
     free(pos); free(b); free(v);
 }
 
-/* start: 0 = the reference's cold start, 1 = profile start; a failed profile start is repeated from the reference's point */
-int oracle_solve_start(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
-                       const double *bmax, int start, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+/* one solve from the profile start (nonzero return: failure status) */
+static int solve_from_profile(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                              const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
 {
-    if (start != 1) return oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
     Prob P;
     prob_init(&P, ip, dp, ds, grad, curv, bmax);
     const int nz = (4 + (P.withPn ? 1 : 0))*P.N + 2;
@@ -1506,9 +1505,20 @@ int oracle_solve_start(const int *ip, const double *dp, const double *ds, const 
     profile_guess(&P, guess);
     int st = solve_core(ip, dp, ds, grad, curv, bmax, guess, K_MU_INIT, K_PUSH, 1, z_out, lam_out, stats, hist, hist_cap);
     free(guess);
+    return st;
+}
+
+/* start: 0 = the reference's cold start, 1 = profile start; a solve that breaks down (not: runs out of iterations) is repeated
+ * from the other starting point, like the kernel does (msd_kernel.hpp: solve_kernel) */
+int oracle_solve_start(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                       const double *bmax, int start, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+{
+    int st = (start == 1) ? solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
+                          : oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
     if (st < 0 && st != OR_STATUS_MAXITER) {
         const double spent = stats[OR_ST_ITERS];
-        st = oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
+        st = (start == 1) ? oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
+                          : solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
         stats[OR_ST_ITERS] += spent;
     }
     return st;

@@ -60,7 +60,7 @@ class OracleSolver():
         io = opts.get('integrationOptions', {})
         self._prob = cases.oracle_problem(train, track, opts['numIntervals'], numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0))
 
-    def solveBatch(self, T, initialTime=0, terminalVelocity=1, initialVelocity=1, guess=None, warmMu=1e-2, warmPush=1e-3):
+    def solveBatch(self, T, initialTime=0, terminalVelocity=1, initialVelocity=1, guess=None, warmMu=1e-2, warmPush=1e-3, classifyFailures=False):
         from oracle import oracle
         scen = self._front._scenarios(T, initialTime, terminalVelocity, initialVelocity)
         rows = []
