@@ -198,8 +198,8 @@ int msd_solve_batch_shifted(msd_handle h, int nscen, const double *scen, const d
 int msd_synchronize(msd_handle h);
 
 /*
- * The same batch over several handles -- one per device, created from the same msd_problem_desc (`devices[]`;
- * 8e: one stream per device from a single process).  Handle k solves the contiguous slice [k nscen / n, (k + 1) nscen / n);
+ * The same batch over several handles -- one per device, created from the same problem description record. SURVEY 8b: `devices[]`;
+ * 8e: one stream per device from a single process.  Handle k solves the contiguous slice [k nscen / n, (k + 1) nscen / n);
  * every slice is enqueued on its device before any is waited for; no data moves between devices.  kernel_ms receives the
  * longest of the per-device kernel times.  Buffers are host buffers laid out as for msd_solve_batch_warm (z_guess may be NULL).
  */

@@ -110,15 +110,17 @@ static int cu_count(int device, int *out)
 static int configure(msd_problem *h, const msd_problem_desc *d)
 {
     const int N = d->num_intervals;
-    const msd::Geometry geo = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
-    int nmax = 0;      /* largest horizon whose stage blocks fit the 160 KB of LDS of a compute unit with the widest geometry */
-    for (int n = 1; n < 640; n++) {
-        const msd::Geometry g = (d->loss_kind == 2) ? msd::pick_geometry_dynamic(n) : msd::pick_geometry_static(n);
-        if (g.fn && sizeof(double)*(size_t)msd::lds_doubles(n, g.NT*g.SPT, d->loss_kind == 2) <= 160*1024) nmax = n;
+    const bool dyn = d->loss_kind == 2;
+    msd::Geometry geo = dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
+    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, dyn) : 0;
+    if (!geo.fn || lds > 160*1024) {
+        /* the stage blocks do not fit the LDS of a compute unit: the streamed kernel keeps them in device memory */
+        geo = dyn ? msd::Geometry{0, 0, nullptr} : msd::pick_stream_geometry_static(N);
+        lds = sizeof(double)*(size_t)msd::lds_doubles_stream();
+        if (!geo.fn)
+            return fail(MSD_E_UNSUPPORTED, dyn ? "numIntervals = " + std::to_string(N) + " with the dynamic loss model does not fit the LDS-resident kernel (the streamed kernel runs the static loss models)"
+                                               : "numIntervals = " + std::to_string(N) + " exceeds the 5119 intervals of the streamed kernel");
     }
-    const size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, d->loss_kind == 2) : 0;
-    if (!geo.fn || lds > 160*1024)
-        return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " does not fit the LDS-resident kernel (limit for this loss model: " + std::to_string(nmax) + ")");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));      /* nothing of the previous problem may still be running */
     h->kernel = nullptr;                           /* the handle holds no problem until every step below has succeeded (launch() checks) */
@@ -165,7 +167,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     if (rc != MSD_OK) return rc;
     h->max_grid = per_cu*cus;
     {
-        const size_t need = msd::work_doubles(geo.NT*geo.SPT)*(size_t)h->max_grid;
+        const size_t need = (geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, dyn) : msd::work_doubles(geo.NT*geo.SPT))*(size_t)h->max_grid;
         if (need > h->cap_work) {
             hipFree(h->d_work); h->d_work = nullptr; h->cap_work = 0;
             HIP_TRY(hipMalloc((void **)&h->d_work, sizeof(double)*need));

@@ -11,10 +11,11 @@ namespace msd {
 using KernelFn = void (*)(DevProb, int, const double *, const double *, double *, double *, double *, double *, int, double *);
 
 /* NT threads per workgroup, SPT shooting nodes per thread (NT*SPT >= N + 1) */
-struct Geometry { int NT, SPT; KernelFn fn; };
+struct Geometry { int NT, SPT; KernelFn fn; bool stream = false; };     /* stream: stage blocks in device memory (long horizons) */
 
 Geometry pick_geometry_static(int N);
 Geometry pick_geometry_dynamic(int N);
+Geometry pick_stream_geometry_static(int N);
 
 template <bool DYN> inline Geometry pick_geometry_t(int N)
 {
@@ -34,6 +35,13 @@ template <bool DYN> inline Geometry pick_geometry_t(int N)
     if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, DYN>};
     if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, DYN>};
     if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN>};
+    return {0, 0, nullptr};
+}
+
+/* horizons whose stage blocks do not fit the LDS of a compute unit: 1024 threads x 5 nodes, stage blocks streamed through L2 */
+template <bool DYN> inline Geometry pick_stream_geometry_t(int N)
+{
+    if (N + 1 <= 5120) return {1024, 5, solve_kernel<1024, 5, 1, DYN, true>, true};
     return {0, 0, nullptr};
 }
 

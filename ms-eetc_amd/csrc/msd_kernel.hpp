@@ -149,6 +149,9 @@ constexpr int S_DT = 6, S_DB = 7, S_DF = 8, S_DP = 9, S_DS = 10, S_LT = 11, S_LB
 /* dynamic loss model only: couplings of (b_i, s_i) with b_{i+1}; never overwritten by the sweeps */
 constexpr int S_EB = 28, S_ES = 29;
 
+/* LDS of the streamed kernel: filter, reduction scratch, misc, uniform records */
+__host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96; }
+
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NT, bool dyn)
 {
     return stage_stride(dyn)*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32 + CONST_DOUBLES;
@@ -464,6 +467,31 @@ __device__ __forceinline__ double push_in(double x, double lb, double ub, bool h
     return x;
 }
 
+/* x^y for the heuristic thresholds of the line search (switching condition and alpha_min, W&B eqs. (19), (23)): single precision
+ * through the hardware log2/exp2 -- a double pow() is several hundred instructions executed by every lane, three times per iteration,
+ * for quantities that only steer which acceptance test applies.  x > 0. */
+__device__ __forceinline__ double hpow(double x, double y)
+{
+    static_assert(K_MU_SUP == 1.5, "mu^1.5 is computed as mu*sqrt(mu) in the barrier update");
+#ifndef MSD_HPOW
+#define MSD_HPOW 1
+#endif
+    return MSD_HPOW ? (double)exp2f((float)y*log2f((float)x)) : pow(x, y);
+}
+
+/* sum of log(prod_j) over a thread's nodes with one logarithm: mantissas multiplied, exponents added (the products of up to twenty
+ * slacks each would underflow if multiplied directly) */
+struct LogSum {
+    double m = 1.0;
+    int e = 0;
+#ifndef MSD_LOGSUM
+#define MSD_LOGSUM 1
+#endif
+    double acc = 0.0;
+    __device__ __forceinline__ void add(double prod) { if (MSD_LOGSUM) { int ex; m *= frexp(prod, &ex); e += ex; } else acc += log(prod); }
+    __device__ __forceinline__ double value() const { return MSD_LOGSUM ? log(m) + 0.6931471805599453*(double)e : acc; }
+};
+
 __device__ __forceinline__ bool cmp_le(double lhs, double rhs, double basval) { return lhs - rhs <= 10.0*DBL_EPSILON*fabs(basval); }
 
 /* ------------------------------------------------------------------------------------------
@@ -493,21 +521,26 @@ template <int CNT, int NS> struct Field<CNT, NS, true> {
 constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_ZLS = 27, W_ZUS = 32, W_DSG = 37, W_RESC = 42, W_RESD = 44,
               W_EV = 49, W_LG = 62, W_FIELDS = 72;
 __host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
+/* work area of a workgroup of the streamed (long-horizon) kernel: node fields, stage blocks, six exchange arrays */
+__host__ __device__ constexpr size_t stream_doubles(int N, int node_slots, bool dyn)
+{
+    return (size_t)W_FIELDS*node_slots + (size_t)(dyn ? 31 : 27)*(N + 1) + 6*(size_t)node_slots;
+}
 
-template <int NS>
+template <int NS, bool STREAM>
 struct Node {
     int i;
     unsigned flags;
     double ds, G, sct, scb, ubB;
     /* iterate */
-    Field<NV, NS, MSD_MEM_X != 0> x;
-    Field<NR, NS, MSD_MEM_SG != 0> sg;
-    Field<2, NS, MSD_MEM_LAM != 0> lam;
-    Field<NR, NS, MSD_MEM_NU != 0> nu;
-    Field<NV, NS, MSD_MEM_Z != 0> zL, zU;
-    Field<NR, NS, MSD_MEM_Z != 0> zLs, zUs;
+    Field<NV, NS, MSD_MEM_X != 0 || STREAM> x;
+    Field<NR, NS, MSD_MEM_SG != 0 || STREAM> sg;
+    Field<2, NS, MSD_MEM_LAM != 0 || STREAM> lam;
+    Field<NR, NS, MSD_MEM_NU != 0 || STREAM> nu;
+    Field<NV, NS, MSD_MEM_Z != 0 || STREAM> zL, zU;
+    Field<NR, NS, MSD_MEM_Z != 0 || STREAM> zLs, zUs;
     /* slack part of the direction; (dx, new dynamics multipliers) stay in the node's LDS stage block */
-    Field<NR, NS, MSD_MEM_DSG != 0> dsg;
+    Field<NR, NS, MSD_MEM_DSG != 0 || STREAM> dsg;
     __device__ __forceinline__ void bind(double *w)      /* w: work area of the workgroup + node slot */
     {
         x.bind(w + W_X*NS); sg.bind(w + W_SG*NS); lam.bind(w + W_LAM*NS); nu.bind(w + W_NU*NS); zL.bind(w + W_ZL*NS); zU.bind(w + W_ZU*NS);
@@ -1209,22 +1242,22 @@ struct ParallelRiccati {
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int NT, int SPT, bool DYN>
+template <int NT, int SPT, bool DYN, bool STREAM>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
-    using NodeT = Node<NS>;
+    using NodeT = Node<NS, STREAM>;
     const DevProb &P;
     Ctx &c;
     double *work;                          /* the workgroup's private work area (work_doubles(NS)) */
     NodeT n[SPT];
     Uni &U;                                /* workgroup-uniform data of the scenario, in LDS (like P): loaded where needed instead of held in registers */
     /* right-hand sides of the linearised constraints: c and d - sigma (or their SOC accumulation) */
-    Field<2, NS, MSD_MEM_RES != 0> resc[SPT];
-    Field<NR, NS, MSD_MEM_RES != 0> resd[SPT];
+    Field<2, NS, MSD_MEM_RES != 0 || STREAM> resc[SPT];
+    Field<NR, NS, MSD_MEM_RES != 0 || STREAM> resd[SPT];
     /* evaluation of the current point with derivatives (evaluate_current), read back by the phases that need it */
-    Field<13, NS, MSD_MEM_EV != 0> evs[SPT];
-    Field<10, NS, MSD_MEM_EV != 0> lgs[SPT];
+    Field<13, NS, MSD_MEM_EV != 0 || STREAM> evs[SPT];
+    Field<10, NS, MSD_MEM_EV != 0 || STREAM> lgs[SPT];
 
     __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_, double *work_, Uni &U_) : P(P_), c(c_), work(work_), U(U_) {}
 
@@ -1333,7 +1366,7 @@ struct Solver {
          * (ROCm 7.2, iterative-ilp scheduling) has produced wrong code around the fenced multipliers -- 192 x 2: the iterate of
          * the last wave corrupted, reproduced with tools/debug_history.py -- and tests/test_gpu_parity.py::
          * test_every_launch_geometry_vs_oracle guards every geometry against a recurrence */
-        if (NT > 128) return;
+        if (NT > 128 || STREAM) return;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             NodeT &nd = n[j];
@@ -1468,6 +1501,7 @@ struct Solver {
         double gl[SPT][NV];
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;
         double th = 0, logs = 0, damp = 0, obj = 0;
+        LogSum lsum;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
@@ -1524,7 +1558,7 @@ struct Solver {
                     for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
                     obj += objective_term(P, nd, xl, q, U.sf); }
             }
-            logs += log(prod);
+            lsum.add(prod);
             /* the contributions that belong to the neighbours' variables */
             c.o1[nd.i] = out_q; c.o2[nd.i] = out_t1; c.o3[nd.i] = out_b1;
         }
@@ -1545,6 +1579,7 @@ struct Solver {
                 dual = fmax(dual, fabs(g));
             }
         }
+        logs = lsum.value();
         double vm[5] = {dual, prim, prim_u, cmax, -cmin};
         block_reduce<5>(vm, OpMax(), c);
         double vs[8] = {sumlam, sumz, nlam, nz, th, logs, damp, obj};
@@ -1723,6 +1758,7 @@ struct Solver {
         c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
         int par = -1;
 #if MSD_PARALLEL_RICCATI
+        if (!STREAM) {
         park_state();
 #if MSD_STASH_KKT
         stash<H_ALL & ~H_DSG>();
@@ -1736,6 +1772,7 @@ struct Solver {
             assemble(mode, mu_, dw);
             if (c.tid == 0) c.misc[MISC_FALLBACKS] += 1.0;
         }
+        }      /* (the streamed long-horizon kernel takes the serial sweeps: its stage blocks live in device memory) */
 #endif
         if (par < 0) {       /* serial sweeps on one lane: the fallback of the scan (cold) or, with MSD_PARALLEL_RICCATI = 0, the only path */
             if (c.tid == 0) {
@@ -1834,6 +1871,7 @@ struct Solver {
         trial_point(alpha, xt, st);
         publish(xt);
         double th = 0, logs = 0, damp = 0, bad = 0, obj = 0;
+        LogSum lsum;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
@@ -1863,8 +1901,9 @@ struct Solver {
                 }
                 obj += objective_term(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
             }
-            logs += log(prod);
+            lsum.add(prod);
         }
+        logs = lsum.value();
         double v[5] = {th, logs, damp, obj, bad};
         block_reduce<5>(v, OpSum(), c);
         theta = uni(v[0]); phi = uni(v[3] - mu_*v[1] + K_D*mu_*v[2]);
@@ -2229,7 +2268,7 @@ struct Solver {
             {
                 bool changed = false;
                 while (total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {
-                    const double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, pow(mu, K_MU_SUP)));
+                    const double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, mu*sqrt(mu)));      /* mu^theta_mu with theta_mu = K_MU_SUP = 1.5 */
                     if (nm >= mu) break;
                     mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = true;
                 }
@@ -2336,7 +2375,7 @@ struct Solver {
             double amin = G_THETA;
             if (gphid < 0) {
                 amin = fmin(amin, G_PHI*theta/(-gphid));
-                if (theta <= theta_min) amin = fmin(amin, K_DELTA*pow(theta, S_THETA)/pow(-gphid, S_PHI));
+                if (theta <= theta_min) amin = fmin(amin, K_DELTA*hpow(theta, S_THETA)/hpow(-gphid, S_PHI));
             }
             amin *= ALPHA_MIN_FRAC;
 
@@ -2344,7 +2383,13 @@ struct Solver {
             while (!accepted) {
                 double th_t, ph_t; bool okt;
                 merit(alpha, mu, th_t, ph_t, okt);
-                const bool ftype = (gphid < 0) && (alpha*pow(-gphid, S_PHI) > K_DELTA*pow(theta, S_THETA));
+                /* switching condition (W&B eq. (19)): single-precision powers decide unless the two sides are within 1e-4 of each other */
+                bool ftype = false;
+                if (gphid < 0) {
+                    double lhs = alpha*hpow(-gphid, S_PHI), rhs = K_DELTA*hpow(theta, S_THETA);
+                    if (fabs(lhs - rhs) <= 1e-4*fmax(lhs, rhs)) { lhs = alpha*pow(-gphid, S_PHI); rhs = K_DELTA*pow(theta, S_THETA); }
+                    ftype = lhs > rhs;
+                }
                 if (acceptable(okt, th_t, ph_t, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
                     accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
                     break;
@@ -2476,7 +2521,7 @@ struct Solver {
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
  * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT, int SPT, int WPS, bool DYN>
+template <int NT, int SPT, int WPS, bool DYN, bool STREAM = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
@@ -2484,10 +2529,21 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     constexpr int NS = NT*SPT;     /* node slots */
     Ctx c;
     c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.nt = NT; c.red_slot = 0;
-    c.S = lds;
-    c.xt = c.S + stage_stride(DYN)*(P.N + 1); c.xb = c.xt + NS; c.xf = c.xb + NS;
+    double *wg_work = work + (STREAM ? stream_doubles(P.N, NS, DYN) : work_doubles(NS))*blockIdx.x;
+    if (STREAM) {
+        /* long horizons (N > 560): stage blocks and exchange arrays behind the node fields in the workgroup's work area (device
+         * memory, L2-resident); LDS keeps the filter, the reduction scratch and the uniform records */
+        c.S = wg_work + work_doubles(NS);
+        c.xt = c.S + stage_stride(DYN)*(P.N + 1);
+        c.filt = lds;
+    } else {
+        c.S = lds;
+        c.xt = c.S + stage_stride(DYN)*(P.N + 1);
+    }
+    c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
-    c.filt = c.o3 + NS; c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
+    if (!STREAM) c.filt = c.o3 + NS;
+    c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
     /* the problem record and the scenario's uniform data live in LDS: phases read what they need (broadcast reads) instead of
      * carrying some eighty uniform values through the whole solve in registers */
     DevProb *Pl = reinterpret_cast<DevProb *>(c.misc + 32);
@@ -2507,7 +2563,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         __syncthreads();
         if (c.tid == 0) *Pl = Ps;
         __syncthreads();
-        Solver<NT, SPT, DYN> s(*Pl, c, work + work_doubles(NS)*blockIdx.x, *Ul);
+        Solver<NT, SPT, DYN, STREAM> s(*Pl, c, wg_work, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
         int startKind = P.start, spent = 0;

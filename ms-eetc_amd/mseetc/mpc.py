@@ -68,8 +68,8 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     Re-solve `numResolves` times; after each solve the train advances `stride` intervals of the current grid, the
     measured time and speed at that node are perturbed by `noise` (relative, standard normal) and the remaining
     horizon (stride intervals shorter) is solved again -- from a cold start like the reference, or with
-    `warmStart=True` from the previous solution moved onto the new grid (scenarios whose previous solve failed are
-    re-solved cold in a second launch).
+    `warmStart=True` from the previous solution moved onto the new grid -- on the device when the new grid is the tail of the old
+    one (msd_solve_batch_shifted), through transferSolution otherwise; a warm start that breaks down is repeated cold inside the launch.
 
     terminalTime: array (B,) of arrival times (absolute).
     Returns a list of dicts per re-solve: position [m], numIntervals, t0 (B,), v0 (B,), status, iterations, cost, z.
@@ -122,19 +122,15 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
             zPrev, posPrev, okPrev = previous
             guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
             usable = okPrev & np.isfinite(guess).all(axis=1)
-            if usable.any() and not usable.all():
-                guess[~usable] = guess[np.flatnonzero(usable)[0]]      # placeholder rows: these scenarios are re-solved cold below
             if usable.any():
+                # scenarios without a usable guess get another scenario's solution as a placeholder: a warm start that breaks down is
+                # repeated from the problem's own starting point inside the launch (solve_kernel), so no second launch is needed
+                if not usable.all():
+                    guess[~usable] = guess[np.flatnonzero(usable)[0]]
                 res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
-                redo = np.flatnonzero(~usable | (res['status'] < 0))
             else:
                 res = solver.solveBatch(T, classifyFailures=False, **common)
-                redo = np.zeros(0, dtype=int)
-            onDevice = redo.size == 0
-            if redo.size:
-                sub = solver.solveBatch(T[redo], initialTime=t_now[redo], terminalVelocity=terminalVelocity, initialVelocity=v_now[redo], classifyFailures=False)
-                for key in ('z', 'status', 'iterations', 'cost'):
-                    res[key][redo] = sub[key]
+            onDevice = True
         else:
             res = solver.solveBatch(T, classifyFailures=False, **common)
             onDevice = True

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -15,22 +16,22 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT, int SPT, bool DYN>
+template <int NT, int SPT, bool DYN, bool STREAM = false>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(msd::lds_doubles(P.N, NT*SPT, DYN));
+        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN));
         blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
-        std::vector<double> work(msd::work_doubles(NT*SPT)*(size_t)nscen);
+        std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN) : msd::work_doubles(NT*SPT))*(size_t)nscen);
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -70,6 +71,11 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     else if (nodes <= 128) { NT = 64; SPT = 2; }
     else if (nodes <= 256) { NT = 128; SPT = 2; }
     else { NT = 192; SPT = 2; }
+    if (force && !strcmp(force, "stream")) {      /* the long-horizon kernel (stage blocks in memory) at a thread count the emulation can afford */
+        if (dyn || nodes > 128*5) return -3;
+        run_blocks<128, 5, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+        return 0;
+    }
     if (NT*SPT < nodes) return -3;
     if (NT == 64 && SPT == 1) { if (dyn) run_blocks<64, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
     else if (NT == 64 && SPT == 2) { if (dyn) run_blocks<64, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }

@@ -1,0 +1,13 @@
+#!/bin/sh
+# TEST-ONLY: the device header under AddressSanitizer + UBSan on the CPU (GPU sanitizers are not available on the pool).
+# Builds the emulation with -fsanitize=address,undefined (a few minutes) and runs the emulation tests against it.
+# Opt-in from pytest: RUN_SANITIZERS=1 python -m pytest tests/test_kernel_emulation.py -k sanitizers
+set -e
+here="$(cd "$(dirname "$0")" && pwd)"
+out=${1:-/tmp/libmsd_emu_san.so}
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared -pthread -ffp-contract=off -I"$here" -o "$out" "$here/emu_driver.cpp"
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
+export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+export MSD_EMU_LIB="$out"
+cd "$here/../.."
+exec python3 -m pytest tests/test_kernel_emulation.py -q -x -k "not sanitizers"

@@ -21,6 +21,14 @@ EMU = Path(__file__).resolve().parent / 'hip_emu'
 def emu():
     src = [EMU / 'emu_driver.cpp', EMU / 'hip' / 'hip_runtime.h'] + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) \
         + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
+    import os
+    if os.environ.get('MSD_EMU_LIB'):      # a sanitizer build made by tests/hip_emu/run_sanitizers.sh
+        so = Path(os.environ['MSD_EMU_LIB'])
+        lib = ctypes.CDLL(str(so))
+        from mseetc._device import ProblemDesc
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.emu_solve_batch.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
+        return lib
     so = EMU / 'libmsd_emu.so'
     if not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in src):
         subprocess.run([str(EMU / 'build.sh')], check=True)
@@ -50,6 +58,26 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
     # the multipliers of a converged solve are determined to the solver tolerance (1e-8 on the scaled problem): relative bound
     assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
+
+
+def test_emulated_streamed_kernel_matches_oracle(emu, monkeypatch):
+    "The long-horizon variant (node fields, stage blocks and exchange arrays in device memory, serial sweeps) at a thread count the emulation can afford."
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    monkeypatch.setenv('EMU_GEOMETRY', 'stream')
+    N, T = 150, 1541.0
+    train, track = cases.train_default(), cases.track_00()
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(prob, prob.scenario(T), start='profile')
+    assert st[0, ST['STATUS']] == 0 and int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
 
 
 def test_emulated_warm_start_matches_oracle(emu):
@@ -119,3 +147,10 @@ def test_emulated_kernel_other_stage_systems(emu, variant):
     assert abs(int(st[0, ST['ITERS']]) - int(ref['stats']['ITERS'])) <= 1
     assert abs(st[0, ST['OBJ']] - ref['stats']['OBJ']) <= 1e-9*abs(ref['stats']['OBJ'])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('RUN_SANITIZERS'), reason="opt-in (several minutes): RUN_SANITIZERS=1")
+def test_emulation_under_sanitizers():
+    "ASan + UBSan over the emulated kernel (all emulation tests, every geometry they use): tests/hip_emu/run_sanitizers.sh must pass."
+    r = subprocess.run([str(EMU / 'run_sanitizers.sh')], capture_output=True, text=True, timeout=3600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
