@@ -45,6 +45,8 @@ struct msd_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
     double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
+    int *d_queue = nullptr;                           /* scenario counters of the launches (a ring: launches in flight on the stream each own one) */
+    int queue_slot = 0;
     size_t cap_work = 0;
     int SPT = 0;
     int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
@@ -156,7 +158,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr;
     P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
 
@@ -219,7 +221,7 @@ int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work);
+    hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     hipFree(h->d_z2); hipFree(h->d_stats2);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -232,6 +234,8 @@ int msd_problem_destroy(msd_handle h)
 int msd_problem_nz(msd_handle h) { return h ? (4 + h->P.withPn)*h->P.N + 2 : 0; }
 int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 : 0) + 3 + (h->P.energyOpt ? 2 : 0) : 0; }
 
+constexpr int QUEUE_RING = 64;
+
 struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0; };
 
 static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
@@ -240,6 +244,14 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
     if (!h->kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
     const int grid = nscen < h->max_grid ? nscen : h->max_grid;
     msd::DevProb P = h->P;
+    if (nscen > grid) {
+        /* more scenarios than resident workgroups: dynamic distribution through a counter (one of QUEUE_RING, so that launches queued
+         * back to back on the stream do not share it) */
+        if (!h->d_queue) HIP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)*QUEUE_RING));
+        P.queue = h->d_queue + h->queue_slot;
+        h->queue_slot = (h->queue_slot + 1) % QUEUE_RING;
+        HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), h->stream));
+    }
     P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
     hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, h->d_work);
     HIP_TRY(hipGetLastError());

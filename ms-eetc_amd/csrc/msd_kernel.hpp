@@ -104,6 +104,7 @@ struct DevProb {
     const double *guessStatus;   /* not null: stats records of the solves the guesses come from; a scenario whose record says "failed" starts cold */
     double warmMu, warmPush;
     double lossMass;         /* per-scenario override of the total mass in the dynamic loss model (0: the table's) */
+    int *queue;              /* device-wide scenario counter of the launch (null: static distribution) */
 };
 
 /* IPOPT default option values */
@@ -2551,7 +2552,19 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     static_assert(sizeof(DevProb) <= 8*UNI_OFF && sizeof(Uni) <= 8*(CONST_DOUBLES - UNI_OFF), "LDS room for the uniform records");
     const int nz = (4 + P.withPn)*P.N + 2;
     const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
-    for (int sidx = blockIdx.x; sidx < nscen; sidx += gridDim.x) {
+    /* scenarios are pulled from a device-wide counter (zeroed by the launch code): solves differ in their iteration counts, and a
+     * workgroup that finishes early takes the next scenario instead of idling behind a static stride (matters once the batch is
+     * several times the resident workgroups: configs 2-4).  queue == null: static stride. */
+    constexpr int MISC_NEXT = 25;
+    for (int turn = 0;; turn++) {
+        int sidx;
+        if (P.queue) {
+            __syncthreads();
+            if (c.tid == 0) c.misc[MISC_NEXT] = (double)atomicAdd(P.queue, 1);
+            __syncthreads();
+            sidx = (int)c.misc[MISC_NEXT];
+        } else sidx = blockIdx.x + turn*gridDim.x;
+        if (sidx >= nscen) break;
         /* per-scenario rolling stock (uniform over the workgroup) */
         DevProb Ps = P;
         if (overrides) {

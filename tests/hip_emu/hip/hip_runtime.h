@@ -61,6 +61,9 @@ static inline void emu_wave_fetch(const double *x, double *y, int K, int src)
     pthread_barrier_wait(&emu_blk->bar);
 }
 
+/* the blocks of an emulated launch run one after the other: a plain read-modify-write is atomic enough */
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
 using std::isfinite;
 
 static inline void __builtin_amdgcn_sched_barrier(int) {}
