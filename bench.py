@@ -63,8 +63,8 @@ def usable_cores():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=0, help='scenarios per GPU (default: the workload\'s per-GPU size)')
     ap.add_argument('--intervals', type=int, default=0, help='shooting intervals (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -42,7 +42,7 @@
 #define MSD_PHASE_FENCE 1
 #endif
 #ifndef MSD_FENCE_PHASES
-#define MSD_FENCE_PHASES 0x3ff      /* bit k: fence after phase k (enum PH_*) */
+#define MSD_FENCE_PHASES 0x155      /* bit k: fence after phase k (enum PH_*): evaluation, assembly, read-back, step lengths, update (tools/ab.sh, round 2) */
 #endif
 #ifndef MSD_FENCE_DUALS
 #define MSD_FENCE_DUALS 1           /* also fence multipliers and residuals, not only the primal point */

@@ -234,18 +234,40 @@ def test_velocity_clipping_like_the_reference():
     assert res['scenarios'][0][2] == 1.0 and abs(res['scenarios'][0][3] - (140/3.6)**2) < 1e-9
 
 
-def test_kkt_certificate_of_gpu_solution():
-    train, track = cases.train_default(), cases.track_00()
-    solver = _solver(train, track, 100)
-    res = solver.solveBatch([1600.0], multipliers=True)
-    prob = cases.oracle_problem(train, track, 100)
+@pytest.mark.parametrize('case', ['c1', 'c1_tight', 'c1_loose', 'c2', 'fig10', 'mintime', 'mpc_resolve'])
+def test_kkt_certificate_of_gpu_solution(case):
+    """
+    First-order optimality of the GPU's (z, lam_g) checked by an implementation that shares nothing with the kernel or the
+    oracle: the numpy restatement of the reference's NLP (tests/nlp_numpy.py, ocp.py:166-284) with complex-step Jacobians.
+    Covers the benchmark problems themselves (configs 1 and 2: both brakes, JSON efficiencies and power limits), for which the
+    reference holds no stored solution, next to the figure-10 and minimum-time configurations that it does pin.
+    """
+    kw, eo = {}, True
+    if case.startswith('c1'):
+        train, track, N, T = cases.train_default(), cases.track_00(), 100, {'c1': 1600.0, 'c1_tight': 1500.0, 'c1_loose': 1772.0}[case]
+    elif case == 'c2':
+        train, track, N, T = cases.train_default(), cases.track_CH(), 200, 1300.0
+    elif case == 'fig10':
+        train, track, N, T = cases.train_fig10(), cases.track_00(), 100, 1541.0
+    elif case == 'mintime':
+        train, track, N, T, eo = cases.train_fig5(), cases.track_00(8500), 100, 400.0, False
+        kw = dict(terminalVelocity=100/3.6, initialVelocity=1)
+    else:
+        train, track, N, T = cases.train_default(), cases.track_00(crop=20000), 40, 900.0
+        kw = dict(initialTime=100.0, initialVelocity=20.0, terminalVelocity=5.0)
+    solver = _solver(train, track, N, energyOptimal=eo, start='profile')
+    res = solver.solveBatch([T], multipliers=True, **kw)
+    assert res['status'][0] == 0
+    prob = cases.oracle_problem(train, track, N, energyOptimal=eo, losses='static' if eo else 'none')      # (only packs the problem data for the numpy NLP)
     nlp = cases.numpy_nlp(prob)
     sc = res['scenarios'][0]
     cert = kkt_certificate(nlp, res['z'][0], res['lam_g'][0], sc[0], sc[1], sc[2], sc[3])
     # feasibility: IPOPT's bound relaxation (1e-8 relative).  stat / sign_g are complementarity products of the multipliers the
     # certificate reconstructs: the solver stops when the scaled optimality error is below 1e-8 and IPOPT's unscaled side
     # condition compl_inf_tol = 1e-4 holds, so 1e-4 is the bound the stopping rule guarantees (typical values are 1e-6 .. 1e-5)
-    assert cert['feas_g'] < 1.5e-8 and cert['feas_z'] < 1.5e-8 and cert['stat'] < 1e-4 and cert['sign_g'] < 1e-4
+    assert cert['feas_g'] < 1.5e-8 and cert['feas_z'] < 1.5e-8 and cert['stat'] < 1e-4 and cert['sign_g'] < 1e-4, cert
+    # the objective the kernel reports is the NLP's objective at z
+    assert abs(float(nlp.obj(res['z'][0])) - res['stats'][0, 2]) <= 1e-10*abs(res['stats'][0, 2])
 
 
 def test_full_config1_batch_properties():
