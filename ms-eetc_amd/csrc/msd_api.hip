@@ -55,6 +55,11 @@ struct msd_problem {
     /* second result buffers: a solve that warm-starts from the previous solve of the handle reads one pair while it writes the other */
     double *d_z2 = nullptr, *d_stats2 = nullptr;
     int prev_nscen = 0, prev_nz = 0, prev_stp = 0;      /* what d_z / d_stats hold (prev_nscen = 0: nothing) */
+    /* multipliers of the solves (msd_problem_keep_duals): written to d_dual, read from it by a shifted warm start that writes d_dual2 */
+    bool keep_duals = false;
+    double *d_dual = nullptr, *d_dual2 = nullptr;
+    size_t cap_dual = 0;
+    int prev_dual_nodes = 0;                            /* nodes per scenario of what d_dual holds (0: nothing) */
     int cap_scen = 0, cap_guess = 0;
     double *h_hist = nullptr;
     int hist_cap = 0;
@@ -158,7 +163,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
 
@@ -223,7 +228,7 @@ int msd_problem_destroy(msd_handle h)
     hipSetDevice(h->device);
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
-    hipFree(h->d_z2); hipFree(h->d_stats2);
+    hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -236,7 +241,8 @@ int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 
 
 constexpr int QUEUE_RING = 64;
 
-struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0; };
+struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0;
+                   const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr; };
 
 static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
                   const WarmStart &ws = WarmStart())
@@ -253,6 +259,7 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
         HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), h->stream));
     }
     P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
+    P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
     hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, h->d_work);
     HIP_TRY(hipGetLastError());
     return MSD_OK;
@@ -365,6 +372,21 @@ static int enqueue_batch(msd_handle h, int nscen, const double *scen, const doub
             return fail(MSD_E_INVALID, "no previous solve of this handle matches the shifted warm start (same batch, horizon longer by `shift` intervals)");
         ws.d_guess = h->d_z + (size_t)stp*shift; ws.stride = h->prev_nz; ws.d_status = h->d_stats; ws.mu = mu_init; ws.push = bound_push;
         std::swap(h->d_z, h->d_z2); std::swap(h->d_stats, h->d_stats2);       /* results go to the other pair */
+        if (h->keep_duals && h->prev_dual_nodes == h->P.N + 1 + shift) {
+            ws.d_dual_in = h->d_dual; ws.dual_stride = (long long)MSD_DUAL_STRIDE*h->prev_dual_nodes; ws.dual_shift = shift;
+            std::swap(h->d_dual, h->d_dual2);
+        }
+    }
+    if (h->keep_duals) {
+        const size_t need = (size_t)MSD_DUAL_STRIDE*(h->P.N + 1)*nscen;
+        if (need > h->cap_dual) {
+            if (ws.d_dual_in) return fail(MSD_E_INVALID, "the multiplier buffers cannot grow between a solve and its shifted re-solve");
+            hipFree(h->d_dual); hipFree(h->d_dual2); h->d_dual = h->d_dual2 = nullptr; h->cap_dual = 0; h->prev_dual_nodes = 0;
+            HIP_TRY(hipMalloc((void **)&h->d_dual, sizeof(double)*need));
+            HIP_TRY(hipMalloc((void **)&h->d_dual2, sizeof(double)*need));
+            h->cap_dual = need;
+        }
+        ws.d_dual_out = h->d_dual;
     }
     if (z_guess) {
         if (nscen > h->cap_guess) {
@@ -386,6 +408,7 @@ static int enqueue_batch(msd_handle h, int nscen, const double *scen, const doub
     HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
     if (d_hist) HIP_TRY(hipMemcpyAsync(h->h_hist, d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
     h->prev_nscen = nscen; h->prev_nz = (int)nz; h->prev_stp = 4 + h->P.withPn;
+    h->prev_dual_nodes = h->keep_duals ? h->P.N + 1 : 0;
     return MSD_OK;
 }
 
@@ -405,6 +428,14 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
     rc = enqueue_batch(h, nscen, scen, overrides, z_guess, mu_init, bound_push, z_out, lam_out, stats);
     if (rc != MSD_OK) return rc;
     return finish_batch(h, kernel_ms);
+}
+
+int msd_problem_keep_duals(msd_handle h, int on)
+{
+    if (!h) return fail(MSD_E_INVALID, "null handle");
+    h->keep_duals = on != 0;
+    if (!h->keep_duals) h->prev_dual_nodes = 0;
+    return MSD_OK;
 }
 
 int msd_solve_batch_shifted(msd_handle h, int nscen, const double *scen, const double *overrides, int shift_intervals, double mu_init, double bound_push,

@@ -105,6 +105,12 @@ struct DevProb {
     double warmMu, warmPush;
     double lossMass;         /* per-scenario override of the total mass in the dynamic loss model (0: the table's) */
     int *queue;              /* device-wide scenario counter of the launch (null: static distribution) */
+    /* primal-dual warm start: multipliers per node in MSD_DUAL_STRIDE doubles (lam 2, nu 5, zL 5, zU 5, zLs 5, zUs 5) */
+    double *dualOut;         /* not null: [nscen][N + 1][MSD_DUAL_STRIDE], the multipliers of every solve are recorded */
+    const double *dualIn;    /* not null (with guess): multipliers to start from, dualInStride doubles between scenarios, node 0 of this
+                              * problem = node dualShift of the recorded one */
+    long long dualInStride;
+    int dualShift;
 };
 
 /* IPOPT default option values */
@@ -2057,8 +2063,8 @@ struct Solver {
     }
 
     /* one solve; startKind: MSD_START_* (ignored with an external guess); returns the status, iters_out = iterations spent */
-    __device__ __forceinline__ int run(const double *scen, const double *guess, int startKind, int iter_offset, int &iters_out,
-                                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+    __device__ __forceinline__ int run(const double *scen, const double *guess, const double *dual_in, int startKind, int iter_offset, int &iters_out,
+                                       double *z_out, double *lam_out, double *dual_out, double *stats, double *hist, int hist_cap)
     {
         const int N = P.N;
         const bool ext = guess != nullptr;
@@ -2206,10 +2212,40 @@ struct Solver {
 
         double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
 
+        /* ---- primal-dual warm start: constraint multipliers as recorded, bound and slack multipliers too but not below 1e-3 of
+         *      their central-path value mu/slack at the pushed point (a multiplier that was zero must be able to grow) ---- */
+        const bool dualStart = ext && dual_in != nullptr;
+        if (dualStart) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                node_fence();
+                NodeT &nd = n[j];
+                if (!nd.node()) continue;
+                const double *q = dual_in + (size_t)MSD_DUAL_STRIDE*nd.i;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    nd.zL[k] = fmax(q[7 + k], 1e-3*mu_start/(nd.x[k] - lbv(k)));
+                    if (hasU(k)) nd.zU[k] = fmax(q[12 + k], 1e-3*mu_start/(ubv(j, k) - nd.x[k]));
+                }
+                if (!nd.ival()) continue;
+                nd.lam[0] = q[0]; nd.lam[1] = q[1];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (!U.rowOn[r]) continue;
+                    nd.nu[r] = q[2 + r];
+                    if (U.rL[r]) nd.zLs[r] = fmax(q[17 + r], 1e-3*mu_start/(nd.sg[r] - U.dL[r]));
+                    if (U.rU[r]) nd.zUs[r] = fmax(q[22 + r], 1e-3*mu_start/(U.dU[r] - nd.sg[r]));
+                }
+            }
+        }
+
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
+        bool lsq = !dualStart;
 #if MSD_PROFILE_SKIP_LSQ
-        if (ext || startKind != MSD_START_PROFILE)
+        if (!ext && startKind == MSD_START_PROFILE) lsq = false;
 #endif
+        if (lsq)
         {
             const bool ok = direction(MODE_LSQ, 0.0, 0.0);
             double lmax = 0;
@@ -2482,6 +2518,22 @@ struct Solver {
             c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
         }
 
+        /* ---- the multipliers for a later primal-dual warm start ---- */
+        if (dual_out) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                node_fence();
+                const NodeT &nd = n[j];
+                if (!nd.node()) continue;
+                double *q = dual_out + (size_t)MSD_DUAL_STRIDE*nd.i;
+                q[0] = nd.ival() ? nd.lam[0] : 0.0; q[1] = nd.ival() ? nd.lam[1] : 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; r++) { q[2 + r] = nd.ival() ? nd.nu[r] : 0.0; q[17 + r] = nd.ival() ? nd.zLs[r] : 0.0; q[22 + r] = nd.ival() ? nd.zUs[r] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < NV; k++) { q[7 + k] = nd.zL[k]; q[12 + k] = nd.zU[k]; }
+            }
+        }
+
         /* ---- outputs: z in the reference's layout (ocp.py:166-272), multipliers in the reference's row order ---- */
         const int stp = 4 + P.withPn;
 #pragma unroll
@@ -2579,13 +2631,15 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         Solver<NT, SPT, DYN, STREAM> s(*Pl, c, wg_work, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
+        const double *dual_in = (guess && P.dualIn) ? P.dualIn + (size_t)P.dualInStride*sidx + (size_t)MSD_DUAL_STRIDE*P.dualShift : nullptr;
+        double *dual_out = P.dualOut ? P.dualOut + (size_t)MSD_DUAL_STRIDE*(P.N + 1)*sidx : nullptr;
         int startKind = P.start, spent = 0;
         /* a solve that breaks down (not: runs out of iterations) is repeated from the other starting point */
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             int iters = 0;
-            const int st = s.run(scen + (size_t)MSD_SC_COUNT*sidx, guess, startKind, spent, iters, z_out + (size_t)nz*sidx,
-                                 lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, stats + (size_t)MSD_ST_COUNT*sidx,
+            const int st = s.run(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                 lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
                                  (hist && sidx == 0) ? hist : nullptr, hist_cap);
             __syncthreads();
             if (st >= 0 || st == MSD_STATUS_MAXITER) break;

@@ -83,6 +83,7 @@ def lib():
         L.msd_interval_last_error.restype = ctypes.c_char_p
         L.msd_solve_batch_shifted.argtypes = [vp, ctypes.c_int, _dptr, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr,
                                               ctypes.POINTER(ctypes.c_float)]
+        L.msd_problem_keep_duals.argtypes = [vp, ctypes.c_int]
         L.msd_solve_batch_multi.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr,
                                             _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
@@ -276,6 +277,11 @@ class DeviceProblem():
 
     def solve_batch_device(self, B, d_scen, d_z, d_lam, d_stats, d_overrides=None):
         _check(lib().msd_solve_batch_device_ex(self._h, int(B), d_scen, d_overrides, d_z, d_lam, d_stats))
+
+    def keep_duals(self, on=True):
+        "Record the multipliers of every solve on the device; shifted warm starts then start from them too (msd_problem_keep_duals)."
+        _check(lib().msd_problem_keep_duals(self._h, int(bool(on))))
+        return self
 
     def geometry(self):
         "(threads per scenario, shooting nodes per thread) of the launch"

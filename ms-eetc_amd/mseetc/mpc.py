@@ -63,13 +63,14 @@ def transferSolution(z, positionsOld, positionsNew, withPnBrake):
 
 def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2, noise=0.0, seed=0,
                      initialTime=0.0, initialVelocity=1.0, terminalVelocity=1.0, device=0, solverFactory=None,
-                     warmStart=False, warmMu=1e-2, warmPush=1e-3):
+                     warmStart=False, warmMu=1e-2, warmPush=1e-3, dualMu=1e-4):
     """
     Re-solve `numResolves` times; after each solve the train advances `stride` intervals of the current grid, the
     measured time and speed at that node are perturbed by `noise` (relative, standard normal) and the remaining
     horizon (stride intervals shorter) is solved again -- from a cold start like the reference, or with
     `warmStart=True` from the previous solution moved onto the new grid -- on the device when the new grid is the tail of the old
-    one (msd_solve_batch_shifted), through transferSolution otherwise; a warm start that breaks down is repeated cold inside the launch.
+    one (msd_solve_batch_shifted: primal point and multipliers, barrier parameter `dualMu`), through transferSolution otherwise (primal
+    point only, `warmMu`); a warm start that breaks down is repeated cold inside the launch.
 
     terminalTime: array (B,) of arrival times (absolute).
     Returns a list of dicts per re-solve: position [m], numIntervals, t0 (B,), v0 (B,), status, iterations, cost, z.
@@ -106,6 +107,8 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
 
         if hasattr(solver, 'adoptDevice'):
             solver.adoptDevice(last)      # same device handle for every re-solve
+            if warmStart and solverFactory is None:
+                solver.problem.keep_duals(True)      # the multipliers of every solve stay on the device for the next re-solve
 
         common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 
@@ -116,7 +119,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         if tail:
             # the new grid is the tail of the old one and the previous solutions are still on the device (same handle): the re-solve
             # warm-starts from them there -- no upload, and scenarios without a usable guess start cold inside the same launch
-            res = solver.solveBatch(T, shift=stride, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
+            res = solver.solveBatch(T, shift=stride, warmMu=dualMu, warmPush=warmPush, classifyFailures=False, **common)
             onDevice = True
         elif warmStart and previous is not None:
             zPrev, posPrev, okPrev = previous

@@ -1046,20 +1046,44 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
  */
 static int solve_core(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                       const double *bmax, const double *guess, double mu0, double push, int skip_lsq,
-                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap,
+                      const double *dual_guess, double *dual_out);
 
 int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                       const double *bmax, const double *guess, double mu0, double push,
                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
 {
-    return solve_core(ip, dp, ds, grad, curv, bmax, guess, mu0, push, 0, z_out, lam_out, stats, hist, hist_cap);
+    return solve_core(ip, dp, ds, grad, curv, bmax, guess, mu0, push, 0, z_out, lam_out, stats, hist, hist_cap, NULL, NULL);
+}
+
+static void profile_guess(const Prob *P, double *z);
+
+/* primal-dual warm start; dual_guess / dual_out: [N + 1][OR_DUAL_STRIDE] (either may be NULL); start = the starting point of a plain solve
+ * (guess == NULL), so that one entry serves the first solve of a sequence, which only records its multipliers */
+int oracle_solve_dual(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, int start, const double *guess, const double *dual_guess, double mu0, double push,
+                      double *z_out, double *lam_out, double *dual_out, double *stats)
+{
+    if (guess) return solve_core(ip, dp, ds, grad, curv, bmax, guess, mu0, push, 0, z_out, lam_out, stats, NULL, 0, dual_guess, dual_out);
+    if (start == 1) {
+        Prob P;
+        prob_init(&P, ip, dp, ds, grad, curv, bmax);
+        const int nz = (4 + (P.withPn ? 1 : 0))*P.N + 2;
+        double *g = malloc(nz*sizeof(double));
+        profile_guess(&P, g);
+        int st = solve_core(ip, dp, ds, grad, curv, bmax, g, K_MU_INIT, K_PUSH, 1, z_out, lam_out, stats, NULL, 0, NULL, dual_out);
+        free(g);
+        return st;
+    }
+    return solve_core(ip, dp, ds, grad, curv, bmax, NULL, 0.0, 0.0, 0, z_out, lam_out, stats, NULL, 0, NULL, dual_out);
 }
 
 /* skip_lsq: start with zero constraint multipliers instead of the least-squares estimate (profile start: the estimate costs a
  * KKT solve and buys no iterations there) */
 static int solve_core(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                       const double *bmax, const double *guess, double mu0, double push, int skip_lsq,
-                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
+                      double *z_out, double *lam_out, double *stats, double *hist, int hist_cap,
+                      const double *dual_guess, double *dual_out)
 {
     const int warm = guess != NULL;
     const double kp = warm ? push : K_PUSH;
@@ -1139,6 +1163,28 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         }
     }
 
+    /* primal-dual warm start (OR_DUAL_STRIDE doubles per node: lam 2, nu 5, zL 5, zU 5, zLs 5, zUs 5): the constraint multipliers are
+     * taken as given (no least-squares estimate), the bound and slack multipliers too but not below 1e-3 of their central-path
+     * value mu0/slack at the pushed point -- a multiplier that was zero at the old solution must be able to grow */
+    if (warm && dual_guess) {
+        for (int i = 0; i <= N; i++) {
+            const double *q = dual_guess + OR_DUAL_STRIDE*i; StageIt *I = &W->it[i]; StageBd *B = &W->bd[i];
+            for (int k = 0; k < NV; k++) {
+                if (!B->on[k]) continue;
+                if (B->hasL[k]) I->zL[k] = fmax(q[7 + k], 1e-3*mu0/(I->x[k] - B->lb[k]));
+                if (B->hasU[k]) I->zU[k] = fmax(q[12 + k], 1e-3*mu0/(B->ub[k] - I->x[k]));
+            }
+            if (i == N) break;
+            I->lam[0] = q[0]; I->lam[1] = q[1];
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) { I->nu[r] = 0; continue; }
+                I->nu[r] = q[2 + r];
+                if (W->rhasL[r]) I->zLs[r] = fmax(q[17 + r], 1e-3*mu0/(I->sig[r] - W->dL[r]));
+                if (W->rhasU[r]) I->zUs[r] = fmax(q[22 + r], 1e-3*mu0/(W->dU[r] - I->sig[r]));
+            }
+        }
+        skip_lsq = 2;
+    }
     double mu = warm ? mu0 : K_MU_INIT, tau = fmax(K_TAU_MIN, 1 - mu);
     double (*res_c)[2] = calloc(N + 1, sizeof *res_c);
     double (*res_d)[NR] = calloc(N + 1, sizeof *res_d);
@@ -1148,7 +1194,9 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
     /* least-squares multiplier estimate (W&B section 3.6): solve with W = 0, Sigma = I, no barrier terms.
      * Realised with the same machinery: a temporary iterate whose Sigma are 1 and whose gradient is
      * grad f - zL + zU; constraint residuals zero. */
-    if (skip_lsq) {
+    if (skip_lsq == 2) {
+        /* multipliers given */
+    } else if (skip_lsq) {
         for (int i = 0; i < N; i++) { W->it[i].lam[0] = W->it[i].lam[1] = 0; for (int r = 0; r < NR; r++) W->it[i].nu[r] = 0; }
     } else {
         /* build h = grad f - zL + zU by tricking bar_terms: use a private assembly */
@@ -1415,6 +1463,13 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         zi[c++] = W->it[i].x[VF]; if (P->withPn) zi[c++] = W->it[i].x[VP];
         zi[c++] = W->it[i].x[VS]; zi[c++] = W->it[i].x[VT]; zi[c++] = W->it[i].x[VB];
     }
+    if (dual_out)
+        for (int i = 0; i <= N; i++) {
+            double *q = dual_out + OR_DUAL_STRIDE*i; const StageIt *I = &W->it[i];
+            q[0] = (i < N) ? I->lam[0] : 0; q[1] = (i < N) ? I->lam[1] : 0;
+            for (int r = 0; r < NR; r++) { q[2 + r] = (i < N) ? I->nu[r] : 0; q[17 + r] = (i < N) ? I->zLs[r] : 0; q[22 + r] = (i < N) ? I->zUs[r] : 0; }
+            for (int k = 0; k < NV; k++) { q[7 + k] = I->zL[k]; q[12 + k] = I->zU[k]; }
+        }
     z_out[stp*N] = W->it[N].x[VT]; z_out[stp*N + 1] = W->it[N].x[VB];
     if (lam_out) {
         int rpi = rows_per_interval(P);
@@ -1503,7 +1558,7 @@ static int solve_from_profile(const int *ip, const double *dp, const double *ds,
     const int nz = (4 + (P.withPn ? 1 : 0))*P.N + 2;
     double *guess = malloc(nz*sizeof(double));
     profile_guess(&P, guess);
-    int st = solve_core(ip, dp, ds, grad, curv, bmax, guess, K_MU_INIT, K_PUSH, 1, z_out, lam_out, stats, hist, hist_cap);
+    int st = solve_core(ip, dp, ds, grad, curv, bmax, guess, K_MU_INIT, K_PUSH, 1, z_out, lam_out, stats, hist, hist_cap, NULL, NULL);
     free(guess);
     return st;
 }

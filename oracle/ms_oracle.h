@@ -113,6 +113,12 @@ int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const d
                       const double *bmax, const double *guess, double mu0, double push,
                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
 
+/* primal-dual warm start: multipliers of a node in OR_DUAL_STRIDE doubles -- lam (2), nu (5), zL (5), zU (5), zLs (5), zUs (5) */
+#define OR_DUAL_STRIDE 27
+int oracle_solve_dual(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
+                      const double *bmax, int start, const double *guess, const double *dual_guess, double mu0, double push,
+                      double *z_out, double *lam_out, double *dual_out, double *stats);
+
 /* start = 0: the reference's cold start (ocp.py:325-339); start = 1: profile start (see ms_oracle.c), repeated cold when it breaks down (any failure but the iteration limit) */
 int oracle_solve_start(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                        const double *bmax, int start, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);

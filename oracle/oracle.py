@@ -66,6 +66,8 @@ def lib():
         _lib.oracle_solve_warm.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_double, ctypes.c_double, dptr, dptr, dptr, dptr,
                                            ctypes.c_int]
         _lib.oracle_solve_warm.restype = ctypes.c_int
+        _lib.oracle_solve_dual.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, ctypes.c_double, ctypes.c_double, dptr, dptr, dptr, dptr]
+        _lib.oracle_solve_dual.restype = ctypes.c_int
         _lib.oracle_solve_start.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, dptr, ctypes.c_int]
         _lib.oracle_solve_start.restype = ctypes.c_int
         _lib.oracle_solve_batch_start.argtypes = [iptr, dptr, dptr, dptr, dptr, dptr, ctypes.c_int, ctypes.c_int, dptr, dptr, dptr, ctypes.c_int]
@@ -265,6 +267,30 @@ def solve(prob, dp, history=False, guess=None, mu0=1e-3, push=1e-3, start='refer
         out['hist'] = hist[:int(st[ST['ITERS']]) + 1]
 
     return out
+
+
+DUAL_STRIDE = 27     # OR_DUAL_STRIDE
+
+
+def solve_dual(prob, dp, guess=None, duals=None, mu0=1e-4, push=1e-3, start='reference'):
+    """
+    One solve that records its multipliers ('duals': (N + 1, 27)) and, with `guess` (nz,) and `duals`, starts from both
+    (primal-dual warm start).  Without a guess it is a plain solve from `start`.
+    """
+
+    L = lib()
+    z = np.zeros(prob.nz)
+    lam = np.zeros(prob.rowsPerInterval*prob.N)
+    st = np.zeros(ST['COUNT'])
+    out = np.zeros((prob.N + 1, DUAL_STRIDE))
+    dp = np.ascontiguousarray(dp, dtype=np.float64)
+    g = None if guess is None else np.ascontiguousarray(guess, dtype=np.float64)
+    d = None if duals is None else np.ascontiguousarray(duals, dtype=np.float64)
+    assert g is None or g.shape == (prob.nz,)
+    assert d is None or d.shape == (prob.N + 1, DUAL_STRIDE)
+    L.oracle_solve_dual(_i(prob.ip), _d(dp), _d(prob.ds), _d(prob.grad), _d(prob.curv), _d(prob.bmax), START[start],
+                        _d(g) if g is not None else None, _d(d) if d is not None else None, float(mu0), float(push), _d(z), _d(lam), _d(out), _d(st))
+    return dict(z=z, lam_g=lam, duals=out, stats={k: st[v] for k, v in ST.items() if k != 'COUNT'})
 
 
 def solve_batch(prob, scen, nthreads=0, start='reference'):

@@ -38,6 +38,12 @@ static void run_blocks(msd::DevProb P, int nscen, const double *scen, const doub
     }
 }
 
+/* primal-dual warm starts in the emulation: buffers for the next emu_solve_batch* call (dual_in already points at the first node used) */
+static const double *g_dual_in = nullptr;
+static double *g_dual_out = nullptr;
+static long long g_dual_stride = 0;
+extern "C" void emu_set_duals(const double *dual_in, long long stride, double *dual_out) { g_dual_in = dual_in; g_dual_stride = stride; g_dual_out = dual_out; }
+
 extern "C" int emu_solve_batch_ex(const msd_problem_desc *d, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap);
 extern "C" int emu_solve_batch(const msd_problem_desc *d, int nscen, const double *scen, double *z, double *lam, double *stats, double *hist, int cap)
 {
@@ -53,7 +59,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
                                    double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
-    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr;
+    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
     std::vector<double> pos(d->num_intervals + 1, 0.0);
     for (int i = 0; i < d->num_intervals; i++) pos[i + 1] = pos[i] + d->ds[i];
     P.pos = pos.data();

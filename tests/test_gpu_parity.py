@@ -487,6 +487,47 @@ def test_config4_warm_started_mpc_matches_cold():
     assert itw < 0.85*itc      # the cold re-solves already use the profile start (about 21 iterations); warm ones need about 15
 
 
+def test_shifted_primal_dual_warm_start_vs_oracle():
+    """
+    msd_solve_batch_shifted with msd_problem_keep_duals: the re-solve of a horizon shortened by two intervals starts from the
+    previous solutions and multipliers, which never leave the device.  Against the oracle's primal-dual warm start, scenario by
+    scenario; a scenario whose first solve failed starts cold inside the same launch.
+    """
+    import copy
+    from oracle import oracle
+    from mseetc.track import computeDiscretizationPoints
+    train, track, N = cases.train_default(), cases.track_00(), 100
+    T = np.array([1541.0, 1600.0, 900.0, 1720.0])           # the third is infeasible: no guess for its re-solve
+    s1 = _solver(train, track, N, start='profile')
+    s1.problem.keep_duals(True)
+    r1 = s1.solveBatch(T, classifyFailures=False)
+    assert list(r1['status'] >= 0) == [True, True, False, True]
+    pos = computeDiscretizationPoints(track, N).index.values
+    track2 = copy.deepcopy(track); track2.updateLimits(positionStart=float(pos[2]))
+    s2 = _solver(train, track2, N - 2, start='profile').adoptDevice(s1)
+    stp = 5
+    t_now = np.where(r1['status'] >= 0, r1['z'][:, stp*2 + 3]*1.003, 60.0)
+    v_now = np.where(r1['status'] >= 0, np.sqrt(np.abs(r1['z'][:, stp*2 + 4]))*0.997, 15.0)
+    T2 = T.copy(); T2[2] = 1650.0                             # feasible now, but without a guess
+    r2 = s2.solveBatch(T2, initialTime=t_now, initialVelocity=v_now, shift=2, warmMu=1e-4, warmPush=1e-3, classifyFailures=False)
+    assert np.all(r2['status'] == 0), r2['status']
+    prob1, prob2 = cases.oracle_problem(train, track, N), cases.oracle_problem(train, track2, N - 2)
+    for k in (0, 1, 3):
+        first = oracle.solve_dual(prob1, prob1.scenario(float(T[k])), start='profile')
+        sc = prob2.scenario(float(T2[k]), float(t_now[k]), 1.0, float(v_now[k]))
+        warm = oracle.solve_dual(prob2, sc, guess=first['z'][stp*2:], duals=first['duals'][2:], mu0=1e-4, push=1e-3)
+        cold = oracle.solve(prob2, sc, start='profile')
+        assert warm['stats']['STATUS'] == 0
+        assert abs(r2['cost'][k] - warm['stats']['OBJ']) <= OBJ_RTOL*abs(warm['stats']['OBJ'])
+        assert np.max(np.abs(r2['z'][k] - warm['z'])/np.maximum(1.0, np.abs(warm['z']))) <= 10*Z_RTOL
+        assert abs(int(r2['iterations'][k]) - int(warm['stats']['ITERS'])) <= 2
+        assert int(r2['iterations'][k]) <= 0.6*int(cold['stats']['ITERS'])
+    sc = prob2.scenario(float(T2[2]), float(t_now[2]), 1.0, float(v_now[2]))
+    cold = oracle.solve(prob2, sc, start='profile')
+    assert abs(int(r2['iterations'][2]) - int(cold['stats']['ITERS'])) <= 2 and abs(r2['cost'][2] - cold['stats']['OBJ']) <= OBJ_RTOL*abs(cold['stats']['OBJ'])
+    s2.close()
+
+
 def test_handle_reuse_across_problems():
     # msd_problem_reconfigure: one device handle carried through problems of different horizon, track and layout gives the
     # results of fresh handles (the receding-horizon loop reuses its stream and buffers this way)

@@ -110,6 +110,59 @@ def test_emulated_warm_start_matches_oracle(emu):
     assert np.max(np.abs(z[0] - warm['z'])/np.maximum(1, np.abs(warm['z']))) < 1e-8
 
 
+def test_emulated_primal_dual_warm_start_matches_oracle(emu):
+    """
+    A solve records its multipliers; the re-solve of the horizon shortened by two intervals starts from the tail of its solution
+    and of its multipliers (barrier parameter 1e-4, no least-squares estimate): same iterates as the oracle's primal-dual warm
+    start, a third of the iterations of a cold solve.
+    """
+    import copy
+    from mseetc.ocp import casadiSolver
+    from mseetc.track import computeDiscretizationPoints
+    from mseetc._device import ProblemDesc, ST
+    from oracle import oracle
+    dp = ctypes.POINTER(ctypes.c_double)
+    emu.emu_solve_batch_warm.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, dp, dp, dp, ctypes.c_double, ctypes.c_double, dp, dp, dp, dp, ctypes.c_int]
+    emu.emu_set_duals.argtypes = [dp, ctypes.c_longlong, dp]
+    emu.emu_set_duals.restype = None
+    d = lambda a: a.ctypes.data_as(dp)
+    N, crop, T = 40, 16000, 700.0
+    train, track = cases.train_default(), cases.track_00(crop)
+    opts = lambda n: dict(numIntervals=n, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+    s1 = casadiSolver(train, track, opts(N), startingPoint='profile')
+    stp = 4 + int(s1.withPnBrake)
+    z1, lam1, st1, hist = np.zeros((1, stp*N + 2)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    duals1 = np.zeros((N + 1, oracle.DUAL_STRIDE))
+    emu.emu_set_duals(None, 0, d(duals1))
+    assert emu.emu_solve_batch(ctypes.byref(s1._desc), 1, d(s1._scenarios(T, 0, 1, 1)), d(z1), d(lam1), d(st1), d(hist), 8) == 0
+    prob1 = cases.oracle_problem(train, track, N)
+    ref1 = oracle.solve_dual(prob1, prob1.scenario(T), start='profile')
+    assert st1[0, ST['STATUS']] == 0 and abs(int(st1[0, ST['ITERS']]) - int(ref1['stats']['ITERS'])) <= 1
+    assert np.allclose(duals1, ref1['duals'], rtol=1e-3, atol=1e-6)      # converged multipliers (the two sides may stop one iteration apart)
+    # two intervals further: cropped track, measured state slightly off the plan
+    pos = computeDiscretizationPoints(track, N).index.values
+    track2 = copy.deepcopy(track); track2.updateLimits(positionStart=float(pos[2]))
+    s2 = casadiSolver(train, track2, opts(N - 2), startingPoint='profile')
+    t_now, v_now = ref1['z'][stp*2 + stp - 2]*1.004, np.sqrt(ref1['z'][stp*2 + stp - 1])*0.996
+    scen2 = s2._scenarios(T, t_now, 1, v_now)
+    guess = np.ascontiguousarray(ref1['z'][stp*2:])
+    z2, lam2, st2 = np.zeros((1, stp*(N - 2) + 2)), np.zeros((1, 7*(N - 2))), np.zeros((1, ST['COUNT']))
+    duals2 = np.zeros((N - 1, oracle.DUAL_STRIDE))
+    tail = np.ascontiguousarray(ref1['duals'][2:])      # both sides start from the same numbers
+    emu.emu_set_duals(d(tail), 0, d(duals2))
+    assert emu.emu_solve_batch_warm(ctypes.byref(s2._desc), 1, d(scen2), None, d(guess), 1e-4, 1e-3, d(z2), d(lam2), d(st2), d(hist), 8) == 0
+    emu.emu_set_duals(None, 0, None)
+    prob2 = cases.oracle_problem(train, track2, N - 2)
+    sc2 = prob2.scenario(T, t_now, 1.0, v_now)
+    warm = oracle.solve_dual(prob2, sc2, guess=guess, duals=ref1['duals'][2:], mu0=1e-4, push=1e-3)
+    cold = oracle.solve(prob2, sc2, start='profile')
+    assert warm['stats']['STATUS'] == 0 and st2[0, ST['STATUS']] == 0
+    assert abs(int(st2[0, ST['ITERS']]) - int(warm['stats']['ITERS'])) <= 1
+    assert int(st2[0, ST['ITERS']]) <= 0.5*int(cold['stats']['ITERS'])
+    assert np.max(np.abs(z2[0] - warm['z'])/np.maximum(1, np.abs(warm['z']))) < 1e-7
+    assert abs(st2[0, ST['OBJ']] - cold['stats']['OBJ']) <= 1e-7*abs(cold['stats']['OBJ'])
+
+
 @pytest.mark.parametrize('variant', ['dynamic_losses', 'no_pneumatic_brake_time_optimal'])
 def test_emulated_kernel_other_stage_systems(emu, variant):
     "The two stage-system variants the static both-brakes cases do not reach: dynamic loss rows (couplings folded in assemble) and no Fpb."
