@@ -203,12 +203,11 @@ def main():
 
     child = 'RANK' in os.environ
 
-    if not child:
-        if args.no_build:
-            if entry.stale() and not os.environ.get('MSD_LIB'):       # MSD_LIB: a tuning build (tools/build_variant.py) is being measured
-                raise SystemExit("bench.py --no-build: ms-eetc_amd/lib/libmseetc_hip.so is missing or stale; run `python3 __graft_entry__.py` first")
-        else:
-            entry.build()
+    if args.no_build:
+        if entry.stale() and not os.environ.get('MSD_LIB'):       # MSD_LIB: a tuning build (tools/build_variant.py) is being measured
+            raise SystemExit("bench.py --no-build: ms-eetc_amd/lib/libmseetc_hip.so is missing or stale; run `python3 __graft_entry__.py` first")
+    else:
+        entry.build()      # every rank may call it: an exclusive file lock serialises the ranks, all but the first find the library fresh
 
     import torch      # importing torch and counting devices does not initialise the GPU
 

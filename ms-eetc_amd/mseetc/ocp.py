@@ -162,6 +162,7 @@ class casadiSolver():
         self.withPnBrake = withPnBrake
         self.train = train
         self.track = track
+        self._vmaxTrain = float(train.velocityMax)
         self.energyOptimal = opts.energyOptimal
         self.scalingFactorObjective = scaling
         self.opts = opts
@@ -342,7 +343,9 @@ class casadiSolver():
 
         sub = scen[failed]
         loose = sub.copy()
-        loose[:, 1] = sub[:, 0] + self.track.length/max(self.velocityMin, 1e-3)      # a running time every feasible train meets
+        # a running time the twin can certainly meet: three times the run at top speed or three times the one asked for (a much looser
+        # bound only costs iterations: the profile start of the twin uses up the time it is given)
+        loose[:, 1] = sub[:, 0] + np.maximum(3*self.track.length/self._vmaxTrain, 3*(sub[:, 1] - sub[:, 0]))
         out = twin.problem.solve_batch(loose)
         ok = out['stats'][:, ST['STATUS']] >= 0
         tmin = out['z'][:, -2] - sub[:, 0]

@@ -226,6 +226,77 @@ def test_long_horizons_streamed_kernel_vs_oracle(N):
     s.close()
 
 
+def _random_problem(seed, tmp_path):
+    "A random TTOBench-style track (speed limits, gradients, sometimes curves) and a randomly perturbed VIRM6, as the loaders would read them."
+    import json
+    from mseetc.track import Track, computeDiscretizationPoints
+    rng = np.random.default_rng(1000 + seed)
+    L = float(rng.uniform(6e3, 40e3))
+    cut = lambda k: np.sort(rng.uniform(0.05*L, 0.95*L, k)).round(0)
+    lim = [[0.0, float(rng.choice([100, 120, 140]))]] + [[float(p), float(rng.choice([80, 100, 120, 140, 160]))] for p in cut(rng.integers(1, 4))]
+    grd = [[0.0, float(rng.uniform(-6, 6))]] + [[float(p), float(rng.uniform(-12, 12))] for p in cut(rng.integers(2, 7))]
+    data = {"metadata": {"id": "rnd%d" % seed, "library version": "TTOBench v1.1"}, "altitude": {"unit": "m", "value": 0},
+            "stops": {"unit": "m", "values": [0.0, L]},
+            "speed limits": {"units": {"position": "m", "velocity": "km/h"}, "values": lim},
+            "gradients": {"units": {"position": "m", "slope": "permil"}, "values": grd}}
+    (tmp_path / ("rnd%d.json" % seed)).write_text(json.dumps(data))
+    track = Track(config={'id': 'rnd%d' % seed}, pathJSON=tmp_path)
+    if rng.random() < 0.4:
+        r = float(rng.uniform(400, 1500))
+        track.importCurvatureTuples([[0.0, np.inf, np.inf], [float(round(0.3*L)), r, r], [float(round(0.3*L) + 600), np.inf, np.inf]])
+    train = cases.train_default()
+    train.mass *= float(rng.uniform(0.85, 1.2))
+    train.etaTraction, train.etaRgBrake = float(rng.uniform(0.75, 0.95)), float(rng.uniform(0.6, 0.9))
+    kind = rng.integers(0, 3)
+    if kind == 1:
+        train.forceMinPn = 0                       # regenerative brake only
+    elif kind == 2:
+        train.forceMin = 0                         # pneumatic brake only
+    rows = len(track.mergeDataFrames())
+    N = int(rng.integers(max(rows + 6, 24), 260))
+    for _ in range(20):                            # a breakpoint on a fill-in node is an error of the grid (track.py:103-105): next N
+        try:
+            computeDiscretizationPoints(track, N)
+            break
+        except ValueError:
+            N += 1
+    return train, track, N, rng
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_randomized_problems_vs_oracle(seed, tmp_path):
+    """
+    Problems nobody tuned anything on: random tracks (length, speed-limit sections, gradients up to 12 permil, sometimes a curve), a
+    perturbed train with a random brake configuration, a random horizon (24 ... 260 intervals: one to three waves per scenario) and
+    running times 8 ... 45 % above the minimum, which the time-optimal twin of the problem provides.  Energy-optimal and time-optimal
+    solves against the oracle.
+    """
+    train, track, N, rng = _random_problem(seed, tmp_path)
+    v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
+    fast = _solver(train, track, N, energyOptimal=False, start='profile')
+    Tloose = 3*track.length/train.velocityMax       # a bound the train can meet (a far looser one only costs the time-optimal solve iterations)
+    rt = fast.solveBatch([Tloose], initialVelocity=v0, terminalVelocity=vN)
+    assert rt['status'][0] == 0
+    tmin = float(rt['z'][0][-2])
+    po = cases.oracle_problem(train, track, N, energyOptimal=False, losses='none')
+    ot = oracle_solve = __import__('oracle.oracle', fromlist=['x'])
+    reft = ot.solve(po, po.scenario(Tloose, 0.0, vN, v0), start='profile')
+    assert reft['stats']['STATUS'] == 0 and abs(tmin - reft['z'][-2]) <= 1e-7*tmin
+    T = tmin*np.array([1.08, 1.2, 1.45])
+    s = _solver(train, track, N, start='profile')
+    res = s.solveBatch(T, initialVelocity=v0, terminalVelocity=vN)
+    assert np.all(res['status'] == 0), (seed, N, res['status'])
+    assert int(res['stats'][:, 13].sum()) == 0        # no fallbacks from the stage-parallel KKT solve
+    pe = cases.oracle_problem(train, track, N)
+    for k in range(3):
+        ref = ot.solve(pe, pe.scenario(float(T[k]), 0.0, vN, v0), start='profile')
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ']), (seed, N, k)
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4, (seed, N, k)
+    assert np.all(np.diff(res['cost']) < 0)
+    s.close(); fast.close()
+
+
 def test_velocity_clipping_like_the_reference():
     # initial/terminal speeds are clipped to [vmin, local speed limit] (ocp.py:343-344)
     train, track = cases.train_default(), cases.track_00(crop=20000)
