@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 3
+#define MSD_ABI_VERSION 4
 
 /* error codes */
 #define MSD_OK 0
@@ -105,7 +105,11 @@ typedef struct msd_problem_desc {
     int loss_kind;           /* 0 none, 1 static efficiencies (train.py:199-212), 2 dynamic table (efficiency.py) */
     int max_iterations;      /* ocp.py:18,290                                                 */
     int start_kind;          /* MSD_START_REFERENCE (0) or MSD_START_PROFILE                  */
-    int reserved_i[6];
+    int integrator;          /* shooting integrator (OptionsCasadiSolver.integrationMethod, ocp.py:26, train.py:294-322): 0 = 'RK' (simpleRK order 4),
+                              * MSD_INTEGRATOR_COLLOCATION = 'IRK' (simpleIRK), MSD_INTEGRATOR_ADAPTIVE = 'CVODES' (integration to tolerances) */
+    int coll_degree;         /* 'IRK': OptionsIRK.order = collocation points per step, 1..9 (train.py:485,502)      */
+    int newton_iterations;   /* 'IRK': OptionsIRK.maxIter (train.py:493)                       */
+    int reserved_i[3];
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
     double g, rho;
     double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */
@@ -116,7 +120,8 @@ typedef struct msd_problem_desc {
     double vmin_sq;          /* minimumVelocity^2 (ocp.py:22,271)                             */
     double obj_den;          /* scalingFactorObjective (ocp.py:278,282)                       */
     double tol;              /* IPOPT tol, 1e-8                                               */
-    double reserved_d[7];
+    double int_abstol, int_reltol;   /* 'CVODES': OptionsCVODES.absTol, .relTol (train.py:525-526)     */
+    double reserved_d[5];
     const double *ds;        /* [N]   interval lengths (ocp.py:125)                           */
     const double *grad;      /* [N]   gradient, permil/1000 (ocp.py:195)                      */
     const double *curv;      /* [N]   curvature 1/m (ocp.py:196)                              */
@@ -127,6 +132,9 @@ typedef struct msd_problem_desc {
     const double *loss_table;
     int loss_table_len;
     int reserved_tail;
+    /* integrator = MSD_INTEGRATOR_COLLOCATION: the tables of casadi.simpleIRK, C[(coll_degree+1)^2] (row r, column j: derivative of the
+     * Lagrange polynomial r at point j) then D[coll_degree+1] (the polynomials at 1), on the points {0} + casadi.collocation_points */
+    const double *coll_tables;
 } msd_problem_desc;
 
 typedef struct msd_problem *msd_handle;

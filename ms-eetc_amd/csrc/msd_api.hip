@@ -58,6 +58,7 @@ struct msd_problem {
     /* multipliers of the solves (msd_problem_keep_duals): written to d_dual, read from it by a shifted warm start that writes d_dual2 */
     bool keep_duals = false;
     double *d_dual = nullptr, *d_dual2 = nullptr;
+    double *d_coll = nullptr;                           /* tables of the collocation integrator */
     size_t cap_dual = 0;
     int prev_dual_nodes = 0;                            /* nodes per scenario of what d_dual holds (0: nothing) */
     int cap_scen = 0, cap_guess = 0;
@@ -94,6 +95,15 @@ static int check_desc(const msd_problem_desc *d)
     }
     for (int i = 0; i < d->num_intervals; i++)
         if (!(d->ds[i] > 0)) return fail(MSD_E_INVALID, "interval lengths must be positive");
+    if (d->integrator != 0 && d->integrator != MSD_INTEGRATOR_ADAPTIVE && d->integrator != MSD_INTEGRATOR_COLLOCATION)
+        return fail(MSD_E_INVALID, "Unknown integration method!");
+    if (d->integrator == MSD_INTEGRATOR_COLLOCATION) {
+        if (d->coll_degree < 1 || d->coll_degree > 9) return fail(MSD_E_INVALID, "Order of implicit Runge-Kutta should be a positive integer between 1 and 9!");
+        if (d->newton_iterations < 1) return fail(MSD_E_INVALID, "Maximum number of iterations must be a strictly positive integer!");
+        if (!d->coll_tables) return fail(MSD_E_INVALID, "collocation integrator without its tables");
+    }
+    if (d->integrator == MSD_INTEGRATOR_ADAPTIVE && (!(d->int_abstol > 0) || !(d->int_reltol > 0))) return fail(MSD_E_INVALID, "tolerances of the adaptive integrator must be positive");
+    if (d->integrator != 0 && d->loss_kind == 2) return fail(MSD_E_UNSUPPORTED, "the collocation and adaptive shooting integrators run with the static loss models");
     return MSD_OK;
 }
 
@@ -118,8 +128,11 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
 {
     const int N = d->num_intervals;
     const bool dyn = d->loss_kind == 2;
-    msd::Geometry geo = dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
+    const bool gen = d->integrator != 0;
+    msd::Geometry geo = gen ? msd::pick_geometry_general(N) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
     size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, dyn) : 0;
+    if (gen && (!geo.fn || lds > 160*1024))
+        return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " with the collocation or adaptive shooting integrator does not fit the LDS-resident kernel (the streamed kernel runs 'RK')");
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernel keeps them in device memory */
         geo = dyn ? msd::Geometry{0, 0, nullptr} : msd::pick_stream_geometry_static(N);
@@ -156,6 +169,12 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         HIP_TRY(hipMemcpy(h->d_loss, d->loss_table, sizeof(double)*d->loss_table_len, hipMemcpyHostToDevice));
     }
 
+    if (d->integrator == MSD_INTEGRATOR_COLLOCATION) {
+        const int len = (d->coll_degree + 1)*(d->coll_degree + 2);
+        if (!h->d_coll) HIP_TRY(hipMalloc((void **)&h->d_coll, sizeof(double)*10*11));
+        HIP_TRY(hipMemcpy(h->d_coll, d->coll_tables, sizeof(double)*len, hipMemcpyHostToDevice));
+    }
+
     h->NT = geo.NT; h->SPT = geo.SPT; h->lds_bytes = lds;
     msd::DevProb &P = h->P;
     P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
@@ -166,6 +185,9 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
+    P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
+    P.coll = (d->integrator == MSD_INTEGRATOR_COLLOCATION) ? h->d_coll : nullptr;
+    if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
 
     HIP_TRY(hipFuncSetAttribute((const void *)geo.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, cus = 0;
@@ -228,7 +250,7 @@ int msd_problem_destroy(msd_handle h)
     hipSetDevice(h->device);
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
-    hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2);
+    hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

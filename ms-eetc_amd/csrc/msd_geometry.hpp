@@ -1,6 +1,6 @@
 /*
- * msd_geometry.hpp -- launch geometry of the solve kernel by horizon length.  The kernel instantiations live in two
- * translation units (static / dynamic loss model) so that they compile in parallel.
+ * msd_geometry.hpp -- launch geometry of the solve kernel by horizon length.  The kernel instantiations live in four
+ * translation units (static / dynamic loss model, streamed, other integrators) so that they compile in parallel.
  */
 #pragma once
 
@@ -16,6 +16,7 @@ struct Geometry { int NT, SPT; KernelFn fn; bool stream = false; };     /* strea
 Geometry pick_geometry_static(int N);
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
+Geometry pick_geometry_general(int N);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 
 template <bool DYN> inline Geometry pick_geometry_t(int N)
 {

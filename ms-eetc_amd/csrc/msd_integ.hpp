@@ -1,0 +1,201 @@
+/*
+ * msd_integ.hpp -- the other two integrators TrainIntegrator offers for the shooting intervals of the NLP (reference:
+ * mseetc/train.py:303-322, selected by OptionsCasadiSolver.integrationMethod, ocp.py:26-27,92): collocation (casadi.simpleIRK) and
+ * integration to tolerances (casadi.integrator('cvodes'); SUNDIALS is third-party code that is not part of the reference repository,
+ * its role is taken by an adaptive Dormand-Prince pair at the same tolerances).  Both are written once for values (T = double: line
+ * search) and for second-order jets in (b, w) (T = Jet: the evaluation with derivatives).  They are compiled into their own
+ * instantiations of the solve kernel (template parameter GEN), the explicit Runge-Kutta kernels do not carry them.
+ * Included by msd_kernel.hpp inside namespace msd, after the jet arithmetic and ode_b.
+ */
+#pragma once
+
+constexpr int COLL_MAX = 9;      /* OptionsIRK.order <= 9 (train.py:502) */
+
+__device__ __forceinline__ double jval(const Jet &a) { return a.v; }
+__device__ __forceinline__ double jval(double a) { return a; }
+__device__ __forceinline__ Jet jconst(Jet, double c) { return {c, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ double jconst(double, double c) { return c; }
+/* derivative component k (1..5) of a jet, component 0 = value; a double has the value only */
+__device__ __forceinline__ int jcomps(const Jet &) { return 6; }
+__device__ __forceinline__ int jcomps(double) { return 1; }
+__device__ __forceinline__ double &jcomp(Jet &a, int k) { return (&a.v)[k]; }
+__device__ __forceinline__ double &jcomp(double &a, int) { return a; }
+static_assert(sizeof(Jet) == 6*sizeof(double), "jet components are addressed as an array");
+
+/* LU factorisation with partial pivoting (in place; false = singular) and the solve with it */
+__device__ inline bool lu_factor(int n, double (&A)[COLL_MAX][COLL_MAX], int (&piv)[COLL_MAX])
+{
+    for (int c = 0; c < n; c++) {
+        int p = c; double big = fabs(A[c][c]);
+        for (int r = c + 1; r < n; r++) if (fabs(A[r][c]) > big) { big = fabs(A[r][c]); p = r; }
+        if (!(big > 0)) return false;
+        piv[c] = p;
+        if (p != c) for (int m = 0; m < n; m++) { const double x = A[c][m]; A[c][m] = A[p][m]; A[p][m] = x; }
+        for (int r = c + 1; r < n; r++) {
+            A[r][c] /= A[c][c];
+            for (int m = c + 1; m < n; m++) A[r][m] -= A[r][c]*A[c][m];
+        }
+    }
+    return true;
+}
+__device__ inline void lu_solve(int n, const double (&A)[COLL_MAX][COLL_MAX], const int (&piv)[COLL_MAX], double (&x)[COLL_MAX])
+{
+    for (int c = 0; c < n; c++) if (piv[c] != c) { const double y = x[c]; x[c] = x[piv[c]]; x[piv[c]] = y; }
+    for (int c = 0; c < n; c++) for (int r = c + 1; r < n; r++) x[r] -= A[r][c]*x[c];
+    for (int c = n - 1; c >= 0; c--) {
+        for (int m = c + 1; m < n; m++) x[c] -= A[c][m]*x[m];
+        x[c] /= A[c][c];
+    }
+}
+/* the same solve for the components first..last of an array of jets (or of doubles: component 0 only) */
+template <class T>
+__device__ inline void lu_solve_comps(int n, const double (&A)[COLL_MAX][COLL_MAX], const int (&piv)[COLL_MAX], T (&R)[COLL_MAX], int first)
+{
+    double x[COLL_MAX];
+    const int last = jcomps(R[0]);
+    for (int k = first; k < last; k++) {
+        for (int j = 0; j < n; j++) x[j] = jcomp(R[j], k);
+        lu_solve(n, A, piv, x);
+        for (int j = 0; j < n; j++) jcomp(R[j], k) = x[j];
+    }
+}
+
+/*
+ * casadi.simpleIRK(ode, numSteps, d, scheme, 'fast_newton') over [0, H] (train.py:310): per step of length dt = H/numSteps the d stage
+ * values v solve  dt f(v_j) - (C[0][j] x + sum_r C[r][j] v_r) = 0  (x = start of the step; first guess v_j = x), the step ends at
+ * D[0] x + sum_r D[r] v_r.  Newton's method runs on the values (at most OptionsIRK.maxIter iterations; like error_on_fail = False the
+ * last iterate is used).  The derivatives follow from the implicit-function theorem, applied as two Newton corrections in jet
+ * arithmetic with the Jacobian at the converged values: the first makes the first derivatives exact, the second the second ones.
+ * t != nullptr: the time equation dt/dsigma = ds/sqrt(b) is integrated along (numApproxSteps = 0); its stage equations are linear in
+ * the time stages.  tab: C[(d+1)*(d+1)] row r column j, then D[d+1] (device memory).
+ */
+template <class T>
+__device__ inline T irk_b(const DevProb &P, T b0, T w, double G, double ds, double H, T *t)
+{
+    const int d = P.collD, ld = d + 1;
+    const double *C = P.coll, *D = P.coll + ld*ld;
+    const double dt = H/P.numSteps, wv = jval(w);
+    T xb = b0, xt = t ? *t : jconst(T(), 0.0);
+    for (int k = 0; k < P.numSteps; k++) {
+        double v[COLL_MAX], A[COLL_MAX][COLL_MAX], F[COLL_MAX];
+        int piv[COLL_MAX];
+        const double xv = jval(xb);
+        for (int j = 0; j < d; j++) v[j] = xv;
+        for (int it = 0; it <= P.newtonIters; it++) {
+            double fmaxabs = 0;
+            for (int j = 0; j < d; j++) {
+                const double sv = sqrt(v[j]);
+                const double f = 2*ds*(wv - (P.sr0 + P.sr1*sv + P.sr2*v[j]) - G), df = -2*ds*(0.5*P.sr1/sv + P.sr2);
+                double p = C[j + 1]*xv;
+                for (int r = 0; r < d; r++) { p += C[(r + 1)*ld + j + 1]*v[r]; A[j][r] = -C[(r + 1)*ld + j + 1]; }
+                A[j][j] += dt*df;
+                F[j] = dt*f - p;
+                fmaxabs = fmax(fmaxabs, fabs(F[j]));
+            }
+            /* the Jacobian of the last pass is the one the derivatives use */
+            if (!lu_factor(d, A, piv)) break;
+            if (it == P.newtonIters || !isfinite(fmaxabs) || fmaxabs <= 1e-13*fmax(1.0, fabs(xv))) break;
+            lu_solve(d, A, piv, F);
+            for (int j = 0; j < d; j++) v[j] -= F[j];
+        }
+        T V[COLL_MAX], R[COLL_MAX];
+        for (int j = 0; j < d; j++) V[j] = jconst(T(), v[j]);
+        if (jcomps(xb) > 1) {
+            for (int pass = 0; pass < 2; pass++) {
+                for (int j = 0; j < d; j++) {
+                    T p = xb*C[j + 1];
+                    for (int r = 0; r < d; r++) p = p + V[r]*C[(r + 1)*ld + j + 1];
+                    R[j] = ode_b(P, V[j], w, G, ds)*dt - p;
+                }
+                lu_solve_comps(d, A, piv, R, 1);
+                for (int j = 0; j < d; j++) { jcomp(R[j], 0) = 0.0; V[j] = V[j] - R[j]; }
+            }
+        }
+        T nb = xb*D[0];
+        for (int r = 0; r < d; r++) nb = nb + V[r]*D[r + 1];
+        if (t) {
+            /* sum_r C[r][j] vt_r = dt ds/sqrt(V_j) - C[0][j] xt */
+            double M[COLL_MAX][COLL_MAX];
+            int pm[COLL_MAX];
+            for (int j = 0; j < d; j++) for (int r = 0; r < d; r++) M[j][r] = C[(r + 1)*ld + j + 1];
+            lu_factor(d, M, pm);
+            for (int j = 0; j < d; j++) R[j] = xrecip(xsqrt(V[j]))*(dt*ds) - xt*C[j + 1];
+            lu_solve_comps(d, M, pm, R, 0);
+            T nt = xt*D[0];
+            for (int r = 0; r < d; r++) nt = nt + R[r]*D[r + 1];
+            xt = nt;
+        }
+        xb = nb;
+    }
+    if (t) *t = xt;
+    return xb;
+}
+
+/*
+ * (t, b) over the unit interval to the tolerances of OptionsCVODES (train.py:312-322, :521-534): Dormand-Prince 5(4), step-size
+ * control on the values; the derivatives are those of the accepted steps (the discrete map), carried in jet arithmetic.
+ */
+template <class T>
+__device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds, T &tau, T &bplus)
+{
+    constexpr double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                     a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                     a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                     b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                     e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+    T yt = jconst(T(), 0.0), yb = b0;
+    T kt[7], kb[7];
+    auto rhs = [&](const T &bj, T &ot, T &ob) { ot = xrecip(xsqrt(bj))*ds; ob = ode_b(P, bj, w, G, ds); };
+    double sig = 0, h = 0.05;
+    rhs(yb, kt[0], kb[0]);
+    for (int step = 0; step < 100000 && sig < 1.0; step++) {
+        if (sig + h > 1.0) h = 1.0 - sig;
+        T s;
+        s = yb + kb[0]*(h*a21); rhs(s, kt[1], kb[1]);
+        s = (yb + kb[0]*(h*a31)) + kb[1]*(h*a32); rhs(s, kt[2], kb[2]);
+        s = ((yb + kb[0]*(h*a41)) + kb[1]*(h*a42)) + kb[2]*(h*a43); rhs(s, kt[3], kb[3]);
+        s = (((yb + kb[0]*(h*a51)) + kb[1]*(h*a52)) + kb[2]*(h*a53)) + kb[3]*(h*a54); rhs(s, kt[4], kb[4]);
+        s = ((((yb + kb[0]*(h*a61)) + kb[1]*(h*a62)) + kb[2]*(h*a63)) + kb[3]*(h*a64)) + kb[4]*(h*a65); rhs(s, kt[5], kb[5]);
+        const T nt = ((((yt + kt[0]*(h*b1)) + kt[2]*(h*b3)) + kt[3]*(h*b4)) + kt[4]*(h*b5)) + kt[5]*(h*b6);
+        const T nb = ((((yb + kb[0]*(h*b1)) + kb[2]*(h*b3)) + kb[3]*(h*b4)) + kb[4]*(h*b5)) + kb[5]*(h*b6);
+        const bool finite = isfinite(jval(nt)) && isfinite(jval(nb)) && jval(nb) > 0;
+        double err = 0;
+        if (finite) {
+            rhs(nb, kt[6], kb[6]);
+            const double sct = P.intAtol + P.intRtol*fmax(fabs(jval(yt)), fabs(jval(nt))), scb = P.intAtol + P.intRtol*fmax(fabs(jval(yb)), fabs(jval(nb)));
+            const double et = h*(e1*jval(kt[0]) + e3*jval(kt[2]) + e4*jval(kt[3]) + e5*jval(kt[4]) + e6*jval(kt[5]) + e7*jval(kt[6]));
+            const double eb = h*(e1*jval(kb[0]) + e3*jval(kb[2]) + e4*jval(kb[3]) + e5*jval(kb[4]) + e6*jval(kb[5]) + e7*jval(kb[6]));
+            err = fmax(fabs(et/sct), fabs(eb/scb));
+        }
+        if (finite && (err <= 1.0 || h < 1e-14)) {
+            sig += h;
+            yt = nt; yb = nb; kt[0] = kt[6]; kb[0] = kb[6];     /* first same as last */
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-300) break;
+    }
+    tau = yt; bplus = yb;
+}
+
+/* one shooting interval with the integrator the problem names (P.integ: MSD_INTEGRATOR_ADAPTIVE or MSD_INTEGRATOR_COLLOCATION) */
+template <class T>
+__device__ inline void interval_map_general(const DevProb &P, double b0, double w0, double G, double ds, T &tau, T &bplus)
+{
+    const T b = make_var(T(), b0, 0), w = make_var(T(), w0, 1);
+    if (P.integ == MSD_INTEGRATOR_ADAPTIVE) { dopri_tb<T>(P, b, w, G, ds, tau, bplus); return; }     /* train.py:314: time integrated along */
+    if (P.numApprox == 0) {
+        T t = jconst(T(), 0.0);
+        bplus = irk_b<T>(P, b, w, G, ds, 1.0, &t);
+        tau = t;
+        return;
+    }
+    const int ns = P.numApprox;                                   /* train.py:324-344 */
+    T prev = b, acc = jconst(T(), 0.0);
+    for (int j = 1; j <= ns; j++) {
+        const T cur = irk_b<T>(P, b, w, G, ds, (double)j/ns, (T *)nullptr);
+        acc = acc + xrecip(xsqrt(prev) + xsqrt(cur))*(2*ds*((double)j/ns - (double)(j - 1)/ns));
+        prev = cur;
+    }
+    tau = acc; bplus = prev;
+}

@@ -111,6 +111,11 @@ struct DevProb {
                               * problem = node dualShift of the recorded one */
     long long dualInStride;
     int dualShift;
+    /* integrator of the shooting intervals other than the explicit Runge-Kutta map (kernels instantiated with GEN; msd_integ.hpp) */
+    int integ;               /* 0, MSD_INTEGRATOR_ADAPTIVE or MSD_INTEGRATOR_COLLOCATION */
+    int collD, newtonIters;  /* collocation points per step, Newton iterations (OptionsIRK.order, .maxIter) */
+    double intAtol, intRtol; /* OptionsCVODES.absTol, .relTol */
+    const double *coll;      /* C[(collD+1)^2], D[collD+1] of casadi.simpleIRK */
 };
 
 /* IPOPT default option values */
@@ -245,6 +250,8 @@ template <class T> __device__ __forceinline__ void interval_map(const DevProb &P
     }
     tau = acc; bplus = prev;
 }
+
+#include "msd_integ.hpp"
 
 /* ------------------------------------------------------------------------------------------
  * dynamic loss model (reference: mseetc/efficiency.py:7-141 with utils.py:197-220 and train.py:214-217).
@@ -583,7 +590,8 @@ __device__ __forceinline__ void opaque_a(double &v) { asm volatile("" : "+a"(v))
 __device__ __forceinline__ void opaque_z(double &v) { if (MSD_FENCE_AGPR >= 1) opaque_a(v); else opaque(v); }
 __device__ __forceinline__ void opaque_d(double &v) { if (MSD_FENCE_AGPR >= 2) opaque_a(v); else opaque(v); }
 
-/* a workgroup-uniform double into scalar registers */
+/* a workgroup-uniform value into scalar registers */
+__device__ __forceinline__ int wg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v)
 {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -599,20 +607,20 @@ struct Ev {
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
-template <bool DERIV, bool DYN>
+template <bool DERIV, bool DYN, bool GEN>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
                                               double (&cv)[2], double (&dv)[NR], Ev &e)
 {
     const double b = x[VB], f = x[VF], p = P.withPn ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
-        interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
+        if (GEN) interval_map_general<Jet>(P, b, f + p, nG, nds, tau, bp); else interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau.v); cv[1] = b1 - bp.v;
         e.tb = tau.g0; e.tw = tau.g1; e.tbb = tau.h00; e.tbw = tau.h01; e.tww = tau.h11;
         e.Bb = bp.g0; e.Bw = bp.g1; e.Bbb = bp.h00; e.Bbw = bp.h01; e.Bww = bp.h11;
     } else {
         double tau, bp;
-        interval_map<double>(P, b, f + p, nG, nds, tau, bp);
+        if (GEN) interval_map_general<double>(P, b, f + p, nG, nds, tau, bp); else interval_map<double>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau); cv[1] = b1 - bp;
     }
     const double sb = sqrt(b), sb1 = sqrt(b1);
@@ -1249,7 +1257,7 @@ struct ParallelRiccati {
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int NT, int SPT, bool DYN, bool STREAM>
+template <int NT, int SPT, bool DYN, bool STREAM, bool GEN>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -1886,7 +1894,7 @@ struct Solver {
             double prod = 1.0;
             if (nd.ival()) {
                 double cv[2], dv[NR]; Ev dummy;
-                eval_interval<false, DYN>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
+                eval_interval<false, DYN, GEN>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
                 th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
@@ -1931,7 +1939,7 @@ struct Solver {
             for (int r = 0; r < NR; r++) td[j][r] = 0;
             if (n[j].ival()) {
                 double dv[NR]; Ev dummy;
-                eval_interval<false, DYN>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
+                eval_interval<false, DYN, GEN>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
 #pragma unroll
                 for (int r = 0; r < NR; r++) td[j][r] = U.rowOn[r] ? dv[r] - st[j][r] : 0.0;
             }
@@ -1953,7 +1961,7 @@ struct Solver {
                 Ev ej;
 #pragma unroll
                 for (int k = 0; k < NV; k++) xl[k] = n[j].x[k];
-                eval_interval<true, DYN>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
+                eval_interval<true, DYN, GEN>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
                 resc[j][0] = cv[0]; resc[j][1] = cv[1];
 #pragma unroll
                 for (int r = 0; r < NR; r++) resd[j][r] = U.rowOn[r] ? dv[r] - n[j].sg[r] : 0.0;
@@ -2183,16 +2191,21 @@ struct Solver {
         }
         commit_uniforms(u);
 
-        /* ---- push into the interior, slacks, bound multipliers ---- */
+        /* ---- push into the interior, slacks, bound multipliers.  Primal-dual warm start: constraint multipliers as recorded, bound and
+         *      slack multipliers too but not below 1e-3 of their central-path value mu/slack at the pushed point (a multiplier that was
+         *      zero must be able to grow) ---- */
+        const bool dualStart = ext && dual_in != nullptr;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence();
+            const double *q = dualStart ? dual_in + (size_t)MSD_DUAL_STRIDE*n[j].i : nullptr;
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 if (!n[j].on(k)) continue;
                 n[j].x[k] = push_in(n[j].x[k], lbv(k), ubv(j, k), true, hasU(k), kp);
                 n[j].zL[k] = warm ? mu_start/(n[j].x[k] - lbv(k)) : 1.0;
                 n[j].zU[k] = hasU(k) ? (warm ? mu_start/(ubv(j, k) - n[j].x[k]) : 1.0) : 0.0;
+                if (dualStart) { n[j].zL[k] = fmax(q[7 + k], 1e-3*n[j].zL[k]); if (hasU(k)) n[j].zU[k] = fmax(q[12 + k], 1e-3*n[j].zU[k]); }
             }
         }
         evaluate_current();     /* resd = d(x) since the slacks are still zero */
@@ -2208,44 +2221,26 @@ struct Solver {
                 n[j].zUs[r] = U.rU[r] ? (warm ? mu_start/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
                 resd[j][r] -= n[j].sg[r];
             }
-        }
-
-        double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
-
-        /* ---- primal-dual warm start: constraint multipliers as recorded, bound and slack multipliers too but not below 1e-3 of
-         *      their central-path value mu/slack at the pushed point (a multiplier that was zero must be able to grow) ---- */
-        const bool dualStart = ext && dual_in != nullptr;
-        if (dualStart) {
-#pragma unroll
-            for (int j = 0; j < SPT; j++) {
-                node_fence();
-                NodeT &nd = n[j];
-                if (!nd.node()) continue;
-                const double *q = dual_in + (size_t)MSD_DUAL_STRIDE*nd.i;
-#pragma unroll
-                for (int k = 0; k < NV; k++) {
-                    if (!nd.on(k)) continue;
-                    nd.zL[k] = fmax(q[7 + k], 1e-3*mu_start/(nd.x[k] - lbv(k)));
-                    if (hasU(k)) nd.zU[k] = fmax(q[12 + k], 1e-3*mu_start/(ubv(j, k) - nd.x[k]));
-                }
-                if (!nd.ival()) continue;
-                nd.lam[0] = q[0]; nd.lam[1] = q[1];
+            if (dualStart) {
+                const double *q = dual_in + (size_t)MSD_DUAL_STRIDE*n[j].i;
+                n[j].lam[0] = q[0]; n[j].lam[1] = q[1];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     if (!U.rowOn[r]) continue;
-                    nd.nu[r] = q[2 + r];
-                    if (U.rL[r]) nd.zLs[r] = fmax(q[17 + r], 1e-3*mu_start/(nd.sg[r] - U.dL[r]));
-                    if (U.rU[r]) nd.zUs[r] = fmax(q[22 + r], 1e-3*mu_start/(U.dU[r] - nd.sg[r]));
+                    n[j].nu[r] = q[2 + r];
+                    if (U.rL[r]) n[j].zLs[r] = fmax(q[17 + r], 1e-3*n[j].zLs[r]);
+                    if (U.rU[r]) n[j].zUs[r] = fmax(q[22 + r], 1e-3*n[j].zUs[r]);
                 }
             }
         }
 
+        double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
+
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
-        bool lsq = !dualStart;
+        if (!dualStart)
 #if MSD_PROFILE_SKIP_LSQ
-        if (!ext && startKind == MSD_START_PROFILE) lsq = false;
+        if (ext || startKind != MSD_START_PROFILE)
 #endif
-        if (lsq)
         {
             const bool ok = direction(MODE_LSQ, 0.0, 0.0);
             double lmax = 0;
@@ -2574,7 +2569,7 @@ struct Solver {
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
  * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT, int SPT, int WPS, bool DYN, bool STREAM = false>
+template <int NT, int SPT, int WPS, bool DYN, bool STREAM = false, bool GEN = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
@@ -2614,7 +2609,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             __syncthreads();
             if (c.tid == 0) c.misc[MISC_NEXT] = (double)atomicAdd(P.queue, 1);
             __syncthreads();
-            sidx = (int)c.misc[MISC_NEXT];
+            sidx = wg_uniform((int)c.misc[MISC_NEXT]);     /* scalar: every pointer derived from it stays out of the vector registers */
         } else sidx = blockIdx.x + turn*gridDim.x;
         if (sidx >= nscen) break;
         /* per-scenario rolling stock (uniform over the workgroup) */
@@ -2628,7 +2623,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         __syncthreads();
         if (c.tid == 0) *Pl = Ps;
         __syncthreads();
-        Solver<NT, SPT, DYN, STREAM> s(*Pl, c, wg_work, *Ul);
+        Solver<NT, SPT, DYN, STREAM, GEN> s(*Pl, c, wg_work, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
         const double *dual_in = (guess && P.dualIn) ? P.dualIn + (size_t)P.dualInStride*sidx + (size_t)MSD_DUAL_STRIDE*P.dualShift : nullptr;
@@ -2657,7 +2652,8 @@ __global__ void stage_eval_kernel(DevProb P, int n, const double *b, const doubl
     int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
     Jet tau, bp;
-    interval_map<Jet>(P, b[k], w[k], track_resistance(P, grad[k], curv[k]), ds[k], tau, bp);
+    if (P.integ) interval_map_general<Jet>(P, b[k], w[k], track_resistance(P, grad[k], curv[k]), ds[k], tau, bp);
+    else interval_map<Jet>(P, b[k], w[k], track_resistance(P, grad[k], curv[k]), ds[k], tau, bp);
     double *o = out + 12*(size_t)k;
     o[0] = tau.v; o[1] = bp.v; o[2] = tau.g0; o[3] = tau.g1; o[4] = bp.g0; o[5] = bp.g1;
     o[6] = tau.h00; o[7] = tau.h01; o[8] = tau.h11; o[9] = bp.h00; o[10] = bp.h01; o[11] = bp.h11;

@@ -1,0 +1,27 @@
+/* solve-kernel instantiations with the collocation and adaptive shooting integrators (static loss models); see msd_geometry.hpp */
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "msd_geometry.hpp"
+
+namespace msd {
+
+/* kernels that carry the collocation and the adaptive shooting integrators (msd_integ.hpp) */
+Geometry pick_geometry_general(int N)
+{
+    const int nodes = N + 1;
+    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, false, false, true>};
+    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, false, false, true>};
+    if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, false, false, true>};
+#ifdef MSD_MINIMAL_GEOMETRIES
+    return {0, 0, nullptr};
+#endif
+    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, false, false, true>};
+    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, false, false, true>};
+    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, false, false, true>};
+    return {0, 0, nullptr};
+}
+
+}  // namespace msd

@@ -14,7 +14,8 @@ import numpy as np
 
 LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+INTEGRATOR_ADAPTIVE, INTEGRATOR_COLLOCATION = 1, 2     # MSD_INTEGRATOR_* (also the methods of msd_interval_integrate)
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, COUNT=14)
 SC_COUNT = 4
 OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, TOTAL_MASS=9, COUNT=10)
@@ -37,14 +38,15 @@ class ProblemDesc(ctypes.Structure):
     _fields_ = [('abi_version', ctypes.c_int), ('num_intervals', ctypes.c_int), ('with_pn_brake', ctypes.c_int),
                 ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
                 ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
-                ('start_kind', ctypes.c_int), ('reserved_i', ctypes.c_int*6),
+                ('start_kind', ctypes.c_int), ('integrator', ctypes.c_int), ('coll_degree', ctypes.c_int), ('newton_iterations', ctypes.c_int),
+                ('reserved_i', ctypes.c_int*3),
                 ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
                 ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
                 ('loss_ct', ctypes.c_double), ('loss_cr', ctypes.c_double), ('vmin_sq', ctypes.c_double), ('obj_den', ctypes.c_double),
-                ('tol', ctypes.c_double), ('reserved_d', ctypes.c_double*7),
+                ('tol', ctypes.c_double), ('int_abstol', ctypes.c_double), ('int_reltol', ctypes.c_double), ('reserved_d', ctypes.c_double*5),
                 ('ds', _dptr), ('grad', _dptr), ('curv', _dptr), ('bmax', _dptr),
-                ('loss_table', _dptr), ('loss_table_len', ctypes.c_int), ('reserved_tail', ctypes.c_int)]
+                ('loss_table', _dptr), ('loss_table_len', ctypes.c_int), ('reserved_tail', ctypes.c_int), ('coll_tables', _dptr)]
 
 
 class DeviceError(RuntimeError):
@@ -126,8 +128,12 @@ START = dict(reference=0, profile=1)   # MSD_START_*
 
 
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
-              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference'):
-    "Fill a ProblemDesc; the numpy arrays are kept alive on the returned object."
+              pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference',
+              integrator=None):
+    """
+    Fill a ProblemDesc; the numpy arrays are kept alive on the returned object.  integrator: None ('RK'), ('CVODES', absTol, relTol) or
+    ('IRK', order, maxIter, C, D) with the tables of mseetc.train.collocationTables.
+    """
 
     d = ProblemDesc()
     d.abi_version = ABI_VERSION
@@ -144,6 +150,14 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
     if lossTable is not None:
         keep.append(np.ascontiguousarray(lossTable, dtype=np.float64))
         d.loss_table, d.loss_table_len = _d(keep[-1]), len(keep[-1])
+    if integrator is not None and integrator[0] == 'CVODES':
+        d.integrator, d.int_abstol, d.int_reltol = INTEGRATOR_ADAPTIVE, float(integrator[1]), float(integrator[2])
+    elif integrator is not None and integrator[0] == 'IRK':
+        d.integrator, d.coll_degree, d.newton_iterations = INTEGRATOR_COLLOCATION, int(integrator[1]), int(integrator[2])
+        keep.append(np.concatenate([np.asarray(integrator[3], dtype=np.float64).ravel(), np.asarray(integrator[4], dtype=np.float64).ravel()]))
+        d.coll_tables = _d(keep[-1])
+    elif integrator is not None:
+        raise ValueError("Unknown integration method!")
     d._keep = keep
 
     return d

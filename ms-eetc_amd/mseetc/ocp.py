@@ -13,7 +13,7 @@ scenarios of the same (train, track, options) in one launch.
 import numpy as np
 import pandas as pd
 
-from .train import OptionsRK, OptionsIRK, OptionsCVODES
+from .train import OptionsRK, OptionsIRK, OptionsCVODES, collocationTables
 from .track import computeDiscretizationPoints
 from .utils import Options, classifyLosses, postProcessDataFrame, LOSS_NONE, LOSS_DYNAMIC
 from . import _device
@@ -27,7 +27,7 @@ class OptionsCasadiSolver(Options):
         self.maxIterations = 1e3          # interior-point iteration limit (a float in the reference, too)
         self.energyOptimal = True         # objective: traction energy [kWh] (True) or running time [s] (False)
         self.minimumVelocity = 1          # m/s; speeds are bounded below by it (b = v^2 stays away from 0)
-        self.integrationMethod = 'RK'     # transcription of the interval dynamics: 'RK' | 'IRK' | 'CVODES' (the device runs 'RK')
+        self.integrationMethod = 'RK'     # transcription of the interval dynamics: 'RK' | 'IRK' | 'CVODES'
         self.integrationOptions = {}      # options of that method (OptionsRK / OptionsIRK / OptionsCVODES)
         self.integrateLosses = False      # loss slack from the integrated loss power instead of the mid-point rule
 
@@ -91,11 +91,9 @@ class casadiSolver():
 
         opts = OptionsCasadiSolver(optsDict)
 
-        if opts.integrationMethod != 'RK':
-            raise NotImplementedError("Only the explicit Runge-Kutta transcription runs on the device.")
-
         if opts.integrateLosses:
-            raise NotImplementedError("integrateLosses=True is outside the device hot path.")
+            raise NotImplementedError("integrateLosses=True (loss slacks from a time-domain integration inside the NLP, ocp.py:231-241) is not "
+                                      "transcribed on the device; postProcessDataFrame(integrateLosses=True) integrates the losses of a solution.")
 
         N = int(opts.numIntervals)
 
@@ -145,12 +143,27 @@ class casadiSolver():
         model = train.exportModel()
         io = opts.integrationOptions
 
+        # shooting integrator (ocp.py:92, train.py:294-322)
+        if opts.integrationMethod == 'IRK':
+            C, D = collocationTables(io.order, io.collMethod)
+            integrator = ('IRK', io.order, io.maxIter, C, D)
+        elif opts.integrationMethod == 'CVODES':
+            integrator = ('CVODES', io.absTol, io.relTol)
+        else:
+            integrator = None
+
+        if integrator is not None and lossKind == LOSS_DYNAMIC:
+            raise NotImplementedError("The 'IRK' and 'CVODES' transcriptions run with constant efficiencies; the dynamic loss model needs 'RK'.")
+
+        numSteps = io.numSteps if opts.integrationMethod != 'CVODES' else 1
+        numApproxSteps = io.numApproxSteps if opts.integrationMethod != 'CVODES' else 0     # train.py:314
+
         self._desc = _device.make_desc(
-            N, withPnBrake, hasPower, opts.energyOptimal, io.numSteps, io.numApproxSteps, lossKind, int(opts.maxIterations),
+            N, withPnBrake, hasPower, opts.energyOptimal, numSteps, numApproxSteps, lossKind, int(opts.maxIterations),
             (model.sr0, model.sr1, model.sr2), train.g, rho, forceMax, forceMin if withRgBrake else 0.0, forceMinPn,
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
             self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
-            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint)
+            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint, integrator=integrator)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU

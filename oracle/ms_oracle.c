@@ -180,6 +180,8 @@ static const int var2loc[NV] = {LT, LB, LF, LP, LS};
 
 typedef struct {
     int N, withPn, hasPower, energyOpt, numSteps, numApprox, lossKind, maxIter;
+    int integ, collD, newtonIters;
+    double intAtol, intRtol;
     const double *ds, *grad, *curv, *bmax;
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     double t0, tEnd, v0sq, vNsq;
@@ -190,6 +192,8 @@ static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds
 {
     P->N = ip[OR_IP_N]; P->withPn = ip[OR_IP_WITH_PN]; P->hasPower = ip[OR_IP_HAS_POWER]; P->energyOpt = ip[OR_IP_ENERGY_OPT];
     P->numSteps = ip[OR_IP_NUM_STEPS]; P->numApprox = ip[OR_IP_NUM_APPROX]; P->lossKind = ip[OR_IP_LOSS_KIND]; P->maxIter = ip[OR_IP_MAX_ITER];
+    P->integ = ip[OR_IP_INTEGRATOR]; P->collD = ip[OR_IP_COLL_DEGREE]; P->newtonIters = ip[OR_IP_NEWTON_ITERS];
+    P->intAtol = dp[OR_DP_INT_ATOL]; P->intRtol = dp[OR_DP_INT_RTOL];
     P->ds = ds; P->grad = grad; P->curv = curv; P->bmax = bmax;
     P->sr0 = dp[OR_DP_SR0]; P->sr1 = dp[OR_DP_SR1]; P->sr2 = dp[OR_DP_SR2]; P->g = dp[OR_DP_G]; P->rho = dp[OR_DP_RHO];
     P->fmax = dp[OR_DP_FMAX]; P->fmin = dp[OR_DP_FMIN]; P->fminPn = dp[OR_DP_FMIN_PN];
@@ -230,6 +234,170 @@ static jet rk4_b(const Prob *P, jet b, jet w, double G, double ds, double H)
     return b;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * the other two integrators TrainIntegrator offers for the shooting intervals (train.py:303-322)
+ * ---------------------------------------------------------------------------------------- */
+#define COLL_MAX 9
+static int g_coll_d = 0;
+static double g_coll_C[(COLL_MAX + 1)*(COLL_MAX + 1)], g_coll_D[COLL_MAX + 1];
+void oracle_set_collocation(int d, const double *C, const double *D)
+{
+    if (d < 1 || d > COLL_MAX) { g_coll_d = 0; return; }
+    g_coll_d = d;
+    memcpy(g_coll_C, C, sizeof(double)*(d + 1)*(d + 1));
+    memcpy(g_coll_D, D, sizeof(double)*(d + 1));
+}
+
+/* LU factorisation with partial pivoting (in place) and the solve with it; 0 = singular */
+static int lu_factor(int n, double A[COLL_MAX][COLL_MAX], int piv[COLL_MAX])
+{
+    for (int c = 0; c < n; c++) {
+        int p = c; double big = fabs(A[c][c]);
+        for (int r = c + 1; r < n; r++) if (fabs(A[r][c]) > big) { big = fabs(A[r][c]); p = r; }
+        if (!(big > 0)) return 0;
+        piv[c] = p;
+        if (p != c) for (int m = 0; m < n; m++) { double x = A[c][m]; A[c][m] = A[p][m]; A[p][m] = x; }
+        for (int r = c + 1; r < n; r++) {
+            A[r][c] /= A[c][c];
+            for (int m = c + 1; m < n; m++) A[r][m] -= A[r][c]*A[c][m];
+        }
+    }
+    return 1;
+}
+static void lu_solve(int n, double A[COLL_MAX][COLL_MAX], const int piv[COLL_MAX], double x[COLL_MAX])
+{
+    for (int c = 0; c < n; c++) if (piv[c] != c) { double y = x[c]; x[c] = x[piv[c]]; x[piv[c]] = y; }
+    for (int c = 0; c < n; c++) for (int r = c + 1; r < n; r++) x[r] -= A[r][c]*x[c];
+    for (int c = n - 1; c >= 0; c--) {
+        for (int m = c + 1; m < n; m++) x[c] -= A[c][m]*x[m];
+        x[c] /= A[c][c];
+    }
+}
+/* the same solve for every derivative component of an array of jets (the values are left alone) */
+static void lu_solve_jets(int n, double A[COLL_MAX][COLL_MAX], const int piv[COLL_MAX], jet R[COLL_MAX], int with_value)
+{
+    double x[COLL_MAX];
+    for (int comp = with_value ? 0 : 1; comp < 6; comp++) {
+        for (int j = 0; j < n; j++) x[j] = (&R[j].v)[comp];
+        lu_solve(n, A, piv, x);
+        for (int j = 0; j < n; j++) (&R[j].v)[comp] = x[j];
+    }
+}
+
+/*
+ * casadi.simpleIRK(ode, numSteps, d, scheme, 'fast_newton') over [0, H] (train.py:310): per step of length dt = H/numSteps the d
+ * stage values v solve  dt f(v_j) - (C[0][j] x + sum_r C[r][j] v_r) = 0  (x = start of the step; initial guess v_j = x) and the
+ * step ends at D[0] x + sum_r D[r] v_r.  Newton's method runs on the values (at most OptionsIRK.maxIter iterations; like
+ * error_on_fail = False the last iterate is used); the derivatives follow from the implicit-function theorem, applied as two
+ * Newton corrections in jet arithmetic with the Jacobian at the converged values (the first makes the first derivatives exact,
+ * the second the second derivatives).  t != NULL: the time equation dt/dsigma = ds/sqrt(b) is integrated along (numApproxSteps = 0);
+ * its stage equations are linear in the time stages.
+ */
+static jet irk_b(const Prob *P, jet b0, jet w, double G, double ds, double H, jet *t)
+{
+    const int d = g_coll_d, ld = d + 1;
+    const double *C = g_coll_C, *D = g_coll_D;
+    const double dt = H/P->numSteps;
+    jet xb = b0, xt = t ? *t : j_const(0);
+    for (int k = 0; k < P->numSteps; k++) {
+        double v[COLL_MAX], A[COLL_MAX][COLL_MAX], F[COLL_MAX];
+        int piv[COLL_MAX];
+        for (int j = 0; j < d; j++) v[j] = xb.v;
+        for (int it = 0; it <= P->newtonIters; it++) {
+            double fmaxabs = 0;
+            for (int j = 0; j < d; j++) {
+                const double sv = sqrt(v[j]);
+                const double f = 2*ds*(w.v - (P->sr0 + P->sr1*sv + P->sr2*v[j]) - G), df = -2*ds*(0.5*P->sr1/sv + P->sr2);
+                double p = C[0*ld + j + 1]*xb.v;
+                for (int r = 0; r < d; r++) { p += C[(r + 1)*ld + j + 1]*v[r]; A[j][r] = -C[(r + 1)*ld + j + 1]; }
+                A[j][j] += dt*df;
+                F[j] = dt*f - p;
+                fmaxabs = fmax(fmaxabs, fabs(F[j]));
+            }
+            /* the Jacobian of the last pass is the one the derivatives use */
+            if (!lu_factor(d, A, piv)) break;
+            if (it == P->newtonIters || !isfinite(fmaxabs) || fmaxabs <= 1e-13*fmax(1.0, fabs(xb.v))) break;
+            lu_solve(d, A, piv, F);
+            for (int j = 0; j < d; j++) v[j] -= F[j];
+        }
+        jet V[COLL_MAX], R[COLL_MAX];
+        for (int j = 0; j < d; j++) V[j] = j_const(v[j]);
+        for (int pass = 0; pass < 2; pass++) {
+            for (int j = 0; j < d; j++) {
+                jet p = j_scale(xb, C[0*ld + j + 1]);
+                for (int r = 0; r < d; r++) p = j_axpy(C[(r + 1)*ld + j + 1], V[r], p);
+                R[j] = j_sub(j_scale(ode_b(P, V[j], w, G, ds), dt), p);
+            }
+            lu_solve_jets(d, A, piv, R, 0);
+            for (int j = 0; j < d; j++) { R[j].v = 0; V[j] = j_sub(V[j], R[j]); }
+        }
+        jet nb = j_scale(xb, D[0]);
+        for (int r = 0; r < d; r++) nb = j_axpy(D[r + 1], V[r], nb);
+        if (t) {
+            /* sum_r C[r][j] vt_r = dt ds/sqrt(V_j) - C[0][j] xt */
+            double M[COLL_MAX][COLL_MAX];
+            int pm[COLL_MAX];
+            for (int j = 0; j < d; j++) for (int r = 0; r < d; r++) M[j][r] = C[(r + 1)*ld + j + 1];
+            lu_factor(d, M, pm);
+            for (int j = 0; j < d; j++) R[j] = j_sub(j_scale(j_recip(j_sqrt(V[j])), dt*ds), j_scale(xt, C[0*ld + j + 1]));
+            lu_solve_jets(d, M, pm, R, 1);
+            jet nt = j_scale(xt, D[0]);
+            for (int r = 0; r < d; r++) nt = j_axpy(D[r + 1], R[r], nt);
+            xt = nt;
+        }
+        xb = nb;
+    }
+    if (t) *t = xt;
+    return xb;
+}
+
+/*
+ * Adaptive integration of (t, b) over the unit interval to the tolerances of OptionsCVODES (train.py:312-322 uses SUNDIALS' CVODES,
+ * a third-party code that is not available here): Dormand-Prince 5(4) with the usual step-size controller acting on the values;
+ * the derivatives are those of the accepted steps (the discrete map), carried in jet arithmetic.
+ */
+static void dopri_tb(const Prob *P, jet b0, jet w, double G, double ds, jet *tau, jet *bplus)
+{
+    static const double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                 a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                 a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                 b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                 e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+    jet y[2] = {j_const(0), b0}, k[7][2], yn[2];
+#define RHS(bj, out) do { (out)[0] = j_scale(j_recip(j_sqrt(bj)), ds); (out)[1] = ode_b(P, (bj), w, G, ds); } while (0)
+    double sig = 0, h = 0.05;
+    RHS(y[1], k[0]);
+    for (int step = 0; step < 100000 && sig < 1.0; step++) {
+        if (sig + h > 1.0) h = 1.0 - sig;
+        jet yb;
+        yb = j_axpy(h*a21, k[0][1], y[1]); RHS(yb, k[1]);
+        yb = j_axpy(h*a32, k[1][1], j_axpy(h*a31, k[0][1], y[1])); RHS(yb, k[2]);
+        yb = j_axpy(h*a43, k[2][1], j_axpy(h*a42, k[1][1], j_axpy(h*a41, k[0][1], y[1]))); RHS(yb, k[3]);
+        yb = j_axpy(h*a54, k[3][1], j_axpy(h*a53, k[2][1], j_axpy(h*a52, k[1][1], j_axpy(h*a51, k[0][1], y[1])))); RHS(yb, k[4]);
+        yb = j_axpy(h*a65, k[4][1], j_axpy(h*a64, k[3][1], j_axpy(h*a63, k[2][1], j_axpy(h*a62, k[1][1], j_axpy(h*a61, k[0][1], y[1]))))); RHS(yb, k[5]);
+        for (int m = 0; m < 2; m++)
+            yn[m] = j_axpy(h*b6, k[5][m], j_axpy(h*b5, k[4][m], j_axpy(h*b4, k[3][m], j_axpy(h*b3, k[2][m], j_axpy(h*b1, k[0][m], y[m])))));
+        const int finite = isfinite(yn[0].v) && isfinite(yn[1].v) && yn[1].v > 0;
+        double err = 0;
+        if (finite) {
+            RHS(yn[1], k[6]);
+            for (int m = 0; m < 2; m++) {
+                const double sc = P->intAtol + P->intRtol*fmax(fabs(y[m].v), fabs(yn[m].v));
+                err = fmax(err, fabs(h*(e1*k[0][m].v + e3*k[2][m].v + e4*k[3][m].v + e5*k[4][m].v + e6*k[5][m].v + e7*k[6][m].v)/sc));
+            }
+        }
+        if (finite && (err <= 1.0 || h < 1e-14)) {
+            sig += h;
+            for (int m = 0; m < 2; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }     /* first same as last */
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-300) break;
+    }
+#undef RHS
+    *tau = y[0]; *bplus = y[1];
+}
+
 /*
  * One shooting interval: tau = t+ - t and b+ as jets in (b, w), w = Fel + Fpb.
  * numApprox == 0: RK4 on (t, b) jointly (train.py:296-301, dt/ds = ds/sqrt(b) :255,258).
@@ -238,6 +406,14 @@ static jet rk4_b(const Prob *P, jet b, jet w, double G, double ds, double H)
 static void interval_map(const Prob *P, double b0, double w0, double G, double ds, jet *tau, jet *bplus)
 {
     jet b = j_var(b0, 0), w = j_var(w0, 1);
+
+    if (P->integ == 2) { dopri_tb(P, b, w, G, ds, tau, bplus); return; }       /* train.py:314: numApproxSteps = 0 */
+    if (P->integ == 1 && P->numApprox == 0) {
+        jet t = j_const(0);
+        *bplus = irk_b(P, b, w, G, ds, 1.0, &t);
+        *tau = t;
+        return;
+    }
 
     if (P->numApprox == 0) {
         double h = 1.0/P->numSteps;
@@ -264,7 +440,7 @@ static void interval_map(const Prob *P, double b0, double w0, double G, double d
     int ns = P->numApprox;
     jet prev = b, acc = j_const(0);
     for (int j = 1; j <= ns; j++) {
-        jet cur = rk4_b(P, b, w, G, ds, (double)j/ns);
+        jet cur = (P->integ == 1) ? irk_b(P, b, w, G, ds, (double)j/ns, NULL) : rk4_b(P, b, w, G, ds, (double)j/ns);
         /* 2*ds*(e_{j} - e_{j-1})/(v_{j-1} + v_j) */
         jet den = j_add(j_sqrt(prev), j_sqrt(cur));
         acc = j_add(acc, j_scale(j_recip(den), 2*ds*((double)j/ns - (double)(j - 1)/ns)));

@@ -53,6 +53,9 @@ enum {
     OR_IP_NUM_APPROX,     /* trapezoidal time sub-intervals (0: integrate time with RK4)     */
     OR_IP_LOSS_KIND,      /* 0 none, 1 static efficiencies, 2 dynamic table (oracle_set_loss_table)   */
     OR_IP_MAX_ITER,
+    OR_IP_INTEGRATOR,     /* shooting integrator (train.py:280-322): 0 simpleRK order 4, 1 simpleIRK (collocation), 2 adaptive (CVODES' role) */
+    OR_IP_COLL_DEGREE,    /* collocation points per step (OptionsIRK.order, train.py:485); tables via oracle_set_collocation */
+    OR_IP_NEWTON_ITERS,   /* OptionsIRK.maxIter (train.py:493)                               */
     OR_IP_COUNT
 };
 
@@ -72,6 +75,7 @@ enum {
     OR_DP_OBJ_DEN,        /* scalingFactorObjective (ocp.py:278,282)                         */
     OR_DP_TOL,            /* IPOPT tol (1e-8)                                                */
     OR_DP_T0, OR_DP_TEND, OR_DP_V0SQ, OR_DP_VNSQ,   /* scenario (already clipped, ocp.py:343-344) */
+    OR_DP_INT_ATOL, OR_DP_INT_RTOL,                 /* adaptive integrator: OptionsCVODES absTol, relTol (train.py:521-534) */
     OR_DP_COUNT
 };
 
@@ -112,6 +116,12 @@ int oracle_solve(const int *ip, const double *dp, const double *ds, const double
 int oracle_solve_warm(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                       const double *bmax, const double *guess, double mu0, double push,
                       double *z_out, double *lam_out, double *stats, double *hist, int hist_cap);
+
+/*
+ * Tables of casadi.simpleIRK for OR_IP_INTEGRATOR = 1: C[(d+1)*(d+1)] (row r, column j: derivative of the Lagrange polynomial r at point j)
+ * and D[d+1] (the polynomials at 1) on the points {0} + collocation points; copied (d <= 9).
+ */
+void oracle_set_collocation(int d, const double *C, const double *D);
 
 /* primal-dual warm start: multipliers of a node in OR_DUAL_STRIDE doubles -- lam (2), nu (5), zL (5), zU (5), zLs (5), zUs (5) */
 #define OR_DUAL_STRIDE 27

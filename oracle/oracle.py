@@ -18,9 +18,9 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 
-IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, COUNT=8)
+IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, INTEGRATOR=8, COLL_DEGREE=9, NEWTON_ITERS=10, COUNT=11)
 DP = dict(SR0=0, SR1=1, SR2=2, G=3, RHO=4, FMAX=5, FMIN=6, FMIN_PN=7, PW_UPPER=8, PW_LOWER=9, ACC_MIN=10, ACC_MAX=11,
-          LOSS_CT=12, LOSS_CR=13, VMIN_SQ=14, OBJ_DEN=15, TOL=16, T0=17, TEND=18, V0SQ=19, VNSQ=20, COUNT=21)
+          LOSS_CT=12, LOSS_CR=13, VMIN_SQ=14, OBJ_DEN=15, TOL=16, T0=17, TEND=18, V0SQ=19, VNSQ=20, INT_ATOL=21, INT_RTOL=22, COUNT=23)
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, COUNT=11)
 
 _lib = None
@@ -77,6 +77,8 @@ def lib():
         _lib.oracle_stage_eval.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
         _lib.oracle_set_loss_table.restype = None
         _lib.oracle_set_loss_table.argtypes = [dptr]
+        _lib.oracle_set_collocation.restype = None
+        _lib.oracle_set_collocation.argtypes = [ctypes.c_int, dptr, dptr]
         _lib.oracle_loss_rows.restype = None
         _lib.oracle_loss_rows.argtypes = [dptr, ctypes.c_double, ctypes.c_double, dptr]
         _lib.oracle_nlp_eval.restype = None
@@ -102,6 +104,17 @@ def set_loss_table(block):
     global _loss_keepalive
     _loss_keepalive = np.ascontiguousarray(block, dtype=np.float64)
     lib().oracle_set_loss_table(_d(_loss_keepalive))
+
+
+def set_collocation(C, D):
+    "Install the tables of the collocation integrator: C (d+1, d+1), D (d+1) on the points {0} + collocation points (copied)."
+
+    C = np.ascontiguousarray(C, dtype=np.float64)
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    lib().oracle_set_collocation(len(D) - 1, _d(C), _d(D))
+
+
+INTEGRATOR = dict(RK=0, IRK=1, CVODES=2)
 
 
 def loss_rows(block, f, v):
@@ -160,7 +173,9 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     """
     (train attribute bag, grid frame, option dict) -> Problem.
     `points`: DataFrame of computeDiscretizationPoints (index = positions).
-    `opts`: dict with numIntervals, maxIterations, energyOptimal, minimumVelocity, numSteps, numApproxSteps.
+    `opts`: dict with numIntervals, maxIterations, energyOptimal, minimumVelocity, numSteps, numApproxSteps and, for the other two
+    integrators of train.py:303-322, integrationMethod ('RK', 'IRK', 'CVODES'), order, maxIter, absTol, relTol (the collocation
+    tables go in through set_collocation).
     """
 
     N = int(opts['numIntervals'])
@@ -213,6 +228,11 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     ip[IP['NUM_APPROX']] = int(opts.get('numApproxSteps', 0))
     ip[IP['LOSS_KIND']] = int(lossKind)
     ip[IP['MAX_ITER']] = int(opts.get('maxIterations', 1000))
+    ip[IP['INTEGRATOR']] = INTEGRATOR[opts.get('integrationMethod', 'RK')]
+    ip[IP['COLL_DEGREE']] = int(opts.get('order', 0)) if ip[IP['INTEGRATOR']] == 1 else 0
+    ip[IP['NEWTON_ITERS']] = int(opts.get('maxIter', 10))
+    if ip[IP['INTEGRATOR']] == 2:
+        ip[IP['NUM_APPROX']] = 0     # train.py:314
 
     dp = np.zeros(DP['COUNT'])
     dp[DP['SR0']], dp[DP['SR1']], dp[DP['SR2']] = train.r0/totalMass, train.r1/totalMass, train.r2/totalMass
@@ -226,6 +246,7 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     dp[DP['VMIN_SQ']] = float(opts.get('minimumVelocity', 1))**2
     dp[DP['OBJ_DEN']] = objDen
     dp[DP['TOL']] = tol
+    dp[DP['INT_ATOL']], dp[DP['INT_RTOL']] = float(opts.get('absTol', 1e-8)), float(opts.get('relTol', 1e-6))
 
     grad = points['Gradient [permil]'].values[:N].astype(float)/1e3   # ocp.py:195
     curv = points['Curvature [1/m]'].values[:N].astype(float)         # ocp.py:196

@@ -45,10 +45,20 @@ def train_fig5():
     return train
 
 
-def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1):
+def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1, integration=None):
+    """
+    integration: None ('RK') or the reference's options of the other shooting integrators, e.g. dict(integrationMethod='IRK', order=2,
+    collMethod='radau', maxIter=10) / dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6).  The oracle keeps ONE set of
+    collocation tables (module state, like its loss table): the last problem packed with 'IRK' owns them.
+    """
     pts = computeDiscretizationPoints(track, N)
     opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal, minimumVelocity=vmin,
                 numSteps=numSteps, numApproxSteps=numApproxSteps)
+    if integration:
+        opts.update(integration)
+        if integration['integrationMethod'] == 'IRK':
+            from mseetc.train import collocationTables
+            oracle.set_collocation(*collocationTables(integration['order'], integration.get('collMethod', 'radau')))
     if losses == 'static':
         kind, ct, cr = 1, (1 - train.etaTraction)/train.etaTraction, 1 - train.etaRgBrake
     else:

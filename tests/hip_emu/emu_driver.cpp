@@ -16,7 +16,7 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT, int SPT, bool DYN, bool STREAM = false>
+template <int NT, int SPT, bool DYN, bool STREAM = false, bool GEN = false>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
@@ -31,7 +31,7 @@ static void run_blocks(msd::DevProb P, int nscen, const double *scen, const doub
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN, STREAM>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -68,8 +68,17 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax; P.loss = d->loss_table;
+    P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol; P.coll = d->coll_tables;
+    if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;
     const bool dyn = d->loss_kind == 2;
     const int nodes = P.N + 1;
+    if (d->integrator != 0) {       /* the kernels with the collocation / adaptive shooting integrators: two geometries are enough here */
+        if (dyn) return -3;
+        if (nodes <= 64) run_blocks<64, 1, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+        else if (nodes <= 128) run_blocks<64, 2, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+        else return -3;
+        return 0;
+    }
     const char *force = getenv("EMU_GEOMETRY");     /* "NTxSPT" to test other geometries */
     int NT = 0, SPT = 0;
     if (force) sscanf(force, "%dx%d", &NT, &SPT);

@@ -5,6 +5,7 @@ refuses -- loudly -- to solve without a device.  No compute call is made here.
 """
 
 import ctypes
+import subprocess
 import re
 from pathlib import Path
 
@@ -31,12 +32,21 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, n), n
 
 
-def test_desc_struct_matches_header(built):
-    # size of msd_problem_desc as laid out by ctypes == 16 ints + 24 doubles + 5 pointers + 2 ints (ABI version 2)
+def test_desc_struct_matches_header(built, tmp_path):
+    # the ctypes mirror against the C compiler's layout of the header: size and the offset of every field
     from mseetc._device import ProblemDesc, ABI_VERSION
-    assert ctypes.sizeof(ProblemDesc) == 16*4 + 24*8 + 5*8 + 2*4
     header = (ROOT / 'include' / 'mseetc_hip.h').read_text()
     assert '#define MSD_ABI_VERSION {}'.format(ABI_VERSION) in header
+    fields = [f[0] for f in ProblemDesc._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mseetc_hip.h"\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(msd_problem_desc));\n'
+                   + ''.join('  printf("%zu\\n", offsetof(msd_problem_desc, {}));\n'.format(f) for f in fields) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', str(ROOT / 'include'), '-o', str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(ProblemDesc)
+    assert out[1:] == [getattr(ProblemDesc, f).offset for f in fields]
 
 
 def test_no_device_fails_loudly(built):

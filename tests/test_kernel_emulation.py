@@ -17,8 +17,8 @@ import cases
 EMU = Path(__file__).resolve().parent / 'hip_emu'
 
 
-@pytest.fixture(scope='module')
-def emu():
+def load_emulation():
+    "Build (when out of date) and load the host emulation of the kernels."
     src = [EMU / 'emu_driver.cpp', EMU / 'hip' / 'hip_runtime.h'] + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) \
         + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
     import os
@@ -37,6 +37,11 @@ def emu():
     dp = ctypes.POINTER(ctypes.c_double)
     lib.emu_solve_batch.argtypes = [ctypes.POINTER(ProblemDesc), ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
     return lib
+
+
+@pytest.fixture(scope='module')
+def emu():
+    return load_emulation()
 
 
 @pytest.mark.parametrize('N,crop,T,start', [(30, 12000, 520.0, 'reference'), (70, 30000, 1100.0, 'reference'), (70, 30000, 1100.0, 'profile')])

@@ -1,0 +1,202 @@
+"""
+The other two shooting integrators of the NLP (reference: OptionsCasadiSolver.integrationMethod = 'IRK' / 'CVODES', ocp.py:26,92 ->
+TrainIntegrator, train.py:303-322): collocation (casadi.simpleIRK) and integration to tolerances (CVODES' role, played by an adaptive
+Dormand-Prince pair).  CPU part: the oracle's restatement against checkers that share nothing with it (the numpy collocation equations
+solved by scipy, a DOP853 reference solution, finite differences of the oracle's own values) and the emulated kernel against the
+oracle.  GPU part: the HIP kernels against the oracle through the C ABI.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+from scipy.integrate import solve_ivp
+
+import cases
+from oracle import oracle
+from oracle.oracle import DP
+from test_integrators import _irk_numpy
+
+IRK2 = dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10)
+IRK3L = dict(integrationMethod='IRK', order=3, collMethod='legendre', maxIter=10)
+ADAPT = dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6)
+
+
+def _problem(N=30, crop=12000, numSteps=1, numApprox=0, integration=None, train=None, **kw):
+    return cases.oracle_problem(train or cases.train_default(), cases.track_00(crop), N, numSteps=numSteps, numApproxSteps=numApprox, integration=integration, **kw)
+
+
+# ---- the oracle's integrators ----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('order,scheme,numSteps,numApprox', [(2, 'radau', 1, 0), (3, 'legendre', 2, 0), (1, 'radau', 3, 0), (2, 'radau', 1, 2),
+                                                             (4, 'radau', 2, 3), (9, 'radau', 1, 0), (5, 'legendre', 1, 1)])
+def test_oracle_collocation_values_vs_numpy(order, scheme, numSteps, numApprox):
+    from mseetc.train import collocationTables
+    prob = _problem(numSteps=numSteps, numApprox=numApprox, integration=dict(integrationMethod='IRK', order=order, collMethod=scheme, maxIter=30))
+    model = cases.train_default().exportModel()
+    C, D = collocationTables(order, scheme)
+    rng = np.random.default_rng(11)
+    for _ in range(12):
+        b0, w, ds, grad, curv = rng.uniform(100, 1500), rng.uniform(-0.3, 0.4), rng.uniform(10, 400), rng.uniform(-0.012, 0.012), rng.uniform(-1/320, 1/320)
+        out = oracle.stage_eval(prob, b0, w, ds, grad, curv)
+        G = model.resistance(grad, curv)
+        if numApprox == 0:
+            t, b = _irk_numpy(model, C, D, numSteps, 0.0, b0, ds, w, G, True)
+        else:
+            bs = [b0] + [_irk_numpy(model, C, D, numSteps, 0.0, b0, ds, w, G, False, h=j/numApprox)[1] for j in range(1, numApprox + 1)]
+            t = sum(2*ds/numApprox/(np.sqrt(bs[j]) + np.sqrt(bs[j + 1])) for j in range(numApprox))
+            b = bs[-1]
+        assert abs(out[0] - t) <= 1e-11*abs(t) and abs(out[1] - b) <= 1e-11*abs(b)
+
+
+@pytest.mark.parametrize('integration,numSteps,numApprox', [(IRK2, 1, 0), (IRK3L, 2, 2), (dict(IRK2, order=4), 3, 1), (ADAPT, 1, 0)])
+def test_oracle_integrator_derivatives_by_finite_differences(integration, numSteps, numApprox):
+    prob = _problem(numSteps=numSteps, numApprox=numApprox, integration=integration)
+    if integration is ADAPT:
+        # the derivatives are those of the accepted steps: differencing needs a fixed step sequence, which tolerances this loose
+        # do not give; tight tolerances make the steps' influence on the value vanish instead
+        prob.dp[DP['INT_ATOL']], prob.dp[DP['INT_RTOL']] = 1e-13, 1e-12
+    ev = lambda b, w, ds: np.array(oracle.stage_eval(prob, b, w, ds, 0.003, 0.001))
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        b, w, ds = rng.uniform(150, 1400), rng.uniform(-0.3, 0.4), rng.uniform(20, 350)
+        h = 1e-5
+        f0 = ev(b, w, ds)
+        gb = (ev(b*(1 + h), w, ds) - ev(b*(1 - h), w, ds))/(2*h*b)
+        gw = (ev(b, w + h, ds) - ev(b, w - h, ds))/(2*h)
+        # layout: tau, b+, dtau/db, dtau/dw, db+/db, db+/dw, then the Hessians (bb, bw, ww) of tau and of b+
+        fd = np.array([gb[0], gw[0], gb[1], gw[1], gb[2], gw[2], gw[3], gb[4], gw[4], gw[5]])
+        # (central differences of step 1e-5 carry about 1e-6 of noise on the smallest second derivatives)
+        scale = np.maximum(np.abs(fd), 1e-5*np.max(np.abs(fd)))
+        assert np.max(np.abs(f0[2:] - fd)/scale) < 1e-5, (integration, f0[2:], fd)
+
+
+def test_oracle_adaptive_integrator_vs_dop853():
+    prob = _problem(integration=ADAPT)
+    dp = prob.dp
+    rng = np.random.default_rng(9)
+    for _ in range(10):
+        b0, w, ds, grad = rng.uniform(100, 1500), rng.uniform(-0.3, 0.4), rng.uniform(10, 400), rng.uniform(-0.012, 0.012)
+        out = oracle.stage_eval(prob, b0, w, ds, grad, 0.0)
+        G = dp[DP['G']]*grad/dp[DP['RHO']]
+        rhs = lambda s, y: [1/np.sqrt(y[1]), 2*(w - (dp[DP['SR0']] + dp[DP['SR1']]*np.sqrt(y[1]) + dp[DP['SR2']]*y[1]) - G)]
+        sol = solve_ivp(rhs, [0, ds], [0.0, b0], rtol=1e-13, atol=1e-13, method='DOP853')
+        # relTol = 1e-6 per step: the global error stays well below 1e-5
+        assert abs(out[0] - sol.y[0, -1]) <= 1e-5*abs(sol.y[0, -1]) and abs(out[1] - sol.y[1, -1]) <= 1e-5*abs(sol.y[1, -1])
+
+
+def test_oracle_nlp_with_accurate_integrators_agree():
+    """
+    Three transcriptions whose integrators are all accurate on this grid (RK4 with 32 steps, 5-point Radau with 4 steps, the adaptive
+    pair at tight tolerances; the train enters and leaves at 8 m/s, away from the 1/v singularity of the time equation) are the same NLP
+    up to the integration error: their optima agree to 1e-7, a thousand times closer than the one-step RK4 transcription is to them,
+    whichever integrator code produced them.
+    """
+    T, v = 520.0, 8.0
+    settings = [dict(numSteps=32, numApprox=0), dict(numSteps=4, numApprox=0, integration=dict(IRK2, order=5)),
+                dict(integration=dict(ADAPT, absTol=1e-11, relTol=1e-10)), dict(numSteps=1, numApprox=0)]
+    objs = []
+    for kw in settings:
+        prob = _problem(**kw)
+        r = oracle.solve(prob, prob.scenario(T, 0.0, v, v), start='profile')
+        assert r['stats']['STATUS'] == 0
+        objs.append(r['stats']['OBJ'])
+    assert abs(objs[1] - objs[0]) < 1e-7*objs[0] and abs(objs[2] - objs[0]) < 1e-7*objs[0], objs
+    assert abs(objs[3] - objs[0]) > 1e-3*objs[0], objs
+
+
+# ---- the emulated kernel ----------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('method,io,integration', [('IRK', dict(order=2, numSteps=1, numApproxSteps=0), IRK2),
+                                                   ('IRK', dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=2), IRK3L),
+                                                   ('CVODES', dict(), ADAPT)])
+def test_emulated_kernel_with_other_integrators_matches_oracle(method, io, integration):
+    from test_kernel_emulation import load_emulation
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    lib = load_emulation()
+    N, T = 30, 520.0
+    train, track = cases.train_default(), cases.track_00(12000)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationMethod=method, integrationOptions=io), startingPoint='profile')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = _problem(N, 12000, io.get('numSteps', 1), io.get('numApproxSteps', 0), integration)
+    ref = oracle.solve(prob, prob.scenario(T), start='profile')
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
+
+
+# ---- the HIP kernels ----------------------------------------------------------------------------------------------------------------
+
+CASES = [('IRK', dict(order=2, numSteps=1, numApproxSteps=0), IRK2, 30, 12000, 520.0),
+         ('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2, 100, None, 1541.0),
+         ('IRK', dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=2), IRK3L, 60, 30000, 1100.0),
+         ('IRK', dict(order=9, numSteps=1, numApproxSteps=1), dict(IRK2, order=9), 40, 12000, 520.0),
+         ('CVODES', dict(), ADAPT, 100, None, 1541.0),
+         ('CVODES', dict(absTol=1e-10, relTol=1e-9), dict(ADAPT, absTol=1e-10, relTol=1e-9), 150, None, 1600.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method,io,integration,N,crop,T', CASES)
+def test_gpu_other_integrators_vs_oracle(method, io, integration, N, crop, T):
+    from mseetc.ocp import casadiSolver
+    train, track = cases.train_default(), cases.track_00(crop) if crop else cases.track_00()
+    for start in ('profile', 'reference'):
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=400, integrationMethod=method, integrationOptions=io), startingPoint=start)
+        Ts = T*np.array([1.0, 1.04, 1.11])
+        res = solver.solveBatch(Ts)
+        prob = cases.oracle_problem(train, track, N, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), integration=integration)
+        for k, Tk in enumerate(Ts):
+            ref = oracle.solve(prob, prob.scenario(Tk), start=start)
+            assert res['status'][k] == 0 and ref['stats']['STATUS'] == 0
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+            assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-5
+            assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
+
+
+@pytest.mark.gpu
+def test_gpu_stage_function_of_other_integrators_vs_oracle_and_standalone_kernels():
+    """
+    msd_stage_eval of an 'IRK' / 'CVODES' problem: values against the stand-alone interval integrators (msd_interval_integrate,
+    csrc/msd_integrators.hip -- other code), values and both derivative orders against the oracle.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc.train import TrainIntegrator
+    train, track = cases.train_default(), cases.track_00()
+    model = train.exportModel()
+    rng = np.random.default_rng(21)
+    n = 200
+    b, w, ds = rng.uniform(100, 1500, n), rng.uniform(-0.3, 0.4, n), rng.uniform(10, 400, n)
+    grad, curv = rng.uniform(-0.012, 0.012, n), rng.uniform(-1/320, 1/320, n)
+    w = np.maximum(w, (16.0 - b)/(2*ds) + 0.25)      # stay clear of standstill within the interval (resistances + gradient < 0.25 N/kg)
+    for method, io, integration in [('IRK', dict(order=3, numSteps=2, numApproxSteps=0), dict(IRK2, order=3)), ('IRK', dict(order=2, numSteps=1, numApproxSteps=2), IRK2),
+                                    ('CVODES', dict(), ADAPT)]:
+        solver = casadiSolver(train, track, dict(numIntervals=50, integrationMethod=method, integrationOptions=io))
+        out = solver.problem.stage_eval(b, w, ds, grad, curv)
+        alone = TrainIntegrator(model, method, io).solveMany(np.zeros(n), b, ds, w, grad, curv)
+        assert np.max(np.abs(out[:, 0] - alone['time'])/np.abs(alone['time'])) < 1e-9
+        assert np.max(np.abs(out[:, 1] - alone['velSquared'])/np.abs(alone['velSquared'])) < 1e-9
+        prob = cases.oracle_problem(train, track, 50, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), integration=integration)
+        for k in range(0, n, 4):
+            ref = np.array(oracle.stage_eval(prob, b[k], w[k], ds[k], grad[k], curv[k]))
+            assert np.max(np.abs(out[k] - ref)/np.maximum(np.abs(ref), 1e-9*np.max(np.abs(ref)))) < 1e-8, (method, k)
+
+
+@pytest.mark.gpu
+def test_gpu_other_integrators_surface_and_limits():
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import DeviceError
+    train, track = cases.train_default(), cases.track_00()
+    solver = casadiSolver(train, track, dict(numIntervals=100, integrationMethod='IRK', integrationOptions=dict(order=2, numApproxSteps=1)))
+    df, stats = solver.solve(1541)
+    assert stats['IP iterations'] > 5 and abs(df.index[-1] - 1541) < 1e-4      # (the bound of t_N is relaxed by 1e-8 relative, like IPOPT does)
+    rk = casadiSolver(train, track, dict(numIntervals=100, integrationOptions=dict(numApproxSteps=1)))
+    assert abs(stats['Cost'] - rk.solve(1541)[1]['Cost']) < 1e-3*stats['Cost']      # both integrate b accurately on this grid
+    with pytest.raises(DeviceError):
+        casadiSolver(train, track, dict(numIntervals=700, integrationMethod='CVODES')).solve(1541)      # beyond the LDS-resident kernels
+    with pytest.raises(NotImplementedError):
+        casadiSolver(train, track, dict(numIntervals=50, integrateLosses=True))
