@@ -109,7 +109,9 @@ typedef struct msd_problem_desc {
                               * MSD_INTEGRATOR_COLLOCATION = 'IRK' (simpleIRK), MSD_INTEGRATOR_ADAPTIVE = 'CVODES' (integration to tolerances) */
     int coll_degree;         /* 'IRK': OptionsIRK.order = collocation points per step, 1..9 (train.py:485,502)      */
     int newton_iterations;   /* 'IRK': OptionsIRK.maxIter (train.py:493)                       */
-    int reserved_i[3];
+    int integrate_losses;    /* OptionsCasadiSolver.integrateLosses (ocp.py:28,231-241): loss slacks [J/kg per interval] bound the loss power integrated
+                              * over the running time of the interval; constant efficiencies (loss_kind 1), 'RK' shooting                          */
+    int reserved_i[2];
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
     double g, rho;
     double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */

@@ -103,6 +103,8 @@ static int check_desc(const msd_problem_desc *d)
         if (!d->coll_tables) return fail(MSD_E_INVALID, "collocation integrator without its tables");
     }
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE && (!(d->int_abstol > 0) || !(d->int_reltol > 0))) return fail(MSD_E_INVALID, "tolerances of the adaptive integrator must be positive");
+    if (d->integrate_losses && d->energy_optimal && (d->loss_kind != 1 || d->integrator != 0))
+        return fail(MSD_E_UNSUPPORTED, "integrateLosses runs with constant efficiencies (loss_kind 1) and the 'RK' transcription");
     if (d->integrator != 0 && d->loss_kind == 2) return fail(MSD_E_UNSUPPORTED, "the collocation and adaptive shooting integrators run with the static loss models");
     return MSD_OK;
 }
@@ -128,11 +130,12 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
 {
     const int N = d->num_intervals;
     const bool dyn = d->loss_kind == 2;
-    const bool gen = d->integrator != 0;
-    msd::Geometry geo = gen ? msd::pick_geometry_general(N) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
-    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, dyn) : 0;
-    if (gen && (!geo.fn || lds > 160*1024))
-        return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " with the collocation or adaptive shooting integrator does not fit the LDS-resident kernel (the streamed kernel runs 'RK')");
+    const bool gen = d->integrator != 0, intloss = d->integrate_losses != 0 && d->energy_optimal != 0;
+    const bool wide = dyn || intloss;      /* stage blocks with the slack-b and slack-Fpb couplings */
+    msd::Geometry geo = gen ? msd::pick_geometry_general(N) : intloss ? msd::pick_geometry_intloss(N) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N);
+    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide) : 0;
+    if ((gen || intloss) && (!geo.fn || lds > 160*1024))
+        return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " with the collocation or adaptive shooting integrator or with integrateLosses does not fit the LDS-resident kernel (the streamed kernel runs 'RK' with the mid-point loss rows)");
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernel keeps them in device memory */
         geo = dyn ? msd::Geometry{0, 0, nullptr} : msd::pick_stream_geometry_static(N);

@@ -1,6 +1,6 @@
 /*
  * msd_geometry.hpp -- launch geometry of the solve kernel by horizon length.  The kernel instantiations live in four
- * translation units (static / dynamic loss model, streamed, other integrators) so that they compile in parallel.
+ * translation units (static / dynamic / integrated loss model, streamed, other integrators) so that they compile in parallel.
  */
 #pragma once
 
@@ -17,13 +17,14 @@ Geometry pick_geometry_static(int N);
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
 Geometry pick_geometry_general(int N);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
+Geometry pick_geometry_intloss(int N);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
 
-template <bool DYN> inline Geometry pick_geometry_t(int N)
+template <int DYN> inline Geometry pick_geometry_t(int N)
 {
     const int nodes = N + 1;
     /* MSD_GEOMETRY=128x1 selects the one-node-per-thread variant (tuning experiments only) */
     const char *g = getenv("MSD_GEOMETRY");
-    if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, solve_kernel<128, 1, 2, DYN>};
+    if constexpr (DYN != LOSS_INTEGRATED) { if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, solve_kernel<128, 1, 2, DYN>}; }
 #ifdef MSD_ONLY_192X2              /* debugging builds */
     return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN>} : Geometry{0, 0, nullptr};
 #endif

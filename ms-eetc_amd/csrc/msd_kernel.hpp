@@ -137,6 +137,10 @@ constexpr int RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5;
 
 /* LDS layout (in doubles) */
 /* stage block stride: odd -> the per-thread writes spread over the banks; the dynamic loss model needs three more entries */
+/* DYN (template parameter of the kernels): loss transcription -- 0 constant efficiencies at the mid-point speed (ocp.py:221-226), 1 dynamic
+ * table (efficiency.py), 2 constant efficiencies integrated over the running time (integrateLosses, ocp.py:231-241; msd_lossint.hpp).
+ * 1 and 2 couple the loss slack with b and Fpb and use the wider stage block */
+constexpr int LOSS_STATIC = 0, LOSS_TABLE = 1, LOSS_INTEGRATED = 2;
 constexpr int S_STRIDE_STATIC = 27, S_STRIDE_DYN = 31;
 __host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE_DYN : S_STRIDE_STATIC; }
 constexpr int FILT_CAP = 64;
@@ -252,6 +256,7 @@ template <class T> __device__ __forceinline__ void interval_map(const DevProb &P
 }
 
 #include "msd_integ.hpp"
+#include "msd_lossint.hpp"
 
 /* ------------------------------------------------------------------------------------------
  * dynamic loss model (reference: mseetc/efficiency.py:7-141 with utils.py:197-220 and train.py:214-217).
@@ -577,7 +582,12 @@ struct Uni {
 #ifndef MSD_NODE_FENCE
 #define MSD_NODE_FENCE 1
 #endif
-__device__ __forceinline__ void node_fence() { if (MSD_NODE_FENCE) __builtin_amdgcn_sched_barrier(0); }
+/* SITE: 0 KKT pass, 1 assembly, 2 read-back, 3 step lengths, 4 trial point, 5 merit, 6 trial residuals, 7 evaluation, 8 start-up,
+ * 9 barrier gradient, 10 accepted step, 11 after the loop; MSD_NODE_FENCE_SITES: bit per site (tuning builds) */
+#ifndef MSD_NODE_FENCE_SITES
+#define MSD_NODE_FENCE_SITES 0xFFFu
+#endif
+template <int SITE> __device__ __forceinline__ void node_fence() { if (MSD_NODE_FENCE && ((MSD_NODE_FENCE_SITES >> SITE) & 1u)) __builtin_amdgcn_sched_barrier(0); }
 
 /* value the optimiser must treat as redefined here (no instruction is emitted) */
 __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); }
@@ -603,11 +613,12 @@ __device__ __forceinline__ double uni(double v)
 struct Ev {
     double sb, sb1, b1;
     double tb, tw, tbb, tbw, tww, Bb, Bw, Bbb, Bbw, Bww;
-    double lg[2][5];     /* dynamic loss rows: g_f, g_v, g_ff, g_fv, g_vv of the traction / brake row at (f, vbar) */
+    double lg[2][5];     /* dynamic loss rows: g_f, g_v, g_ff, g_fv, g_vv of the traction / brake row at (f, vbar);
+                          * integrated losses: X, X_v, X_d, X_w, X_vv | X_vd, X_vw, X_dd, X_dw, X_ww (d = running time) */
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
-template <bool DERIV, bool DYN, bool GEN>
+template <bool DERIV, int DYN, bool GEN>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
                                               double (&cv)[2], double (&dv)[NR], Ev &e)
 {
@@ -628,7 +639,20 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
     dv[RPW0] = U.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
     dv[RPW1] = U.rs[RPW1]*f*sb1;
     dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nG);     /* ocp.py:199 */
-    if (DYN) {
+    if (DYN == LOSS_INTEGRATED) {
+        /* ocp.py:233-240: s - E_tr, s - E_rgb with E = int loss power dt over t1 - t = +-kappa f X(v, t1 - t, f + p) */
+        if (DERIV) {
+            const Jet3 X = loss_distance<Jet3>(P, sb, t1 - x[VT], f + p, nG);
+            dv[RLTR] = U.rs[RLTR]*(s - P.ct*f*X.v);
+            dv[RLRG] = U.rs[RLRG]*(s + P.cr*f*X.v);
+            e.lg[0][0] = X.v; e.lg[0][1] = X.g[0]; e.lg[0][2] = X.g[1]; e.lg[0][3] = X.g[2]; e.lg[0][4] = X.h[0];
+            e.lg[1][0] = X.h[1]; e.lg[1][1] = X.h[2]; e.lg[1][2] = X.h[3]; e.lg[1][3] = X.h[4]; e.lg[1][4] = X.h[5];
+        } else {
+            const double X = loss_distance<double>(P, sb, t1 - x[VT], f + p, nG);
+            dv[RLTR] = U.rs[RLTR]*(s - P.ct*f*X);
+            dv[RLRG] = U.rs[RLRG]*(s + P.cr*f*X);
+        }
+    } else if (DYN == LOSS_TABLE) {
         const DynLoss D(P.loss, P.lossMass);
         double lr[2][6];
         loss_rows(D, f, 0.5*(sb + sb1), lr);                                 /* ocp.py:221: mid-point speed of the interval */
@@ -647,14 +671,14 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
-template <class NodeT>
+template <bool LI, class NodeT>
 __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &n, const double (&x)[NV], double q, double sf)
 {
     double J = 0;
     if (n.ival()) {
         const double f = x[VF], p = P.withPn ? x[VP] : 0.0;
         if (P.energyOpt) {
-            J = n.ds*(f + x[VS]);                                             /* ocp.py:223 */
+            J = LI ? n.ds*f + x[VS] : n.ds*(f + x[VS]);                       /* ocp.py:223 resp. :235 */
             if (n.i > 0) J += 1e-3*(f - q)*(f - q);                           /* ocp.py:245 */
         } else J = 1e-4*(f*f + p*p);                                          /* ocp.py:150 */
     } else if (n.i == P.N && !P.energyOpt) J = x[VT];
@@ -671,7 +695,7 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &
  * ---------------------------------------------------------------------------------------- */
 /* lg_out: when not null only the backward sweep runs and the seven numbers the forward sweep needs for the multiplier
  * of the last interval's eliminated row are written there */
-template <bool DYN>
+template <int DYN>
 __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S, double *lg_out)
 {
     constexpr int S_STRIDE = stage_stride(DYN);
@@ -720,7 +744,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
             LGtf = Gtf; LGbf = Gbf; LGqf = Gqf; LGff = Gff; LGfp = Gfp; LGfs = Gfs; Lgf = gf;
             const double gfe = gf + Gff*e0;
             /* reduced blocks over (t, b, q | p, s) */
-            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs;
+            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = (DYN ? s[S_GPS] : 0.0) - Gfs;      /* (p-s coupling: integrated loss rows) */
             double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
             double Hsb = Gfs*eb + Gbs;
             double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
@@ -815,7 +839,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
 #define MSD_PARALLEL_ATTR __forceinline__
 #endif
 
-template <int SPT, bool DYN>
+template <int SPT, int DYN>
 struct ParallelRiccati {
     /* ------------------------------------------------------------------------------------------
      * stage-parallel KKT solve (all threads; msd_scan.hpp).  Thread l owns the consecutive regular stages l*SPT .. l*SPT+SPT-1
@@ -928,7 +952,7 @@ struct ParallelRiccati {
             const double eb = -Bb/Bw, e0 = -rb/Bw;
             LG[0] = Gtf; LG[1] = Gbf; LG[2] = Gqf; LG[3] = Gff; LG[4] = Gfp; LG[5] = Gfs; LG[6] = gf;
             const double gfe = gf + Gff*e0;
-            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = -Gfs;
+            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = (DYN ? s[S_GPS] : 0.0) - Gfs;      /* (p-s coupling: integrated loss rows) */
             double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
             double Hsb = Gfs*eb + Gbs;
             double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
@@ -1257,7 +1281,7 @@ struct ParallelRiccati {
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int NT, int SPT, bool DYN, bool STREAM, bool GEN>
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -1444,16 +1468,39 @@ struct Solver {
         bar_terms(n[j].sg[r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], n[j].zLs[r], n[j].zUs[r], mu_, Sg, gphi);
     }
 
-    /* gradient entries of the rows wrt (b, f, p, s, b1) */
-    __device__ __forceinline__ void row_grads(int j, const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], double (&gs)[NR], double (&gb1)[NR]) const
+    /* second derivatives of phi = f X(v(b), d, f + p) wrt (b, f, p, d) from the cached derivatives of X (integrated losses) */
+    struct LossHess { double bb, bf, bp, bd, ff, fp, fd, pp, pd, dd; };
+    __device__ __forceinline__ LossHess loss_hess(double f, double b, const Ev &ev) const
+    {
+        const double Xv = ev.lg[0][1], Xd = ev.lg[0][2], Xw = ev.lg[0][3], Xvv = ev.lg[0][4], Xvd = ev.lg[1][0], Xvw = ev.lg[1][1], Xdd = ev.lg[1][2],
+                     Xdw = ev.lg[1][3], Xww = ev.lg[1][4];
+        const double vb = 0.5/ev.sb, vbb = -0.25/(b*ev.sb);
+        LossHess L;
+        L.bb = f*(Xvv*vb*vb + Xv*vbb); L.bf = f*Xvw*vb + Xv*vb; L.bp = f*Xvw*vb; L.bd = f*Xvd*vb;
+        L.ff = f*Xww + 2*Xw; L.fp = f*Xww + Xw; L.fd = f*Xdw + Xd; L.pp = f*Xww; L.pd = f*Xdw; L.dd = f*Xdd;
+        return L;
+    }
+
+    /* gradient entries of the rows wrt (b, f, p, s, b1) and wrt the running time t1 - t (gd; integrated losses only) */
+    __device__ __forceinline__ void row_grads(int j, const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], double (&gs)[NR], double (&gb1)[NR],
+                                              double (&gd)[NR]) const
     {
         const double f = n[j].x[VF];
 #pragma unroll
-        for (int r = 0; r < NR; r++) { gb[r] = gf[r] = gp[r] = gs[r] = gb1[r] = 0; }
+        for (int r = 0; r < NR; r++) { gb[r] = gf[r] = gp[r] = gs[r] = gb1[r] = gd[r] = 0; }
         gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
         gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
         gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
-        if (DYN) {
+        if (DYN == LOSS_INTEGRATED) {
+            /* rows s + kappa f X(v(b), t1 - t, f + p), kappa = -ct, +cr */
+            const double X = ev.lg[0][0], Xv = ev.lg[0][1], Xd = ev.lg[0][2], Xw = ev.lg[0][3], vb = 0.5/ev.sb;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int r = (k == 0) ? RLTR : RLRG;
+                const double kap = (k == 0) ? -P.ct : P.cr;
+                gs[r] = 1; gf[r] = kap*(X + f*Xw); gp[r] = P.withPn ? kap*f*Xw : 0.0; gb[r] = kap*f*Xv*vb; gd[r] = kap*f*Xd;
+            }
+        } else if (DYN == LOSS_TABLE) {
             /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
             const double vb = 0.25/ev.sb, vb1 = 0.25/ev.sb1;
             gs[RLTR] = 1; gf[RLTR] = -ev.lg[0][0]; gb[RLTR] = -ev.lg[0][1]*vb; gb1[RLTR] = -ev.lg[0][1]*vb1;
@@ -1463,7 +1510,18 @@ struct Solver {
             gs[RLRG] = 1; gf[RLRG] = P.cr;
         }
 #pragma unroll
-        for (int r = 0; r < NR; r++) { gb[r] *= U.rs[r]; gf[r] *= U.rs[r]; gp[r] *= U.rs[r]; gs[r] *= U.rs[r]; gb1[r] *= U.rs[r]; }
+        for (int r = 0; r < NR; r++) { gb[r] *= U.rs[r]; gf[r] *= U.rs[r]; gp[r] *= U.rs[r]; gs[r] *= U.rs[r]; gb1[r] *= U.rs[r]; gd[r] *= U.rs[r]; }
+    }
+    /*
+     * In the Newton system the running time obeys the linearised time equation, d(t1 - t) = tb db + tw (df + dp) + rt: a row's
+     * dependence on it folds into its (b, f, p) entries and a shift gd rt of its residual -- the stage blocks keep their pattern.
+     * The multiplier of the time equation found this way is lam_t + sum_r (gd_r nu_r+ + ...), see direction().
+     */
+    __device__ __forceinline__ void fold_running_time(const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], const double (&gd)[NR]) const
+    {
+        if (DYN != LOSS_INTEGRATED) return;
+#pragma unroll
+        for (int r = RLTR; r <= RLRG; r++) { gb[r] += gd[r]*ev.tb; gf[r] += gd[r]*ev.tw; if (P.withPn) gp[r] += gd[r]*ev.tw; }
     }
 
     /* objective gradient wrt (f, p, s, q) of the interval and its (constant) curvature; terminal time handled by node N */
@@ -1474,7 +1532,7 @@ struct Solver {
         if (!n[j].ival()) return;
         const double f = n[j].x[VF], p = P.withPn ? n[j].x[VP] : 0.0;
         if (P.energyOpt) {
-            of = sc*n[j].ds; os = sc*n[j].ds;
+            of = sc*n[j].ds; os = (DYN == LOSS_INTEGRATED) ? sc : sc*n[j].ds;
             if (n[j].i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
         } else {
             of = sc*2e-4*f; off = sc*2e-4;
@@ -1519,15 +1577,15 @@ struct Solver {
         LogSum lsum;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<0>();
             const NodeT &nd = n[j];
             const double q = nb_q(j);
             double out_q = 0, out_t1 = 0, out_b1 = 0, prod = 1.0;
 #pragma unroll
             for (int k = 0; k < NV; k++) gl[j][k] = 0;
             if (nd.ival()) {
-                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
+                row_grads(j, e[j], gb, gf, gp, gs, gb1, gd);
                 double of, op, os, oq, off, opp;
                 obj_grads(j, q, of, op, os, oq, off, opp);
                 gl[j][VF] = of; gl[j][VP] = op; gl[j][VS] = os; out_q = oq;
@@ -1535,6 +1593,7 @@ struct Solver {
                 for (int r = 0; r < NR; r++) {
                     if (!U.rowOn[r]) continue;
                     gl[j][VB] += nd.nu[r]*gb[r]; gl[j][VF] += nd.nu[r]*gf[r]; gl[j][VP] += nd.nu[r]*gp[r]; gl[j][VS] += nd.nu[r]*gs[r]; out_b1 += nd.nu[r]*gb1[r];
+                    if (DYN == LOSS_INTEGRATED) { out_t1 += nd.nu[r]*gd[r]; gl[j][VT] -= nd.nu[r]*gd[r]; }      /* running time = t1 - t */
                 }
                 /* dynamics rows: c_t = t1 - t - tau, c_b = b1 - b+ */
                 out_t1 += nd.lam[0]; gl[j][VT] -= nd.lam[0];
@@ -1571,7 +1630,7 @@ struct Solver {
                 { double xl[NV];
 #pragma unroll
                     for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
-                    obj += objective_term(P, nd, xl, q, U.sf); }
+                    obj += objective_term<DYN == LOSS_INTEGRATED>(P, nd, xl, q, U.sf); }
             }
             lsum.add(prod);
             /* the contributions that belong to the neighbours' variables */
@@ -1580,7 +1639,7 @@ struct Solver {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<0>();
             const NodeT &nd = n[j];
             if (!nd.node()) continue;
             if (nd.i > 0) { gl[j][VT] += c.o2[nd.i - 1]; gl[j][VB] += c.o3[nd.i - 1]; }
@@ -1618,17 +1677,19 @@ struct Solver {
         for (int j = 0; j < SPT; j++) load_ev(j, e[j]);
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<1>();
             const NodeT &nd = n[j];
             const double q = nb_q(j);
             double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
             double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
             double nHbb = 0, nHbq = 0, nhb = 0;
-            double Hbs = 0, Eb = 0, Es = 0;     /* only the dynamic loss rows fill these */
+            double Hbs = 0, Hps = 0, Eb = 0, Es = 0;     /* only the dynamic / integrated loss rows fill these */
             if (nd.ival()) {
                 const double f = nd.x[VF];
-                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
+                row_grads(j, e[j], gb, gf, gp, gs, gb1, gd);
+                fold_running_time(e[j], gb, gf, gp, gd);
+                const double rt = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0;
                 double of, op, os, oq, off, opp;
                 obj_grads(j, q, of, op, os, oq, off, opp);
                 hf = of; hp = op; hs = os; hq = oq;
@@ -1645,7 +1706,24 @@ struct Solver {
                     if (U.rowOn[RPW0]) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
                     if (U.rowOn[RPW1]) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
                     if (U.rowOn[RACC]) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
-                    if (DYN && U.rowOn[RLTR]) {
+                    if (DYN == LOSS_INTEGRATED && U.rowOn[RLTR]) {
+                        /* rows s + kappa f X(v(b), d, f + p), d = t1 - t: nu * hess(kappa f X) in (b, f, p, d), then d folded away with
+                         * dd = tb db + tw (df + dp) + rt (quadratic form; the part linear in rt goes to the gradient) */
+                        const LossHess L = loss_hess(f, b, e[j]);
+                        const double W = nd.nu[RLTR]*U.rs[RLTR]*(-P.ct) + nd.nu[RLRG]*U.rs[RLRG]*P.cr;
+                        const double tb = e[j].tb, tw = e[j].tw;
+                        Hbb += W*(L.bb + 2*tb*L.bd + tb*tb*L.dd);
+                        Hbf += W*(L.bf + tb*L.fd + tw*L.bd + tb*tw*L.dd);
+                        Hff += W*(L.ff + 2*tw*L.fd + tw*tw*L.dd);
+                        hb += W*rt*(L.bd + L.dd*tb); hf += W*rt*(L.fd + L.dd*tw);
+                        if (P.withPn) {
+                            Hbp += W*(L.bp + tb*L.pd + tw*L.bd + tb*tw*L.dd);
+                            Hfp += W*(L.fp + tw*L.pd + tw*L.fd + tw*tw*L.dd);
+                            Hpp += W*(L.pp + 2*tw*L.pd + tw*tw*L.dd);
+                            hp += W*rt*(L.pd + L.dd*tw);
+                        }
+                    }
+                    if (DYN == LOSS_TABLE && U.rowOn[RLTR]) {
                         /* rows s - g(f, vbar(b, b1)): nu * hess = -nu * hess(g) */
                         const double vb = 0.25/e[j].sb, vb1 = 0.25/e[j].sb1, vbb = -0.125/(b*e[j].sb), vb1b1 = -0.125/(e[j].b1*e[j].sb1);
 #pragma unroll
@@ -1662,14 +1740,14 @@ struct Solver {
                 for (int r = 0; r < NR; r++) {
                     if (!U.rowOn[r]) continue;
                     double Sg, coef;
-                    if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*resd[j][r] + gphi; }
+                    if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*(resd[j][r] + gd[r]*rt) + gphi; }
                     else { Sg = 1.0; coef = -nd.zLs[r] + nd.zUs[r]; }
                     hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
                     Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
                     Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
                     Hpp += Sg*gp[r]*gp[r]; Hss += Sg*gs[r]*gs[r];
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
-                    if (DYN) { Hbs += Sg*gb[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
+                    if (DYN) { Hbs += Sg*gb[r]*gs[r]; Hps += Sg*gp[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
             } else if (nd.i == P.N && !P.energyOpt) ht = U.sf/P.objDen;
             /* bounds of the node's own variables + regularisation */
@@ -1695,12 +1773,12 @@ struct Solver {
                      * wrong inertia.  The last interval keeps its s row (b_N is a parameter; riccati_solve) */
                     const double Bb = e[j].Bb, Bw = e[j].Bw, rb = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
                     const bool last = nd.i == P.N - 1;
-                    double Gbs = Hbs, Gfs = Hfs, Gps = 0, gsv = hs;
+                    double Gbs = Hbs, Gfs = Hfs, Gps = Hps, gsv = hs;
                     if (DYN && !last) {
                         Hbb += 2*Eb*Bb; Hbf += Eb*Bw; hb += Eb*rb;
                         if (P.withPn) Hbp += Eb*Bw;
                         Gbs += Es*Bb; Gfs += Es*Bw; gsv += Es*rb;
-                        if (P.withPn) Gps = Es*Bw;
+                        if (P.withPn) Gps += Es*Bw;
                     }
                     const double is = (Hss > 0) ? 1.0/Hss : NAN;
                     if (!last) {
@@ -1725,7 +1803,7 @@ struct Solver {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<1>();
             const NodeT &nd = n[j];
             if (nd.node() && nd.i > 0) {
                 double *s = c.S + nd.i*S_STRIDE;
@@ -1803,22 +1881,40 @@ struct Solver {
         if (ok) {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                node_fence();
+                node_fence<2>();
                 NodeT &nd = n[j];
 #pragma unroll
                 for (int r = 0; r < NR; r++) nd.dsg[r] = 0;
                 if (!nd.ival()) continue;
                 Dir d; load_dir(j, d);
                 const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
-                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
+                const double dd = (DYN == LOSS_INTEGRATED) ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time */
+                double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
                 Ev ej; load_ev1(j, ej);
-                row_grads(j, ej, gb, gf, gp, gs, gb1);
+                row_grads(j, ej, gb, gf, gp, gs, gb1, gd);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     if (!U.rowOn[r]) continue;
-                    const double lin = gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1;
+                    const double lin = gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1 + gd[r]*dd;
                     /* Newton: slack step; least squares: nu = Sigma dsigma + (-zL + zU) with Sigma = 1, parked in dsg */
                     nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-nd.zLs[r] + nd.zUs[r]);
+                }
+                if (DYN == LOSS_INTEGRATED && U.rowOn[RLTR]) {
+                    /* the sweeps solved the system with the running time folded into (b, f, p): their multiplier of the time equation is
+                     * lam_t + sum_r (gd_r nu_r+ + nu_r d(grad_d row_r)); take the rows' share out again (fold_running_time) */
+                    double corr = 0;
+#pragma unroll
+                    for (int r = RLTR; r <= RLRG; r++) {
+                        double nup = nd.dsg[r];
+                        if (mode == MODE_NEWTON) { double Sg, gphi; row_terms(j, r, mu_, Sg, gphi); nup = (Sg + dw)*nd.dsg[r] + gphi; }
+                        corr += gd[r]*nup;
+                    }
+                    if (mode == MODE_NEWTON) {
+                        const LossHess L = loss_hess(nd.x[VF], nd.x[VB], ej);
+                        const double W = nd.nu[RLTR]*U.rs[RLTR]*(-P.ct) + nd.nu[RLRG]*U.rs[RLRG]*P.cr;
+                        corr += W*(L.bd*d.dx[VB] + L.fd*d.dx[VF] + L.pd*d.dx[VP] + L.dd*dd);
+                    }
+                    c.S[nd.i*S_STRIDE + S_LT] -= corr;
                 }
             }
         }
@@ -1838,7 +1934,7 @@ struct Solver {
         double ap = 1.0, ad = 1.0;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<3>();
             const NodeT &nd = n[j];
             if (nd.node()) {
                 Dir dd; load_dir(j, dd);
@@ -1870,7 +1966,7 @@ struct Solver {
     {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<4>();
             Dir dd; load_dir(j, dd);
 #pragma unroll
             for (int k = 0; k < NV; k++) xt[j][k] = n[j].x[k] + alpha*dd.dx[k];
@@ -1889,7 +1985,7 @@ struct Solver {
         LogSum lsum;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<5>();
             const NodeT &nd = n[j];
             double prod = 1.0;
             if (nd.ival()) {
@@ -1914,7 +2010,7 @@ struct Solver {
                     if (hasU(k)) { const double s = ubv(j, k) - xt[j][k]; if (s <= 0) bad = 1; else prod *= s; }
                     else damp += xt[j][k] - lbv(k);
                 }
-                obj += objective_term(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
+                obj += objective_term<DYN == LOSS_INTEGRATED>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
             }
             lsum.add(prod);
         }
@@ -1933,7 +2029,7 @@ struct Solver {
         publish(xt);
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<6>();
             tc[j][0] = tc[j][1] = 0;
 #pragma unroll
             for (int r = 0; r < NR; r++) td[j][r] = 0;
@@ -1952,7 +2048,7 @@ struct Solver {
         publish_current();
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<7>();
             resc[j][0] = resc[j][1] = 0;
 #pragma unroll
             for (int r = 0; r < NR; r++) resd[j][r] = 0;
@@ -2063,8 +2159,8 @@ struct Solver {
                 if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             }
             double sl;
-            if (DYN) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
-            else sl = fmax(P.ct*fel, -P.cr*fel) + S0;
+            if (DYN == LOSS_TABLE) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
+            else sl = fmax(P.ct*fel, -P.cr*fel)*((DYN == LOSS_INTEGRATED) ? nd.ds : 1.0) + S0;      /* integrated losses: the slack is an energy per interval */
             nd.x[VF] = fel; nd.x[VP] = fpb; nd.x[VS] = sl;
         }
         __syncthreads();
@@ -2087,7 +2183,7 @@ struct Solver {
         /* ---- static data of the nodes: profile (coalesced reads), bounds (ocp.py:175-181, 247-272) ---- */
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<8>();
             NodeT &nd = n[j];
             nd.i = c.tid + j*c.nt;
             nd.bind(work + nd.i);
@@ -2150,7 +2246,7 @@ struct Solver {
             double gmax = 0, rmax[NR] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                node_fence();
+                node_fence<8>();
                 NodeT &nd = n[j];
                 if (nd.ival()) {
                     double of, op, os, oq, off, opp;
@@ -2164,11 +2260,11 @@ struct Solver {
                     if (nd.i > 0) mt = fmax(mt, fabs(e[j].tb));
                     mt = fmax(mt, fabs(e[j].tw));
                     nd.sct = mt > 100 ? 100/mt : 1;
-                    double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR];
-                    row_grads(j, e[j], gb, gf, gp, gs, gb1);
+                    double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
+                    row_grads(j, e[j], gb, gf, gp, gs, gb1, gd);
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        double m = fmax(fabs(gf[r]), fmax(fabs(gp[r]), fabs(gs[r])));
+                        double m = fmax(fmax(fabs(gf[r]), fabs(gd[r])), fmax(fabs(gp[r]), fabs(gs[r])));      /* (gd: the entries at t and t1) */
                         if (nd.i > 0) m = fmax(m, fabs(gb[r]));
                         if (nd.i < N - 1) m = fmax(m, fabs(gb1[r]));
                         rmax[r] = fmax(rmax[r], m);
@@ -2197,7 +2293,7 @@ struct Solver {
         const bool dualStart = ext && dual_in != nullptr;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<8>();
             const double *q = dualStart ? dual_in + (size_t)MSD_DUAL_STRIDE*n[j].i : nullptr;
 #pragma unroll
             for (int k = 0; k < NV; k++) {
@@ -2211,7 +2307,7 @@ struct Solver {
         evaluate_current();     /* resd = d(x) since the slacks are still zero */
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<8>();
             if (!n[j].ival()) continue;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -2329,7 +2425,7 @@ struct Solver {
                 double og[SPT][NV];
 #pragma unroll
                 for (int j = 0; j < SPT; j++) {
-                    node_fence();
+                    node_fence<9>();
                     double of = 0, op = 0, os = 0, oq = 0, off = 0, opp = 0;
                     if (n[j].node()) obj_grads(j, nb_q(j), of, op, os, oq, off, opp);
                     og[j][VT] = (n[j].i == N && !P.energyOpt) ? U.sf/P.objDen : 0.0; og[j][VB] = 0; og[j][VF] = of; og[j][VP] = op; og[j][VS] = os;
@@ -2339,7 +2435,7 @@ struct Solver {
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < SPT; j++) {
-                    node_fence();
+                    node_fence<9>();
                     const NodeT &nd = n[j];
                     if (!nd.node()) continue;
                     if (nd.i + 1 < N) og[j][VF] += c.o1[nd.i + 1];
@@ -2479,7 +2575,7 @@ struct Solver {
             /* accept x + alpha d; multipliers: equalities with the primal step, bounds with alpha_du (of the accepted direction) */
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                node_fence();
+                node_fence<10>();
                 NodeT &nd = n[j];
                 if (!nd.node()) continue;
                 Dir dd; load_dir(j, dd);
@@ -2517,7 +2613,7 @@ struct Solver {
         if (dual_out) {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                node_fence();
+                node_fence<11>();
                 const NodeT &nd = n[j];
                 if (!nd.node()) continue;
                 double *q = dual_out + (size_t)MSD_DUAL_STRIDE*nd.i;
@@ -2533,7 +2629,7 @@ struct Solver {
         const int stp = 4 + P.withPn;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            node_fence();
+            node_fence<11>();
             const NodeT &nd = n[j];
             if (nd.ival()) {
                 double *zi = z_out + stp*nd.i; int k = 0;
@@ -2569,7 +2665,7 @@ struct Solver {
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
  * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT, int SPT, int WPS, bool DYN, bool STREAM = false, bool GEN = false>
+template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {

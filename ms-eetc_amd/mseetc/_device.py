@@ -39,7 +39,7 @@ class ProblemDesc(ctypes.Structure):
                 ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
                 ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
                 ('start_kind', ctypes.c_int), ('integrator', ctypes.c_int), ('coll_degree', ctypes.c_int), ('newton_iterations', ctypes.c_int),
-                ('reserved_i', ctypes.c_int*3),
+                ('integrate_losses', ctypes.c_int), ('reserved_i', ctypes.c_int*2),
                 ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
                 ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
@@ -129,10 +129,10 @@ START = dict(reference=0, profile=1)   # MSD_START_*
 
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
               pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference',
-              integrator=None):
+              integrator=None, integrateLosses=False):
     """
     Fill a ProblemDesc; the numpy arrays are kept alive on the returned object.  integrator: None ('RK'), ('CVODES', absTol, relTol) or
-    ('IRK', order, maxIter, C, D) with the tables of mseetc.train.collocationTables.
+    ('IRK', order, maxIter, C, D) with the tables of mseetc.train.collocationTables.  integrateLosses: ocp.py:28,231-241.
     """
 
     d = ProblemDesc()
@@ -158,6 +158,7 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
         d.coll_tables = _d(keep[-1])
     elif integrator is not None:
         raise ValueError("Unknown integration method!")
+    d.integrate_losses = int(bool(integrateLosses))
     d._keep = keep
 
     return d

@@ -91,9 +91,6 @@ class casadiSolver():
 
         opts = OptionsCasadiSolver(optsDict)
 
-        if opts.integrateLosses:
-            raise NotImplementedError("integrateLosses=True (loss slacks from a time-domain integration inside the NLP, ocp.py:231-241) is not "
-                                      "transcribed on the device; postProcessDataFrame(integrateLosses=True) integrates the losses of a solution.")
 
         N = int(opts.numIntervals)
 
@@ -155,6 +152,13 @@ class casadiSolver():
         if integrator is not None and lossKind == LOSS_DYNAMIC:
             raise NotImplementedError("The 'IRK' and 'CVODES' transcriptions run with constant efficiencies; the dynamic loss model needs 'RK'.")
 
+        # loss slacks from the loss power integrated over the running time of the interval (ocp.py:231-241)
+        integrateLosses = bool(opts.integrateLosses) and bool(opts.energyOptimal)
+        if integrateLosses and (lossKind == LOSS_DYNAMIC or integrator is not None):
+            raise NotImplementedError("integrateLosses=True runs with constant efficiencies and the 'RK' transcription.")
+        if integrateLosses and lossKind == LOSS_NONE:
+            integrateLosses = False      # perfect efficiency: both loss integrals vanish and the rows reduce to s >= 0
+
         numSteps = io.numSteps if opts.integrationMethod != 'CVODES' else 1
         numApproxSteps = io.numApproxSteps if opts.integrationMethod != 'CVODES' else 0     # train.py:314
 
@@ -163,7 +167,8 @@ class casadiSolver():
             (model.sr0, model.sr1, model.sr2), train.g, rho, forceMax, forceMin if withRgBrake else 0.0, forceMinPn,
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
             self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
-            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint, integrator=integrator)
+            lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint, integrator=integrator,
+            integrateLosses=integrateLosses)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU

@@ -180,7 +180,7 @@ static const int var2loc[NV] = {LT, LB, LF, LP, LS};
 
 typedef struct {
     int N, withPn, hasPower, energyOpt, numSteps, numApprox, lossKind, maxIter;
-    int integ, collD, newtonIters;
+    int integ, collD, newtonIters, intLosses;
     double intAtol, intRtol;
     const double *ds, *grad, *curv, *bmax;
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
@@ -192,6 +192,7 @@ static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds
 {
     P->N = ip[OR_IP_N]; P->withPn = ip[OR_IP_WITH_PN]; P->hasPower = ip[OR_IP_HAS_POWER]; P->energyOpt = ip[OR_IP_ENERGY_OPT];
     P->numSteps = ip[OR_IP_NUM_STEPS]; P->numApprox = ip[OR_IP_NUM_APPROX]; P->lossKind = ip[OR_IP_LOSS_KIND]; P->maxIter = ip[OR_IP_MAX_ITER];
+    P->intLosses = ip[OR_IP_INTEGRATE_LOSSES];
     P->integ = ip[OR_IP_INTEGRATOR]; P->collD = ip[OR_IP_COLL_DEGREE]; P->newtonIters = ip[OR_IP_NEWTON_ITERS];
     P->intAtol = dp[OR_DP_INT_ATOL]; P->intRtol = dp[OR_DP_INT_RTOL];
     P->ds = ds; P->grad = grad; P->curv = curv; P->bmax = bmax;
@@ -398,6 +399,84 @@ static void dopri_tb(const Prob *P, jet b0, jet w, double G, double ds, jet *tau
     *tau = y[0]; *bplus = y[1];
 }
 
+/* ------------------------------------------------------------------------------------------
+ * integrateLosses (ocp.py:231-241 -> TrainIntegrator.initLosses/calcLosses, train.py:367-413): the loss slack of an interval bounds the
+ * loss POWER integrated over the interval's running time dt = t_{i+1} - t_i, along the speed of the time-domain model
+ * dv/dt = w - rr(v) - G started at v_i.  With constant efficiencies the loss power is (1-eta)/eta f v resp. -(1-eta_r) f v (train.py:199-212),
+ * so both integrals are multiples of the distance X(v_i, dt, w) = int_0^dt v.  The reference integrates with CVODES at abstol 1e-8,
+ * reltol 1e-6 (train.py:396; third-party SUNDIALS): here the adaptive Dormand-Prince pair at those tolerances, step control on the
+ * values, first and second derivatives wrt (v_i, dt, w) carried through the accepted steps.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double v, g[3], h[6]; } jet3;      /* h: 00 01 02 11 12 22 */
+static const int J3A[6] = {0, 0, 0, 1, 1, 2}, J3B[6] = {0, 1, 2, 1, 2, 2};
+static jet3 j3_const(double c) { jet3 r; memset(&r, 0, sizeof r); r.v = c; return r; }
+static jet3 j3_var(double v, int k) { jet3 r = j3_const(v); r.g[k] = 1; return r; }
+static jet3 j3_axpy(double s, jet3 a, jet3 y) { y.v += s*a.v; for (int k = 0; k < 3; k++) y.g[k] += s*a.g[k]; for (int k = 0; k < 6; k++) y.h[k] += s*a.h[k]; return y; }
+static jet3 j3_scale(jet3 a, double s) { return j3_axpy(s, a, j3_const(0)); }
+static jet3 j3_mul(jet3 a, jet3 b)
+{
+    jet3 r; r.v = a.v*b.v;
+    for (int k = 0; k < 3; k++) r.g[k] = a.v*b.g[k] + b.v*a.g[k];
+    for (int k = 0; k < 6; k++) r.h[k] = a.v*b.h[k] + b.v*a.h[k] + a.g[J3A[k]]*b.g[J3B[k]] + a.g[J3B[k]]*b.g[J3A[k]];
+    return r;
+}
+
+static jet3 loss_distance(const Prob *P, double v0, double dt0, double w0, double G)
+{
+    static const double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                 a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                 a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                 b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                 e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+    const double atol = 1e-8, rtol = 1e-6;      /* train.py:396 */
+    const jet3 dt = j3_var(dt0, 1), w = j3_var(w0, 2);
+    jet3 y[2] = {j3_var(v0, 0), j3_const(0)}, k[7][2], yn[2];
+    /* d(v, X)/dsigma = dt (w - rr(v) - G, v) on the unit interval */
+#define LRHS(vj, out) do { jet3 acc_ = j3_axpy(-P->sr1, (vj), j3_axpy(-P->sr2, j3_mul((vj), (vj)), j3_axpy(1.0, w, j3_const(-P->sr0 - G)))); \
+                           (out)[0] = j3_mul(dt, acc_); (out)[1] = j3_mul(dt, (vj)); } while (0)
+    double sig = 0, h = 0.05;
+    LRHS(y[0], k[0]);
+    for (int step = 0; step < 100000 && sig < 1.0; step++) {
+        if (sig + h > 1.0) h = 1.0 - sig;
+        jet3 s;
+        s = j3_axpy(h*a21, k[0][0], y[0]); LRHS(s, k[1]);
+        s = j3_axpy(h*a32, k[1][0], j3_axpy(h*a31, k[0][0], y[0])); LRHS(s, k[2]);
+        s = j3_axpy(h*a43, k[2][0], j3_axpy(h*a42, k[1][0], j3_axpy(h*a41, k[0][0], y[0]))); LRHS(s, k[3]);
+        s = j3_axpy(h*a54, k[3][0], j3_axpy(h*a53, k[2][0], j3_axpy(h*a52, k[1][0], j3_axpy(h*a51, k[0][0], y[0])))); LRHS(s, k[4]);
+        s = j3_axpy(h*a65, k[4][0], j3_axpy(h*a64, k[3][0], j3_axpy(h*a63, k[2][0], j3_axpy(h*a62, k[1][0], j3_axpy(h*a61, k[0][0], y[0]))))); LRHS(s, k[5]);
+        for (int m = 0; m < 2; m++)
+            yn[m] = j3_axpy(h*b6, k[5][m], j3_axpy(h*b5, k[4][m], j3_axpy(h*b4, k[3][m], j3_axpy(h*b3, k[2][m], j3_axpy(h*b1, k[0][m], y[m])))));
+        const int finite = isfinite(yn[0].v) && isfinite(yn[1].v);
+        double err = 0;
+        if (finite) {
+            LRHS(yn[0], k[6]);
+            for (int m = 0; m < 2; m++) {
+                const double sc = atol + rtol*fmax(fabs(y[m].v), fabs(yn[m].v));
+                err = fmax(err, fabs(h*(e1*k[0][m].v + e3*k[2][m].v + e4*k[3][m].v + e5*k[4][m].v + e6*k[5][m].v + e7*k[6][m].v)/sc));
+            }
+        }
+        if (finite && (err <= 1.0 || h < 1e-14)) {
+            sig += h;
+            for (int m = 0; m < 2; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-300) break;
+    }
+#undef LRHS
+    return y[1];
+}
+
+/* test hook: X and its nine derivatives (v, dt, w; vv, v dt, v w, dt dt, dt w, w w) */
+void oracle_loss_distance(const int *ip, const double *dp, double v0, double dt, double w, double grad, double curv, double *out10)
+{
+    Prob P; prob_init(&P, ip, dp, NULL, NULL, NULL, NULL);
+    const jet3 X = loss_distance(&P, v0, dt, w, track_resistance(&P, grad, curv));
+    out10[0] = X.v;
+    for (int k = 0; k < 3; k++) out10[1 + k] = X.g[k];
+    for (int k = 0; k < 6; k++) out10[4 + k] = X.h[k];
+}
+
 /*
  * One shooting interval: tau = t+ - t and b+ as jets in (b, w), w = Fel + Fpb.
  * numApprox == 0: RK4 on (t, b) jointly (train.py:296-301, dt/ds = ds/sqrt(b) :255,258).
@@ -490,11 +569,14 @@ void oracle_nlp_eval(const int *ip, const double *dp, const double *ds, const do
                     double lr[2][6];
                     loss_rows(&P.dyn, f, 0.5*(sqrt(b) + sqrt(b1)), lr);      /* ocp.py:221 mid-point speed */
                     g[r++] = s - lr[0][0]; g[r++] = s - lr[1][0];
+                } else if (P.intLosses) {
+                    const jet3 X = loss_distance(&P, sqrt(b), t1 - t, f + p, G);
+                    g[r++] = s - P.ct*f*X.v; g[r++] = s + P.cr*f*X.v;
                 } else { g[r++] = s - P.ct*f; g[r++] = s + P.cr*f; }
             }
         }
         if (P.energyOpt) {
-            J += ds[i]*(f + s);
+            J += P.intLosses ? ds[i]*f + s : ds[i]*(f + s);
             if (i > 0) { double fp = z[stp*(i - 1)]; J += 1e-3*(f - fp)*(f - fp); }
         } else {
             J += 1e-4*(f*f + p*p);
@@ -651,10 +733,15 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     e->d[RPW1] = W->rs[RPW1]*f*sb1;
     e->d[RACC] = W->rs[RACC]*(f + p - (P->sr0 + P->sr1*sb + P->sr2*b) - W->G[i]);
     double lr[2][6];
+    jet3 X = j3_const(0);
     if (P->lossKind == 2) {
         loss_rows(&P->dyn, f, 0.5*(sb + sb1), lr);
         e->d[RLTR] = W->rs[RLTR]*(s - lr[0][0]);
         e->d[RLRG] = W->rs[RLRG]*(s - lr[1][0]);
+    } else if (P->intLosses && P->energyOpt) {
+        X = loss_distance(P, sb, x1[VT] - x[VT], f + p, W->G[i]);                /* ocp.py:233 */
+        e->d[RLTR] = W->rs[RLTR]*(s - P->ct*f*X.v);
+        e->d[RLRG] = W->rs[RLRG]*(s + P->cr*f*X.v);
     } else {
         e->d[RLTR] = W->rs[RLTR]*(s - P->ct*f);
         e->d[RLRG] = W->rs[RLRG]*(s + P->cr*f);
@@ -690,6 +777,43 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
             e->hr[r][LB1][LB1] = -(gvv*vb1*vb1 + gv*vb1b1);
             e->hr[r][LB][LB1] = e->hr[r][LB1][LB] = -gvv*vb*vb1;
         }
+    } else if (P->intLosses && P->energyOpt) {
+        /* rows s + kappa f X(v(b), t1 - t, f + p): chain rule onto the local variables (b, f, p | t, t1) */
+        const double vb = 0.5/sb, vbb = -0.25/(b*sb);
+        enum { QB = 0, QF = 1, QP = 2, QD = 3 };      /* b, f, p, dt */
+        double X1[4], X2[4][4];
+        X1[QB] = X.g[0]*vb; X1[QF] = X.g[2]; X1[QP] = X.g[2]; X1[QD] = X.g[1];
+        X2[QB][QB] = X.h[0]*vb*vb + X.g[0]*vbb;
+        X2[QB][QF] = X2[QB][QP] = X.h[2]*vb; X2[QB][QD] = X.h[1]*vb;
+        X2[QF][QF] = X2[QF][QP] = X2[QP][QP] = X.h[5];
+        X2[QF][QD] = X2[QP][QD] = X.h[4];
+        X2[QD][QD] = X.h[3];
+        for (int a = 0; a < 4; a++) for (int c = 0; c < a; c++) X2[a][c] = X2[c][a];
+        double ph1[4], ph2[4][4];                         /* phi = f X */
+        for (int a = 0; a < 4; a++) {
+            ph1[a] = f*X1[a] + (a == QF ? X.v : 0.0);
+            for (int c = 0; c < 4; c++) ph2[a][c] = f*X2[a][c] + (a == QF ? X1[c] : 0.0) + (c == QF ? X1[a] : 0.0);
+        }
+        /* local columns of (b, f, p, dt): dt = t1 - t enters with +1 at LT1 and -1 at LT */
+        const int col[4] = {LB, LF, LP, -1};
+        for (int k = 0; k < 2; k++) {
+            const int r = k == 0 ? RLTR : RLRG;
+            const double kap = k == 0 ? -P->ct : P->cr;
+            e->gr[r][LS] = 1;
+            for (int a = 0; a < 4; a++) {
+                if (a == QP && !P->withPn) continue;
+                if (col[a] >= 0) e->gr[r][col[a]] += kap*ph1[a];
+                else { e->gr[r][LT1] += kap*ph1[a]; e->gr[r][LT] -= kap*ph1[a]; }
+                for (int c = 0; c < 4; c++) {
+                    if (c == QP && !P->withPn) continue;
+                    const double hv = kap*ph2[a][c];
+                    const int na = col[a] >= 0 ? 1 : 2, nc = col[c] >= 0 ? 1 : 2;
+                    const int ia[2] = {col[a] >= 0 ? col[a] : LT1, LT}, ic[2] = {col[c] >= 0 ? col[c] : LT1, LT};
+                    const double sa[2] = {1, -1};
+                    for (int m = 0; m < na; m++) for (int q = 0; q < nc; q++) e->hr[r][ia[m]][ic[q]] += (na == 2 ? sa[m] : 1)*(nc == 2 ? sa[q] : 1)*hv;
+                }
+            }
+        }
     } else {
         e->gr[RLTR][LS] = 1; e->gr[RLTR][LF] = -P->ct;
         e->gr[RLRG][LS] = 1; e->gr[RLRG][LF] = P->cr;
@@ -701,7 +825,7 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     /* objective of the interval (ocp.py:146-150, 223, 245, 276-284) */
     double sc = W->sf/P->objDen;
     if (P->energyOpt) {
-        e->objg[LF] = sc*P->ds[i]; e->objg[LS] = sc*P->ds[i];
+        e->objg[LF] = sc*P->ds[i]; e->objg[LS] = P->intLosses ? sc : sc*P->ds[i];      /* ocp.py:223 resp. :235 */
         if (i > 0) {
             double q = it[i - 1].x[VF];
             e->objg[LF] += sc*2e-3*(f - q); e->objg[LQ] = -sc*2e-3*(f - q);
@@ -720,7 +844,7 @@ static double objective_value(const Ws *W, const StageIt *it)
     for (int i = 0; i < W->N; i++) {
         double f = it[i].x[VF], p = P->withPn ? it[i].x[VP] : 0.0, s = it[i].x[VS];
         if (P->energyOpt) {
-            J += P->ds[i]*(f + s);
+            J += P->intLosses ? P->ds[i]*f + s : P->ds[i]*(f + s);
             if (i > 0) { double q = it[i - 1].x[VF]; J += 1e-3*(f - q)*(f - q); }
         } else J += 1e-4*(f*f + p*p);
     }
@@ -1717,7 +1841,7 @@ static void profile_guess(const Prob *P, double *z)
         }
         double sl;
         if (P->lossKind == 2) { double lr[2][6]; loss_rows(&P->dyn, fel, 0.5*(v[i] + v[i + 1]), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
-        else sl = fmax(P->ct*fel, -P->cr*fel) + S0;
+        else sl = fmax(P->ct*fel, -P->cr*fel)*(P->intLosses ? P->ds[i] : 1.0) + S0;      /* integrateLosses: the slack is an energy per interval */
         q[0] = fel; if (P->withPn) q[1] = fpb;
         q[nu] = sl; q[nu + 1] = ti; q[nu + 2] = b[i];
         acc += 2*P->ds[i]/(v[i] + v[i + 1]);

@@ -56,6 +56,8 @@ enum {
     OR_IP_INTEGRATOR,     /* shooting integrator (train.py:280-322): 0 simpleRK order 4, 1 simpleIRK (collocation), 2 adaptive (CVODES' role) */
     OR_IP_COLL_DEGREE,    /* collocation points per step (OptionsIRK.order, train.py:485); tables via oracle_set_collocation */
     OR_IP_NEWTON_ITERS,   /* OptionsIRK.maxIter (train.py:493)                               */
+    OR_IP_INTEGRATE_LOSSES, /* OptionsCasadiSolver.integrateLosses (ocp.py:28,231-241): loss slacks from the loss power integrated over the
+                             * running time of the interval (static efficiencies only)                                    */
     OR_IP_COUNT
 };
 

@@ -56,7 +56,7 @@ def oracle_problem(train, track, N, energyOptimal=True, losses='static', numStep
                 numSteps=numSteps, numApproxSteps=numApproxSteps)
     if integration:
         opts.update(integration)
-        if integration['integrationMethod'] == 'IRK':
+        if integration.get('integrationMethod') == 'IRK':
             from mseetc.train import collocationTables
             oracle.set_collocation(*collocationTables(integration['order'], integration.get('collMethod', 'radau')))
     if losses == 'static':

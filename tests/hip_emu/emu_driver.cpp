@@ -16,16 +16,16 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT, int SPT, bool DYN, bool STREAM = false, bool GEN = false>
+template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN));
+        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0));
         blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
-        std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN) : msd::work_doubles(NT*SPT))*(size_t)nscen);
+        std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
@@ -72,6 +72,13 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;
     const bool dyn = d->loss_kind == 2;
     const int nodes = P.N + 1;
+    if (d->integrate_losses) {      /* loss slacks from the integrated loss power (msd_lossint.hpp) */
+        if (dyn || d->integrator != 0) return -3;
+        if (nodes <= 64) run_blocks<64, 1, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+        else if (nodes <= 128) run_blocks<64, 2, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
+        else return -3;
+        return 0;
+    }
     if (d->integrator != 0) {       /* the kernels with the collocation / adaptive shooting integrators: two geometries are enough here */
         if (dyn) return -3;
         if (nodes <= 64) run_blocks<64, 1, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);

@@ -1,9 +1,14 @@
 """
+Transcription options beyond the default (f4 of SURVEY.md section 8): the other two shooting integrators and integrateLosses.
+
 The other two shooting integrators of the NLP (reference: OptionsCasadiSolver.integrationMethod = 'IRK' / 'CVODES', ocp.py:26,92 ->
 TrainIntegrator, train.py:303-322): collocation (casadi.simpleIRK) and integration to tolerances (CVODES' role, played by an adaptive
 Dormand-Prince pair).  CPU part: the oracle's restatement against checkers that share nothing with it (the numpy collocation equations
 solved by scipy, a DOP853 reference solution, finite differences of the oracle's own values) and the emulated kernel against the
 oracle.  GPU part: the HIP kernels against the oracle through the C ABI.
+
+integrateLosses (ocp.py:28,231-241): the loss slacks bound the loss power integrated over the running time of the interval; oracle against the
+closed-form solution of the time-domain speed equation and finite differences, kernels against the oracle.
 """
 
 import ctypes
@@ -199,4 +204,143 @@ def test_gpu_other_integrators_surface_and_limits():
     with pytest.raises(DeviceError):
         casadiSolver(train, track, dict(numIntervals=700, integrationMethod='CVODES')).solve(1541)      # beyond the LDS-resident kernels
     with pytest.raises(NotImplementedError):
-        casadiSolver(train, track, dict(numIntervals=50, integrateLosses=True))
+        casadiSolver(train, track, dict(numIntervals=50, integrateLosses=True, integrationMethod='IRK'))
+    with pytest.raises(DeviceError):
+        casadiSolver(train, track, dict(numIntervals=700, integrateLosses=True)).solve(1541)
+    # integrateLosses through the reference's surface: same optimum as the mid-point rows to about 1e-4 (X = ds up to the RK4 error)
+    il = casadiSolver(train, track, dict(numIntervals=100, integrateLosses=True, integrationOptions=dict(numApproxSteps=1)))
+    dfi, sti = il.solve(1541)
+    assert abs(sti['Cost'] - rk.solve(1541)[1]['Cost']) < 3e-4*sti['Cost']
+    assert il.solve(1541, initialVelocity=5, terminalVelocity=3)[1]['Solver status'] == 'Solve_Succeeded'
+
+
+# ---- integrateLosses ------------------------------------------------------------------------------------------------------------------
+
+def _distance_closed_form(a, sr1, sr2, v0, dt):
+    """
+    X(dt) for dv/dt = a - sr1 v - sr2 v^2 (a = w - sr0 - G), v(0) = v0: the Riccati equation has the roots v+- of sr2 v^2 + sr1 v - a = 0;
+    with k = sr2 (v+ - v-) and C = (v0 - v+)/(v0 - v-):  X = v+ dt + ln((1 - C exp(-k dt))/(1 - C))/sr2.  Complex arithmetic covers the
+    oscillatory case (a below -sr1^2/(4 sr2): strong braking), where the roots are a conjugate pair and X stays real.
+    """
+    disc = np.sqrt(complex(sr1*sr1 + 4*sr2*a))
+    vp, vm = (-sr1 + disc)/(2*sr2), (-sr1 - disc)/(2*sr2)
+    k, C = sr2*(vp - vm), (v0 - vp)/(v0 - vm)
+    X = vp*dt + np.log((1 - C*np.exp(-k*dt))/(1 - C))/sr2
+    assert abs(X.imag) < 1e-9*max(1.0, abs(X.real))
+    return X.real
+
+
+def _loss_distance(prob, v0, dt, w, grad=0.0, curv=0.0):
+    L = oracle.lib()
+    dptr, iptr = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    L.oracle_loss_distance.restype = None
+    L.oracle_loss_distance.argtypes = [iptr, dptr] + [ctypes.c_double]*5 + [dptr]
+    out = np.zeros(10)
+    L.oracle_loss_distance(oracle._i(prob.ip), oracle._d(prob.dp), v0, dt, w, grad, curv, oracle._d(out))
+    return out
+
+
+def test_oracle_loss_distance_vs_closed_form_and_finite_differences():
+    prob = _problem(numApprox=1, integration=dict(integrateLosses=True))
+    dp = prob.dp
+    rng = np.random.default_rng(13)
+    for _ in range(20):
+        v0, dt, w, grad = rng.uniform(2, 40), rng.uniform(1, 30), rng.uniform(-0.6, 0.5), rng.uniform(-0.012, 0.012)
+        if v0 + dt*(w - 0.15) < 1.0:
+            continue       # the train would stop within the interval
+        out = _loss_distance(prob, v0, dt, w, grad)
+        a = w - dp[DP['SR0']] - dp[DP['G']]*grad/dp[DP['RHO']]
+        X = _distance_closed_form(a, dp[DP['SR1']], dp[DP['SR2']], v0, dt)
+        assert abs(out[0] - X) <= 2e-6*abs(X)                    # reltol 1e-6 per step (train.py:396)
+        h = 1e-4
+        g = [(_loss_distance(prob, v0 + h, dt, w, grad) - _loss_distance(prob, v0 - h, dt, w, grad))/(2*h),
+             (_loss_distance(prob, v0, dt + h, w, grad) - _loss_distance(prob, v0, dt - h, w, grad))/(2*h),
+             (_loss_distance(prob, v0, dt, w + h, grad) - _loss_distance(prob, v0, dt, w - h, grad))/(2*h)]
+        fd = np.array([g[0][0], g[1][0], g[2][0], g[0][1], g[0][2], g[0][3], g[1][2], g[1][3], g[2][3]])
+        # the differences see the step-size controller's decisions (1e-6 relative on X): loose bound on the first, looser on the second
+        # derivatives; the closed form pins the first derivatives independently below
+        scale = np.maximum(np.abs(fd), 1e-3*np.max(np.abs(fd[:3])))
+        assert np.max(np.abs(out[1:4] - fd[:3])/scale[:3]) < 1e-3
+        assert np.max(np.abs(out[4:] - fd[3:])/np.maximum(np.abs(fd[3:]), 1e-2*np.max(np.abs(fd[3:])))) < 5e-2
+        hh = 1e-5
+        gX = [(_distance_closed_form(a, dp[DP['SR1']], dp[DP['SR2']], v0 + hh, dt) - _distance_closed_form(a, dp[DP['SR1']], dp[DP['SR2']], v0 - hh, dt))/(2*hh),
+              (_distance_closed_form(a, dp[DP['SR1']], dp[DP['SR2']], v0, dt + hh) - _distance_closed_form(a, dp[DP['SR1']], dp[DP['SR2']], v0, dt - hh))/(2*hh),
+              (_distance_closed_form(a + hh, dp[DP['SR1']], dp[DP['SR2']], v0, dt) - _distance_closed_form(a - hh, dp[DP['SR1']], dp[DP['SR2']], v0, dt))/(2*hh)]
+        assert np.max(np.abs(out[1:4] - np.array(gX))/np.abs(gX)) < 2e-5
+
+
+def test_oracle_nlp_with_integrated_losses():
+    """
+    At a solution the running time, the speeds and the forces of an interval are consistent, so the distance X covered in the running
+    time is the interval length up to the integration error of the one-step RK4 map: the optimum is that of the mid-point transcription
+    to about 1e-4, and the loss rows hold with X from the closed form.  Both starts reach it.
+    """
+    train, track = cases.train_default(), cases.track_00()
+    mid = cases.oracle_problem(train, track, 100)
+    il = cases.oracle_problem(train, track, 100, integration=dict(integrateLosses=True))
+    r0 = oracle.solve(mid, mid.scenario(1541.0), start='profile')
+    objs = []
+    for start in ('profile', 'reference'):
+        r = oracle.solve(il, il.scenario(1541.0), start=start)
+        assert r['stats']['STATUS'] == 0
+        objs.append(r['stats']['OBJ'])
+    assert abs(objs[0] - objs[1]) < 1e-7*objs[0]
+    assert abs(objs[0] - r0['stats']['OBJ']) < 3e-4*objs[0]
+    # rows at the solution, X from the closed form
+    z = r['z']; dp = il.dp; N = 100; stp = 5
+    ct, cr = dp[DP['LOSS_CT']], dp[DP['LOSS_CR']]
+    worst = 0.0
+    for i in range(N):
+        f, p, s, t, b = z[stp*i:stp*i + 5]
+        t1 = z[stp*(i + 1) + 3] if i + 1 < N else z[stp*N]
+        G = dp[DP['G']]*il.grad[i]/dp[DP['RHO']]
+        X = _distance_closed_form(f + p - dp[DP['SR0']] - G, dp[DP['SR1']], dp[DP['SR2']], np.sqrt(b), t1 - t)
+        worst = min(worst, (s - ct*f*X)/max(1.0, abs(s)), (s + cr*f*X)/max(1.0, abs(s)))
+        assert abs(X - il.ds[i]) < 2e-2*il.ds[i]
+    assert worst > -1e-5
+
+
+@pytest.mark.parametrize('N,crop,T,start', [(30, 12000, 520.0, 'reference'), (70, 30000, 1100.0, 'profile')])
+def test_emulated_kernel_with_integrated_losses_matches_oracle(N, crop, T, start):
+    from test_kernel_emulation import load_emulation
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    lib = load_emulation()
+    train, track = cases.train_default(), cases.track_00(crop)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrateLosses=True, integrationOptions=dict(numSteps=1, numApproxSteps=1)),
+                          startingPoint=start)
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N, integration=dict(integrateLosses=True))
+    ref = oracle.solve(prob, prob.scenario(T), start=start)
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
+    # (the folded stage blocks of the kernel against the oracle's unfolded system: the multipliers of the time equation agree)
+    assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,crop,T,track_name', [(100, None, 1541.0, '00'), (60, 30000, 1100.0, '00'), (200, None, 1900.0, 'CH'), (30, 12000, 520.0, '00')])
+def test_gpu_integrated_losses_vs_oracle(N, crop, T, track_name):
+    from mseetc.ocp import casadiSolver
+    train = cases.train_default()
+    track = cases.track_CH() if track_name == 'CH' else (cases.track_00(crop) if crop else cases.track_00())
+    for start in ('profile', 'reference'):
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=400, integrateLosses=True, integrationOptions=dict(numApproxSteps=1)), startingPoint=start)
+        Ts = T*np.array([1.0, 1.05, 1.12])
+        res = solver.solveBatch(Ts, multipliers=True)
+        prob = cases.oracle_problem(train, track, N, integration=dict(integrateLosses=True))
+        for k, Tk in enumerate(Ts):
+            ref = oracle.solve(prob, prob.scenario(Tk), start=start)
+            assert res['status'][k] == 0 and ref['stats']['STATUS'] == 0
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+            assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-5
+            assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
+            # multipliers in the reference's row order: the time-equation multipliers come out of the folded stage blocks (msd_kernel.hpp: direction)
+            # (multipliers of a solve converged to 1e-8 are less sharp than its primal point when the iterate paths differ in the last bits;
+            #  on one path -- the emulation test above -- they agree to 1e-6)
+            assert np.max(np.abs(res['lam_g'][k] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 5e-3
