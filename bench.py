@@ -335,6 +335,19 @@ def alt_workloads(args, device):
         alt[name] = dict(summarize(scen.shape[0], solver.numIntervals, 3, e, ms, st), workload=text)
         solver.close()
 
+    # the other transcriptions of the reference's options on the config-1 batch (their own kernel instantiations, not tuned)
+    from mseetc.ocp import casadiSolver
+    train, track, N = wl.config('c1')
+    T = wl.c1_times(PER_GPU_BATCH['c1'], seed=20260612)
+    for name, extra, io in (("integrate_losses", dict(integrateLosses=True), dict(numSteps=1, numApproxSteps=1)),
+                            ("irk_radau2", dict(integrationMethod='IRK'), dict(order=2, numSteps=1, numApproxSteps=1)),
+                            ("cvodes_tolerances", dict(integrationMethod='CVODES'), dict())):
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationOptions=io, **extra), device=device, startingPoint='profile')
+        scen = solver._scenarios(T, 0, 1, 1)
+        e, ms, st = measure(solver, scen, None, 3, 1)
+        alt[name] = dict(summarize(scen.shape[0], N, 3, e, ms, st), workload="config 1 batch with {} {}".format(extra, io))
+        solver.close()
+
     # config 4: shrinking-horizon MPC, 512 scenarios per GPU (4096 over 8), 50 re-solves each: wall time of the whole loop
     train, track, N = wl.config('c4')
     T = wl.c1_times(512, seed=20260615)

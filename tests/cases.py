@@ -73,6 +73,7 @@ def numpy_nlp(prob):
                          ds=prob.ds, grad=prob.grad, curv=prob.curv, sr0=dp[DP['SR0']], sr1=dp[DP['SR1']], sr2=dp[DP['SR2']],
                          g=dp[DP['G']], rho=dp[DP['RHO']], fmax=dp[DP['FMAX']], fmin=dp[DP['FMIN']], fminPn=dp[DP['FMIN_PN']],
                          pwUpper=dp[DP['PW_UPPER']], pwLower=dp[DP['PW_LOWER']], accMin=dp[DP['ACC_MIN']], accMax=dp[DP['ACC_MAX']],
-                         ct=dp[DP['LOSS_CT']], cr=dp[DP['LOSS_CR']], vminSq=dp[DP['VMIN_SQ']], objDen=dp[DP['OBJ_DEN']], bmax=prob.bmax)
+                         ct=dp[DP['LOSS_CT']], cr=dp[DP['LOSS_CR']], vminSq=dp[DP['VMIN_SQ']], objDen=dp[DP['OBJ_DEN']], bmax=prob.bmax,
+                         integrateLosses=bool(ip[IP['INTEGRATE_LOSSES']]))
 
 

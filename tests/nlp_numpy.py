@@ -15,7 +15,7 @@ import numpy as np
 class NLP():
 
     def __init__(self, *, N, withPn, hasPower, energyOptimal, numSteps, numApprox, ds, grad, curv,
-                 sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, bmax):
+                 sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, bmax, integrateLosses=False):
         self.__dict__.update(locals())
         del self.__dict__['self']
         self.ds = np.asarray(ds, float)
@@ -77,6 +77,32 @@ class NLP():
             prev = cur
         return tau, prev
 
+    # ---- integrateLosses (ocp.py:231-241, train.py:367-413) ------------------------------------------
+
+    def _distance(self, v0, dt, w):
+        """
+        Distance covered in the time dt by dv/dt = a - sr1 v - sr2 v^2, a = w - sr0 - G, from v0: the closed-form solution of this
+        Riccati equation (no integrator involved).  D = sr1^2 + 4 sr2 a > 0: roots v+- of sr2 v^2 + sr1 v - a, k = sr2 (v+ - v-),
+        C = (v0 - v+)/(v0 - v-), X = v+ dt + ln((1 - C exp(-k dt))/(1 - C))/sr2.  D < 0 (strong braking): u = v + sr1/(2 sr2) obeys
+        du/dt = -sr2 (u^2 + om^2), om^2 = -D/(4 sr2^2): X = ln(cos(th0 - sr2 om dt)/cos(th0))/sr2 - sr1 dt/(2 sr2), th0 = atan(u0/om).
+        Every operation is analytic in (v0, dt, w): complex-step differentiation goes through.
+        """
+        sr1, sr2 = self.sr1, self.sr2
+        a = w - self.sr0 - self.G
+        D = sr1*sr1 + 4*sr2*a
+        pos = D.real > 0
+        Dp = np.where(pos, D, 1.0)
+        rt = np.sqrt(Dp)
+        vp, vm = (-sr1 + rt)/(2*sr2), (-sr1 - rt)/(2*sr2)
+        C = (v0 - vp)/(v0 - vm)
+        Xp = vp*dt + np.log((1 - C*np.exp(-sr2*(vp - vm)*dt))/(1 - C))/sr2
+        Dn = np.where(pos, -1.0, D)
+        om = np.sqrt(-Dn)/(2*sr2)
+        th0 = np.arctan((v0 + sr1/(2*sr2))/om)
+        with np.errstate(invalid='ignore', divide='ignore'):      # (the branch that does not apply may be evaluated outside its domain)
+            Xn = np.log(np.cos(th0 - sr2*om*dt)/np.cos(th0))/sr2 - sr1*dt/(2*sr2)
+        return np.where(pos, Xp, Xn)
+
     # ---- NLP functions -----------------------------------------------------------------------
 
     def rows(self, f, p, s, t0, b0, t1, b1):
@@ -87,7 +113,10 @@ class NLP():
             out += [f*np.sqrt(b0), f*np.sqrt(b1)]
         out += [f + p - (self.sr0 + self.sr1*np.sqrt(b0) + self.sr2*b0) - self.G]
         out += [t1 - (t0 + tau), b1 - bp]
-        if self.energyOptimal:
+        if self.energyOptimal and self.integrateLosses:
+            X = self._distance(np.sqrt(b0), t1 - t0, f + p)       # ocp.py:233 with constant efficiencies: both integrals are multiples of X
+            out += [s - self.ct*f*X, s + self.cr*f*X]
+        elif self.energyOptimal:
             out += [s - self.ct*f, s + self.cr*f]
         return np.stack(out, axis=1)
 
@@ -98,7 +127,7 @@ class NLP():
     def obj(self, z):
         f, p, s, t, b = self.split(z)
         if self.energyOptimal:
-            J = np.sum(self.ds*(f + s)) + 1e-3*np.sum((f[1:] - f[:-1])**2)
+            J = (np.sum(self.ds*f) + np.sum(s) if self.integrateLosses else np.sum(self.ds*(f + s))) + 1e-3*np.sum((f[1:] - f[:-1])**2)      # ocp.py:235 / :223
         else:
             J = t[-1] + 1e-4*(np.sum(f*f) + np.sum(p*p))
         return J/self.objDen

@@ -20,6 +20,7 @@ from scipy.integrate import solve_ivp
 import cases
 from oracle import oracle
 from oracle.oracle import DP
+from nlp_numpy import kkt_certificate
 from test_integrators import _irk_numpy
 
 IRK2 = dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10)
@@ -344,3 +345,44 @@ def test_gpu_integrated_losses_vs_oracle(N, crop, T, track_name):
             # (multipliers of a solve converged to 1e-8 are less sharp than its primal point when the iterate paths differ in the last bits;
             #  on one path -- the emulation test above -- they agree to 1e-6)
             assert np.max(np.abs(res['lam_g'][k] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 5e-3
+
+
+def _certify(nlp, z, lam_g, dp, loss_rtol):
+    """
+    First-order conditions of the integrateLosses NLP checked with the numpy restatement (tests/nlp_numpy.py), whose loss rows use the
+    CLOSED-FORM distance: the rows of the solver (1e-6 integration tolerance, train.py:396) and of the checker differ by that much.
+    """
+    cert = kkt_certificate(nlp, z, lam_g, dp[DP['T0']], dp[DP['TEND']], dp[DP['V0SQ']], dp[DP['VNSQ']])
+    assert cert['feas_g'] < loss_rtol and cert['feas_z'] < 1.5e-8
+    assert cert['stat'] < 2e-5 and cert['sign_g'] < 2e-5
+    return cert
+
+
+@pytest.mark.parametrize('track_name,N,T', [('00', 100, 1600.0), ('CH', 200, 1300.0)])
+def test_kkt_certificate_of_oracle_solution_with_integrated_losses(track_name, N, T):
+    train = cases.train_default()
+    track = cases.track_CH() if track_name == 'CH' else cases.track_00()
+    prob = cases.oracle_problem(train, track, N, integration=dict(integrateLosses=True))
+    dp = prob.scenario(T)
+    out = oracle.solve(prob, dp, start='profile')
+    assert out['stats']['STATUS'] == 0
+    nlp = cases.numpy_nlp(prob)
+    assert nlp.integrateLosses
+    z = out['z']
+    obj, g = oracle.nlp_eval(prob, dp, z)
+    assert abs(obj - nlp.obj(z)) <= 1e-12*abs(obj)
+    assert np.max(np.abs(g - nlp.cons(z))/np.maximum(1.0, np.abs(g))) < 5e-6       # integrated against closed-form loss rows
+    _certify(nlp, z, out['lam_g'], dp, 2e-5)
+
+
+@pytest.mark.gpu
+def test_kkt_certificate_of_gpu_solution_with_integrated_losses():
+    from mseetc.ocp import casadiSolver
+    train, track = cases.train_default(), cases.track_00()
+    solver = casadiSolver(train, track, dict(numIntervals=100, integrateLosses=True, integrationOptions=dict(numApproxSteps=1)))
+    res = solver.solveBatch([1541.0, 1700.0], multipliers=True)
+    prob = cases.oracle_problem(train, track, 100, integration=dict(integrateLosses=True))
+    nlp = cases.numpy_nlp(prob)
+    for k, T in enumerate((1541.0, 1700.0)):
+        assert res['status'][k] == 0
+        _certify(nlp, res['z'][k], res['lam_g'][k], prob.scenario(T), 2e-5)
