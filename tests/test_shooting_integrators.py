@@ -386,3 +386,43 @@ def test_kkt_certificate_of_gpu_solution_with_integrated_losses():
     for k, T in enumerate((1541.0, 1700.0)):
         assert res['status'][k] == 0
         _certify(nlp, res['z'][k], res['lam_g'][k], prob.scenario(T), 2e-5)
+
+
+# ---- random problems with the other transcriptions ---------------------------------------------------------------------------------
+
+TRANSCRIPTIONS = {
+    'intloss': (dict(integrateLosses=True), dict(numSteps=1, numApproxSteps=1), dict(integrateLosses=True)),
+    'irk': (dict(integrationMethod='IRK'), dict(order=2, numSteps=1, numApproxSteps=1), IRK2),
+    'irk3x2': (dict(integrationMethod='IRK'), dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=2), IRK3L),
+    'cvodes': (dict(integrationMethod='CVODES'), dict(), ADAPT),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('which', sorted(TRANSCRIPTIONS))
+def test_gpu_randomized_problems_with_other_transcriptions(which, seed, tmp_path):
+    """
+    The random tracks / trains / horizons of test_gpu_parity.test_randomized_problems_vs_oracle (up to 255 intervals: one or two waves per
+    scenario) under integrateLosses, the collocation and the adaptive shooting integrator: running times 10 ... 40 % above the minimum
+    the time-optimal twin finds, energy and trajectory against the oracle.
+    """
+    from test_gpu_parity import _random_problem
+    from mseetc.ocp import casadiSolver
+    train, track, N, rng = _random_problem(seed, tmp_path)
+    v0, vN = float(rng.uniform(2, 15)), float(rng.uniform(2, 15))
+    extra, io, integration = TRANSCRIPTIONS[which]
+    fast = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, energyOptimal=False, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+    rt = fast.solveBatch([3*track.length/train.velocityMax], initialVelocity=v0, terminalVelocity=vN)
+    assert rt['status'][0] == 0
+    T = float(rt['z'][0][-2])*np.array([1.1, 1.4])
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationOptions=io, **extra), startingPoint='profile')
+    res = solver.solveBatch(T, initialVelocity=v0, terminalVelocity=vN)
+    assert np.all(res['status'] == 0), (which, seed, N, res['status'])
+    prob = cases.oracle_problem(train, track, N, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), integration=integration)
+    for k in range(2):
+        ref = oracle.solve(prob, prob.scenario(float(T[k]), 0.0, vN, v0), start='profile')
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ']), (which, seed, N, k)
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4, (which, seed, N, k)
+    solver.close(); fast.close()
