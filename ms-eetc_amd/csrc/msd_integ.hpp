@@ -80,6 +80,7 @@ __device__ inline T irk_b(const DevProb &P, T b0, T w, double G, double ds, doub
         double v[COLL_MAX], A[COLL_MAX][COLL_MAX], F[COLL_MAX];
         int piv[COLL_MAX];
         const double xv = jval(xb);
+        bool valid = true;
         for (int j = 0; j < d; j++) v[j] = xv;
         for (int it = 0; it <= P.newtonIters; it++) {
             double fmaxabs = 0;
@@ -92,12 +93,14 @@ __device__ inline T irk_b(const DevProb &P, T b0, T w, double G, double ds, doub
                 F[j] = dt*f - p;
                 fmaxabs = fmax(fmaxabs, fabs(F[j]));
             }
-            /* the Jacobian of the last pass is the one the derivatives use */
-            if (!lu_factor(d, A, piv)) break;
+            /* the Jacobian of the last pass is the one the derivatives use; a stage value that left the domain (speed squared below
+             * zero) makes it NaN: the step is reported as NaN, which the line search treats as an invalid trial point */
+            if (!lu_factor(d, A, piv)) { valid = false; break; }
             if (it == P.newtonIters || !isfinite(fmaxabs) || fmaxabs <= 1e-13*fmax(1.0, fabs(xv))) break;
             lu_solve(d, A, piv, F);
             for (int j = 0; j < d; j++) v[j] -= F[j];
         }
+        if (!valid) { if (t) *t = jconst(T(), NAN); return jconst(T(), NAN); }
         T V[COLL_MAX], R[COLL_MAX];
         for (int j = 0; j < d; j++) V[j] = jconst(T(), v[j]);
         if (jcomps(xb) > 1) {

@@ -303,6 +303,7 @@ static jet irk_b(const Prob *P, jet b0, jet w, double G, double ds, double H, je
     for (int k = 0; k < P->numSteps; k++) {
         double v[COLL_MAX], A[COLL_MAX][COLL_MAX], F[COLL_MAX];
         int piv[COLL_MAX];
+        int valid = 1;
         for (int j = 0; j < d; j++) v[j] = xb.v;
         for (int it = 0; it <= P->newtonIters; it++) {
             double fmaxabs = 0;
@@ -315,12 +316,13 @@ static jet irk_b(const Prob *P, jet b0, jet w, double G, double ds, double H, je
                 F[j] = dt*f - p;
                 fmaxabs = fmax(fmaxabs, fabs(F[j]));
             }
-            /* the Jacobian of the last pass is the one the derivatives use */
-            if (!lu_factor(d, A, piv)) break;
+            /* the Jacobian of the last pass is the one the derivatives use; a stage value outside the domain makes it NaN: the step is NaN */
+            if (!lu_factor(d, A, piv)) { valid = 0; break; }
             if (it == P->newtonIters || !isfinite(fmaxabs) || fmaxabs <= 1e-13*fmax(1.0, fabs(xb.v))) break;
             lu_solve(d, A, piv, F);
             for (int j = 0; j < d; j++) v[j] -= F[j];
         }
+        if (!valid) { if (t) *t = j_const(NAN); return j_const(NAN); }
         jet V[COLL_MAX], R[COLL_MAX];
         for (int j = 0; j < d; j++) V[j] = j_const(v[j]);
         for (int pass = 0; pass < 2; pass++) {
