@@ -37,6 +37,7 @@ for p in (str(ROOT / 'ms-eetc_amd'), str(ROOT)):
 
 BYTES_PER_STAGE_ITER = 904.0   # SURVEY.md section 8d, streaming model S (nu = 2): 113 doubles
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector double precision = half of the 157.3 TFLOPS FP32 vector spec of MI355X_MICROARCH.md (~78 TF/s); secondary bound
 
 
 def usable_cores():
@@ -184,14 +185,14 @@ def hbm_traffic(entry):
 
     tf = ROOT / 'profiles' / 'hbm_traffic.json'
     if not tf.exists():
-        return None, "no profiles/hbm_traffic.json"
+        return None, "no profiles/hbm_traffic.json", None
     try:
         rec = json.loads(tf.read_text())
     except Exception:
-        return None, "unreadable profiles/hbm_traffic.json"
+        return None, "unreadable profiles/hbm_traffic.json", None
     if rec.get('kernel_digest') != entry.hip_digest():
-        return None, "profiles/hbm_traffic.json was measured on another build of the kernel (digest mismatch): re-run tools/profile_round.sh"
-    return rec.get('bytes_per_launch'), rec.get('source')
+        return None, "profiles/hbm_traffic.json was measured on another build of the kernel (digest mismatch): re-run tools/profile_round.sh", None
+    return rec.get('bytes_per_launch'), rec.get('source'), rec.get('issue')
 
 
 def main():
@@ -272,7 +273,7 @@ def main():
 
         stage_iters = float(N*np.sum(iters))                 # units one launch processes (this rank)
         achieved = BYTES_PER_STAGE_ITER*stage_iters/(launch_ms*1e-3)/1e9
-        traffic, traffic_source = hbm_traffic(entry)
+        traffic, traffic_source, issue = hbm_traffic(entry)
         geo = solver.problem.geometry()
 
         start_text = ("every solve starts from the device-built speed profile (no information from earlier solves; same optimum as the reference's cold start)"
@@ -291,7 +292,11 @@ def main():
                          "traffic_source": traffic_source,
                          "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d); iterate is LDS/register resident, so real HBM traffic is far below S",
                          "kernel": "msd::solve_kernel<{},{}> (one workgroup of {} threads per scenario, {} shooting nodes per lane)".format(geo[0], geo[1], geo[0], geo[1]),
-                         "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters},
+                         "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters,
+                         # what bounds the kernel in practice (SQ counters of the profiling pass, same digest rule as `traffic`): a latency-bound
+                         # double-precision instruction stream, one wave per SIMD
+                         "issue": issue, "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "fp64_valu_frac_model": (400.0*stage_iters/(launch_ms*1e-3)/1e12)/FP64_VALU_PEAK_TFLOPS},
         }
 
         solver.close()

@@ -34,4 +34,11 @@ rec = {
               "(the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; the kernel's traffic is 8 B/lane scratch and result stores)".format(nf, nw),
     "compulsory_bytes_per_launch": int(line['config']['batch_per_gpu']*(8*(5*line['config']['num_intervals'] + 2) + 168)),
 }
+# issue statistics of the same kernel from the SQ pass (units of four cycles per wave, summed over the waves of a launch)
+sq = {k: mean_counter('sq', k)[0] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU')}
+if all(v is not None for v in sq.values()):
+    rec["issue"] = {"valu_instructions_per_launch": sq['SQ_INSTS_VALU'], "lds_instructions_per_launch": sq['SQ_INSTS_LDS'], "salu_instructions_per_launch": sq['SQ_INSTS_SALU'],
+                    "wave_life_executing": sq['SQ_ACTIVE_INST_ANY']/sq['SQ_WAVE_CYCLES'], "wave_life_waiting_on_counters": sq['SQ_WAIT_ANY']/sq['SQ_WAVE_CYCLES'],
+                    "wave_life_waiting_for_instructions": sq['SQ_WAIT_INST_ANY']/sq['SQ_WAVE_CYCLES'],
+                    "source": "rocprofv3 --pmc SQ_* pass of tools/profile_round.sh (one wave per SIMD: nothing hides a wave's own latencies)"}
 print(json.dumps(rec, indent=1))
