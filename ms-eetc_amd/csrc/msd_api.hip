@@ -8,10 +8,12 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -44,6 +46,7 @@ struct msd_problem {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
+    double *h_stage = nullptr; size_t cap_stage = 0;  /* pinned staging buffer for the profile upload */
     double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
     int *d_queue = nullptr;                           /* scenario counters of the launches (a ring: launches in flight on the stream each own one) */
     int queue_slot = 0;
@@ -123,6 +126,33 @@ static int cu_count(int device, int *out)
 }
 
 /*
+ * Dynamic-LDS attribute and resident workgroups per compute unit of a kernel: asked of the runtime once per (device, kernel, LDS size)
+ * -- a receding-horizon loop reconfigures its handle for every re-solve and the two queries cost more than the rest of it.
+ */
+static int kernel_limits(int device, const void *fn, int threads, size_t lds, int *per_cu)
+{
+    struct Info { size_t lds_attr = 0; std::map<size_t, int> occupancy; };
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, Info> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    Info &info = cache[{device, fn}];
+    if (lds > info.lds_attr) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        info.lds_attr = lds;
+    }
+    /* occupancy by LDS size in steps of 8 KB, asked for the upper end of the step (never more workgroups than fit) */
+    const size_t step = 8*1024, top = std::min<size_t>(((lds + step - 1)/step)*step, 160*1024);
+    auto it = info.occupancy.find(top);
+    if (it == info.occupancy.end()) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, top) != hipSuccess || n < 1) n = 1;
+        it = info.occupancy.emplace(top, n).first;
+    }
+    *per_cu = it->second;
+    return MSD_OK;
+}
+
+/*
  * Load a problem into a handle: kernel geometry for its horizon, scalars, and the profile arrays in the handle's device
  * buffer (grown when the horizon or the loss table outgrows it).  Streams, events and the scenario buffers are kept.
  */
@@ -155,13 +185,22 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         h->cap_N = N;
     }
     {
-        std::vector<double> host(5*(size_t)N + 2);
-        double *ds = host.data(), *grad = ds + N, *curv = grad + N, *bmax = curv + N, *pos = bmax + N + 1;
+        /* through a pinned staging buffer of the handle, on the handle's stream: the launches that follow are ordered behind the copy and
+         * nothing waits here (a synchronous copy from pageable memory costs most of a millisecond per re-solve of a receding horizon);
+         * the stream was synchronised above, so the buffer is free */
+        const size_t len = 5*(size_t)N + 2;
+        if (len > h->cap_stage) {
+            if (h->h_stage) hipHostFree(h->h_stage);
+            h->h_stage = nullptr; h->cap_stage = 0;
+            HIP_TRY(hipHostMalloc((void **)&h->h_stage, sizeof(double)*len, hipHostMallocDefault));
+            h->cap_stage = len;
+        }
+        double *ds = h->h_stage, *grad = ds + N, *curv = grad + N, *bmax = curv + N, *pos = bmax + N + 1;
         memcpy(ds, d->ds, sizeof(double)*N); memcpy(grad, d->grad, sizeof(double)*N); memcpy(curv, d->curv, sizeof(double)*N);
         memcpy(bmax, d->bmax, sizeof(double)*(N + 1));
         pos[0] = 0;
         for (int i = 0; i < N; i++) pos[i + 1] = pos[i] + d->ds[i];
-        HIP_TRY(hipMemcpy(h->d_prof, host.data(), sizeof(double)*host.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(h->d_prof, h->h_stage, sizeof(double)*len, hipMemcpyHostToDevice, h->stream));
     }
     if (d->loss_kind == 2) {
         if (d->loss_table_len > h->cap_loss) {
@@ -192,10 +231,10 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.coll = (d->integrator == MSD_INTEGRATOR_COLLOCATION) ? h->d_coll : nullptr;
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
 
-    HIP_TRY(hipFuncSetAttribute((const void *)geo.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)geo.fn, geo.NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    int rc = cu_count(h->device, &cus);
+    int rc = kernel_limits(h->device, (const void *)geo.fn, geo.NT, lds, &per_cu);
+    if (rc != MSD_OK) return rc;
+    rc = cu_count(h->device, &cus);
     if (rc != MSD_OK) return rc;
     h->max_grid = per_cu*cus;
     {
@@ -254,6 +293,7 @@ int msd_problem_destroy(msd_handle h)
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
     hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
+    if (h->h_stage) hipHostFree(h->h_stage);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

@@ -9,6 +9,7 @@ grids, so every re-solve is one problem shared by the batch and one kernel launc
 """
 
 import copy
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -93,6 +94,24 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     last = None
     log = []
 
+    # The sequence of positions, grids and problem descriptions does not depend on the solutions: while the device solves re-solve k a
+    # worker thread prepares problem k + 1 (crop of the track, grid, description -- pandas work that releases the interpreter while the
+    # main thread waits inside the launch).  Only with the device solver; a substituted factory is called in line.
+    pool = ThreadPoolExecutor(max_workers=1) if solverFactory is None else None
+
+    def prepare(trackNow, Nk):
+        "(solver for Nk intervals on trackNow, track after the train has advanced `stride` intervals or None)"
+        opts = dict(optsDict)
+        opts['numIntervals'] = Nk
+        solver = make(train, trackNow, opts)
+        nxt = None
+        if Nk - stride >= 1:
+            nxt = copy.deepcopy(trackNow)
+            nxt.updateLimits(positionStart=float(solver.points.index.values[stride]))
+        return solver, nxt
+
+    pending = None
+
     for k in range(numResolves):
 
         Nk = N - stride*k
@@ -100,10 +119,10 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         if Nk < 1:
             break
 
-        opts = dict(optsDict)
-        opts['numIntervals'] = Nk
-
-        solver = make(train, current, opts)
+        solver, following = pending.result() if pending is not None else prepare(current, Nk)
+        pending = None
+        if pool is not None and following is not None and k + 1 < numResolves:
+            pending = pool.submit(prepare, following, Nk - stride)
 
         if hasattr(solver, 'adoptDevice'):
             solver.adoptDevice(last)      # same device handle for every re-solve
@@ -159,10 +178,11 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
         t_now = np.where(ok, np.maximum(t_meas*(1 + noise*n1), 0.0), t_now)
         v_now = np.where(ok, v_meas*(1 + noise*n2), v_now)
 
-        advance = float(solver.points.index.values[stride])
-        position += advance
-        current = copy.deepcopy(current)
-        current.updateLimits(positionStart=advance)
+        position += float(solver.points.index.values[stride])
+        current = following
+
+    if pool is not None:
+        pool.shutdown(wait=True)
 
     if last is not None and hasattr(last, 'close'):
         last.close()
