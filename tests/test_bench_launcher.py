@@ -65,3 +65,19 @@ def test_launcher_runs_the_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     assert json.loads(line) == {'world': 2, 'max': 2.0, 'sum': 21}
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_box():
+    """
+    The whole multi-rank path of bench.py on a box with one GPU: the parent starts torch.distributed.run, two ranks share device 0
+    (MSD_BENCH_SHARE_DEVICES=1: gloo instead of RCCL for the barrier and the reductions, everything else as in an 8-GPU run) and rank 0
+    prints the aggregate line.
+    """
+    import json, os, subprocess, sys
+    env = dict(os.environ, MSD_BENCH_SHARE_DEVICES='1')
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1', '--no-build'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['scenarios'] == 2048 and line['config']['converged'] == 2048
+    assert line['value'] > 1e5 and 'alt' not in line and 'cpu_baseline' not in line
