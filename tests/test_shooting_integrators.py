@@ -426,3 +426,24 @@ def test_gpu_randomized_problems_with_other_transcriptions(which, seed, tmp_path
         assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ']), (which, seed, N, k)
         assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4, (which, seed, N, k)
     solver.close(); fast.close()
+
+
+def test_integrated_losses_converge_to_the_gpops_energy():
+    """
+    gpops/00_var_speed_limit_100_GPOPS{I,II}.csv hold 440.1415 / 440.1406 kWh for the figure10.py configuration -- the continuous problem,
+    which the mid-point loss rows and the integrated ones both discretise: the integrateLosses transcription must extrapolate to the same
+    number (tests/test_oracle_pins.py does this for the mid-point rows).
+    """
+    import pandas as pd
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / 'golden'
+    e = {}
+    for N in (100, 300):
+        prob = cases.oracle_problem(cases.train_fig10(), cases.track_00(), N, integration=dict(integrateLosses=True))
+        r = oracle.solve(prob, prob.scenario(1541.0), start='profile')
+        assert r['stats']['STATUS'] == 0
+        e[N] = r['stats']['OBJ']
+    richardson = (9*e[300] - e[100])/8
+    g1 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSI.csv')['Energy [kWh]'].iloc[0]
+    g2 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSII.csv')['Energy [kWh]'].iloc[0]
+    assert abs(richardson - g1) < 0.02 and abs(richardson - g2) < 0.02, (e, richardson)
