@@ -447,3 +447,21 @@ def test_integrated_losses_converge_to_the_gpops_energy():
     g1 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSI.csv')['Energy [kWh]'].iloc[0]
     g2 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSII.csv')['Energy [kWh]'].iloc[0]
     assert abs(richardson - g1) < 0.02 and abs(richardson - g2) < 0.02, (e, richardson)
+
+
+@pytest.mark.parametrize('integration,numApprox', [(IRK2, 1), (ADAPT, 0)])
+def test_other_shooting_integrators_converge_to_the_gpops_energy(integration, numApprox):
+    "The same pin for the 'IRK' and 'CVODES' transcriptions: N = 100 / 300 on the figure10.py configuration extrapolate to GPOPS-II's 440.14 kWh."
+    import pandas as pd
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / 'golden'
+    e = {}
+    for N in (100, 300):
+        prob = cases.oracle_problem(cases.train_fig10(), cases.track_00(), N, numApproxSteps=numApprox, integration=integration)
+        r = oracle.solve(prob, prob.scenario(1541.0), start='profile')
+        assert r['stats']['STATUS'] == 0
+        e[N] = r['stats']['OBJ']
+    richardson = (9*e[300] - e[100])/8
+    g1 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSI.csv')['Energy [kWh]'].iloc[0]
+    g2 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSII.csv')['Energy [kWh]'].iloc[0]
+    assert abs(richardson - g1) < 0.02 and abs(richardson - g2) < 0.02, (e, richardson)
