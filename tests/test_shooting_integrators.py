@@ -465,3 +465,22 @@ def test_other_shooting_integrators_converge_to_the_gpops_energy(integration, nu
     g1 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSI.csv')['Energy [kWh]'].iloc[0]
     g2 = pd.read_csv(gold / '00_var_speed_limit_100_GPOPSII.csv')['Energy [kWh]'].iloc[0]
     assert abs(richardson - g1) < 0.02 and abs(richardson - g2) < 0.02, (e, richardson)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('numSteps,numApprox', [(2, 0), (1, 2), (3, 1)])
+def test_gpu_integrated_losses_with_other_rk_settings(numSteps, numApprox):
+    "integrateLosses on top of the joint (t, b) RK4 map, several RK steps and several trapezoid pieces: the folding uses whatever d tau the map has."
+    from mseetc.ocp import casadiSolver
+    train, track = cases.train_default(), cases.track_00(30000)
+    N, T = 80, 1150.0
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=400, integrateLosses=True, integrationOptions=dict(numSteps=numSteps, numApproxSteps=numApprox)),
+                          startingPoint='profile')
+    res = solver.solveBatch([T, 1.1*T], initialVelocity=8, terminalVelocity=6, multipliers=True)
+    prob = cases.oracle_problem(train, track, N, numSteps=numSteps, numApproxSteps=numApprox, integration=dict(integrateLosses=True))
+    for k, Tk in enumerate((T, 1.1*T)):
+        ref = oracle.solve(prob, prob.scenario(Tk, 0.0, 6.0, 8.0), start='profile')
+        assert res['status'][k] == 0 and ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-5
+        assert np.max(np.abs(res['lam_g'][k] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 5e-3
