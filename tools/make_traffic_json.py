@@ -28,10 +28,11 @@ line = json.load(open(os.path.join(out, 'pmc_fetch.json')))
 rec = {
     "bytes_per_launch": int(1024*(fetch_kb + write_kb)),
     "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+    "bytes_per_launch_with_fetch_doubled": int(1024*(2*fetch_kb + write_kb)),      # upper reading: the guide's x2 for 16 B/lane streams applied anyway
     "kernel_digest": entry.hip_digest(),
     "launch": "{}; {} scenarios, {:.2f} IP iterations per solve".format(line['roofline']['kernel'], line['config']['batch_per_gpu'], line['config']['ip_iterations_mean']),
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_round.sh), mean of {} / {} solve-kernel launches; FETCH_SIZE as reported "
-              "(the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; the kernel's traffic is 8 B/lane scratch and result stores)".format(nf, nw),
+              "(the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; the kernel's traffic is 8 B/lane scratch and result stores, a width the guide calls uncalibrated; bytes_per_launch_with_fetch_doubled is the reading with the correction applied anyway -- WRITE_SIZE dominates either way)".format(nf, nw),
     "compulsory_bytes_per_launch": int(line['config']['batch_per_gpu']*(8*(5*line['config']['num_intervals'] + 2) + 168)),
 }
 # issue statistics of the same kernel from the SQ pass (units of four cycles per wave, summed over the waves of a launch)
