@@ -13,7 +13,8 @@ using KernelFn = void (*)(DevProb, int, const double *, const double *, double *
 /* NT threads per workgroup, SPT shooting nodes per thread (NT*SPT >= N + 1) */
 struct Geometry { int NT, SPT; KernelFn fn; bool stream = false; };     /* stream: stage blocks in device memory (long horizons) */
 
-Geometry pick_geometry_static(int N);
+Geometry pick_geometry_static(int N, bool full);     /* full: both brakes, power rows, energy objective -- the kernels with that structure compiled in */
+Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
 Geometry pick_geometry_general(int N);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */

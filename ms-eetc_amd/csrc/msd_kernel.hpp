@@ -618,11 +618,11 @@ struct Ev {
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
-template <bool DERIV, int DYN, bool GEN>
+template <bool DERIV, int DYN, bool GEN, bool FULL>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
                                               double (&cv)[2], double (&dv)[NR], Ev &e)
 {
-    const double b = x[VB], f = x[VF], p = P.withPn ? x[VP] : 0.0, s = x[VS];
+    const double b = x[VB], f = x[VF], p = (FULL || P.withPn) ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
         if (GEN) interval_map_general<Jet>(P, b, f + p, nG, nds, tau, bp); else interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
@@ -671,17 +671,17 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
-template <bool LI, class NodeT>
+template <bool LI, bool FULL, class NodeT>
 __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &n, const double (&x)[NV], double q, double sf)
 {
     double J = 0;
     if (n.ival()) {
-        const double f = x[VF], p = P.withPn ? x[VP] : 0.0;
-        if (P.energyOpt) {
+        const double f = x[VF], p = (FULL || P.withPn) ? x[VP] : 0.0;
+        if (FULL || P.energyOpt) {
             J = LI ? n.ds*f + x[VS] : n.ds*(f + x[VS]);                       /* ocp.py:223 resp. :235 */
             if (n.i > 0) J += 1e-3*(f - q)*(f - q);                           /* ocp.py:245 */
         } else J = 1e-4*(f*f + p*p);                                          /* ocp.py:150 */
-    } else if (n.i == P.N && !P.energyOpt) J = x[VT];
+    } else if (!FULL && n.i == P.N && !P.energyOpt) J = x[VT];
     return sf*J/P.objDen;
 }
 
@@ -1281,7 +1281,7 @@ struct ParallelRiccati {
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
 
-template <int NT, int SPT, int DYN, bool STREAM, bool GEN>
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN, bool FULL>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -1299,6 +1299,16 @@ struct Solver {
     Field<10, NS, MSD_MEM_EV != 0 || STREAM> lgs[SPT];
 
     __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_, double *work_, Uni &U_) : P(P_), c(c_), work(work_), U(U_) {}
+
+    /* structure of the NLP.  FULL: traction + pneumatic brake, power rows, energy objective -- the rolling stock of the reference's JSON
+     * files (BASELINE configs 1-4) -- known at compile time: no flag loads, no branches on them.  Rows then are: both power rows and the
+     * acceleration row two-sided, the two loss rows bounded below (ocp.py:184-229) */
+    __device__ __forceinline__ bool rowOn(int r) const { return FULL ? true : U.rowOn[r]; }
+    __device__ __forceinline__ bool rL(int r) const { return FULL ? true : U.rL[r]; }
+    __device__ __forceinline__ bool rU(int r) const { return FULL ? (r <= RACC) : U.rU[r]; }
+    __device__ __forceinline__ bool withPn() const { return FULL ? true : P.withPn != 0; }
+    __device__ __forceinline__ bool energyOpt() const { return FULL ? true : P.energyOpt != 0; }
+    __device__ __forceinline__ bool hasPower() const { return FULL ? true : P.hasPower != 0; }
 
     __device__ __forceinline__ void store_ev(int j, const Ev &e)
     {
@@ -1465,7 +1475,7 @@ struct Solver {
     }
     __device__ __forceinline__ void row_terms(int j, int r, double mu_, double &Sg, double &gphi) const
     {
-        bar_terms(n[j].sg[r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], n[j].zLs[r], n[j].zUs[r], mu_, Sg, gphi);
+        bar_terms(n[j].sg[r], U.dL[r], U.dU[r], rL(r), rU(r), n[j].zLs[r], n[j].zUs[r], mu_, Sg, gphi);
     }
 
     /* second derivatives of phi = f X(v(b), d, f + p) wrt (b, f, p, d) from the cached derivatives of X (integrated losses) */
@@ -1490,7 +1500,7 @@ struct Solver {
         for (int r = 0; r < NR; r++) { gb[r] = gf[r] = gp[r] = gs[r] = gb1[r] = gd[r] = 0; }
         gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
         gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
-        gf[RACC] = 1; gp[RACC] = P.withPn ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
+        gf[RACC] = 1; gp[RACC] = withPn() ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
         if (DYN == LOSS_INTEGRATED) {
             /* rows s + kappa f X(v(b), t1 - t, f + p), kappa = -ct, +cr */
             const double X = ev.lg[0][0], Xv = ev.lg[0][1], Xd = ev.lg[0][2], Xw = ev.lg[0][3], vb = 0.5/ev.sb;
@@ -1498,7 +1508,7 @@ struct Solver {
             for (int k = 0; k < 2; k++) {
                 const int r = (k == 0) ? RLTR : RLRG;
                 const double kap = (k == 0) ? -P.ct : P.cr;
-                gs[r] = 1; gf[r] = kap*(X + f*Xw); gp[r] = P.withPn ? kap*f*Xw : 0.0; gb[r] = kap*f*Xv*vb; gd[r] = kap*f*Xd;
+                gs[r] = 1; gf[r] = kap*(X + f*Xw); gp[r] = withPn() ? kap*f*Xw : 0.0; gb[r] = kap*f*Xv*vb; gd[r] = kap*f*Xd;
             }
         } else if (DYN == LOSS_TABLE) {
             /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
@@ -1521,7 +1531,7 @@ struct Solver {
     {
         if (DYN != LOSS_INTEGRATED) return;
 #pragma unroll
-        for (int r = RLTR; r <= RLRG; r++) { gb[r] += gd[r]*ev.tb; gf[r] += gd[r]*ev.tw; if (P.withPn) gp[r] += gd[r]*ev.tw; }
+        for (int r = RLTR; r <= RLRG; r++) { gb[r] += gd[r]*ev.tb; gf[r] += gd[r]*ev.tw; if (withPn()) gp[r] += gd[r]*ev.tw; }
     }
 
     /* objective gradient wrt (f, p, s, q) of the interval and its (constant) curvature; terminal time handled by node N */
@@ -1530,13 +1540,13 @@ struct Solver {
         const double sc = U.sf/P.objDen;
         of = op = os = oq = off = opp = 0;
         if (!n[j].ival()) return;
-        const double f = n[j].x[VF], p = P.withPn ? n[j].x[VP] : 0.0;
-        if (P.energyOpt) {
+        const double f = n[j].x[VF], p = withPn() ? n[j].x[VP] : 0.0;
+        if (energyOpt()) {
             of = sc*n[j].ds; os = (DYN == LOSS_INTEGRATED) ? sc : sc*n[j].ds;
             if (n[j].i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
         } else {
             of = sc*2e-4*f; off = sc*2e-4;
-            if (P.withPn) { op = sc*2e-4*p; opp = sc*2e-4; }
+            if (withPn()) { op = sc*2e-4*p; opp = sc*2e-4; }
         }
     }
 
@@ -1591,7 +1601,7 @@ struct Solver {
                 gl[j][VF] = of; gl[j][VP] = op; gl[j][VS] = os; out_q = oq;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     gl[j][VB] += nd.nu[r]*gb[r]; gl[j][VF] += nd.nu[r]*gf[r]; gl[j][VP] += nd.nu[r]*gp[r]; gl[j][VS] += nd.nu[r]*gs[r]; out_b1 += nd.nu[r]*gb1[r];
                     if (DYN == LOSS_INTEGRATED) { out_t1 += nd.nu[r]*gd[r]; gl[j][VT] -= nd.nu[r]*gd[r]; }      /* running time = t1 - t */
                 }
@@ -1599,7 +1609,7 @@ struct Solver {
                 out_t1 += nd.lam[0]; gl[j][VT] -= nd.lam[0];
                 gl[j][VB] -= nd.lam[0]*e[j].tb + nd.lam[1]*e[j].Bb;
                 gl[j][VF] -= nd.lam[0]*e[j].tw + nd.lam[1]*e[j].Bw;
-                if (P.withPn) gl[j][VP] -= nd.lam[0]*e[j].tw + nd.lam[1]*e[j].Bw;
+                if (withPn()) gl[j][VP] -= nd.lam[0]*e[j].tw + nd.lam[1]*e[j].Bw;
                 out_b1 += nd.lam[1];
                 prim = fmax(prim, fmax(nd.sct*fabs(resc[j][0]), nd.scb*fabs(resc[j][1])));
                 prim_u = fmax(prim_u, fmax(fabs(resc[j][0]), fabs(resc[j][1])));
@@ -1607,18 +1617,18 @@ struct Solver {
                 sumlam += fabs(nd.lam[0])/nd.sct + fabs(nd.lam[1])/nd.scb; nlam += 2;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     const double viol = fabs(resd[j][r]);
                     prim = fmax(prim, viol); prim_u = fmax(prim_u, viol/U.rs[r]); th += viol;
                     sumlam += fabs(nd.nu[r]); nlam += 1;
                     double gsl = -nd.nu[r];
-                    if (U.rL[r]) { const double s = nd.sg[r] - U.dL[r]; gsl -= nd.zLs[r]; const double cp = s*nd.zLs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zLs[r]; nz += 1; prod *= s; }
-                    if (U.rU[r]) { const double s = U.dU[r] - nd.sg[r]; gsl += nd.zUs[r]; const double cp = s*nd.zUs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zUs[r]; nz += 1; prod *= s; }
-                    if (U.rL[r] && !U.rU[r]) damp += nd.sg[r] - U.dL[r];
-                    if (!U.rL[r] && U.rU[r]) damp += U.dU[r] - nd.sg[r];
+                    if (rL(r)) { const double s = nd.sg[r] - U.dL[r]; gsl -= nd.zLs[r]; const double cp = s*nd.zLs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zLs[r]; nz += 1; prod *= s; }
+                    if (rU(r)) { const double s = U.dU[r] - nd.sg[r]; gsl += nd.zUs[r]; const double cp = s*nd.zUs[r]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zUs[r]; nz += 1; prod *= s; }
+                    if (rL(r) && !rU(r)) damp += nd.sg[r] - U.dL[r];
+                    if (!rL(r) && rU(r)) damp += U.dU[r] - nd.sg[r];
                     dual = fmax(dual, fabs(gsl));
                 }
-            } else if (nd.i == P.N && !P.energyOpt) gl[j][VT] = U.sf/P.objDen;
+            } else if (nd.i == P.N && !energyOpt()) gl[j][VT] = U.sf/P.objDen;
             if (nd.node()) {
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
@@ -1630,7 +1640,7 @@ struct Solver {
                 { double xl[NV];
 #pragma unroll
                     for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
-                    obj += objective_term<DYN == LOSS_INTEGRATED>(P, nd, xl, q, U.sf); }
+                    obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xl, q, U.sf); }
             }
             lsum.add(prod);
             /* the contributions that belong to the neighbours' variables */
@@ -1695,18 +1705,18 @@ struct Solver {
                 hf = of; hp = op; hs = os; hq = oq;
                 if (mode == MODE_NEWTON) {
                     Hff = off; Hpp = opp;
-                    if (P.energyOpt && nd.i > 0) { Hqq = off; Hqf = -off; }
+                    if (energyOpt() && nd.i > 0) { Hqq = off; Hqf = -off; }
                     /* - lam_t hess(tau) - lam_b hess(b+) */
                     const double hbb = -(nd.lam[0]*e[j].tbb + nd.lam[1]*e[j].Bbb), hbw = -(nd.lam[0]*e[j].tbw + nd.lam[1]*e[j].Bbw),
                                  hww = -(nd.lam[0]*e[j].tww + nd.lam[1]*e[j].Bww);
                     Hbb += hbb; Hbf += hbw; Hff += hww;
-                    if (P.withPn) { Hbp += hbw; Hfp += hww; Hpp += hww; }
+                    if (withPn()) { Hbp += hbw; Hfp += hww; Hpp += hww; }
                     /* nu * hess(row) */
                     const double b = nd.x[VB];
-                    if (U.rowOn[RPW0]) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
-                    if (U.rowOn[RPW1]) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
-                    if (U.rowOn[RACC]) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
-                    if (DYN == LOSS_INTEGRATED && U.rowOn[RLTR]) {
+                    if (rowOn(RPW0)) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
+                    if (rowOn(RPW1)) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
+                    if (rowOn(RACC)) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
+                    if (DYN == LOSS_INTEGRATED && rowOn(RLTR)) {
                         /* rows s + kappa f X(v(b), d, f + p), d = t1 - t: nu * hess(kappa f X) in (b, f, p, d), then d folded away with
                          * dd = tb db + tw (df + dp) + rt (quadratic form; the part linear in rt goes to the gradient) */
                         const LossHess L = loss_hess(f, b, e[j]);
@@ -1716,14 +1726,14 @@ struct Solver {
                         Hbf += W*(L.bf + tb*L.fd + tw*L.bd + tb*tw*L.dd);
                         Hff += W*(L.ff + 2*tw*L.fd + tw*tw*L.dd);
                         hb += W*rt*(L.bd + L.dd*tb); hf += W*rt*(L.fd + L.dd*tw);
-                        if (P.withPn) {
+                        if (withPn()) {
                             Hbp += W*(L.bp + tb*L.pd + tw*L.bd + tb*tw*L.dd);
                             Hfp += W*(L.fp + tw*L.pd + tw*L.fd + tw*tw*L.dd);
                             Hpp += W*(L.pp + 2*tw*L.pd + tw*tw*L.dd);
                             hp += W*rt*(L.pd + L.dd*tw);
                         }
                     }
-                    if (DYN == LOSS_TABLE && U.rowOn[RLTR]) {
+                    if (DYN == LOSS_TABLE && rowOn(RLTR)) {
                         /* rows s - g(f, vbar(b, b1)): nu * hess = -nu * hess(g) */
                         const double vb = 0.25/e[j].sb, vb1 = 0.25/e[j].sb1, vbb = -0.125/(b*e[j].sb), vb1b1 = -0.125/(e[j].b1*e[j].sb1);
 #pragma unroll
@@ -1738,7 +1748,7 @@ struct Solver {
                 }
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     double Sg, coef;
                     if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*(resd[j][r] + gd[r]*rt) + gphi; }
                     else { Sg = 1.0; coef = -nd.zLs[r] + nd.zUs[r]; }
@@ -1749,7 +1759,7 @@ struct Solver {
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
                     if (DYN) { Hbs += Sg*gb[r]*gs[r]; Hps += Sg*gp[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
-            } else if (nd.i == P.N && !P.energyOpt) ht = U.sf/P.objDen;
+            } else if (nd.i == P.N && !energyOpt()) ht = U.sf/P.objDen;
             /* bounds of the node's own variables + regularisation */
             if (nd.node()) {
                 double Sv[NV], gv[NV];
@@ -1776,9 +1786,9 @@ struct Solver {
                     double Gbs = Hbs, Gfs = Hfs, Gps = Hps, gsv = hs;
                     if (DYN && !last) {
                         Hbb += 2*Eb*Bb; Hbf += Eb*Bw; hb += Eb*rb;
-                        if (P.withPn) Hbp += Eb*Bw;
+                        if (withPn()) Hbp += Eb*Bw;
                         Gbs += Es*Bb; Gfs += Es*Bw; gsv += Es*rb;
-                        if (P.withPn) Gps += Es*Bw;
+                        if (withPn()) Gps += Es*Bw;
                     }
                     const double is = (Hss > 0) ? 1.0/Hss : NAN;
                     if (!last) {
@@ -1856,7 +1866,7 @@ struct Solver {
 #if MSD_STASH_KKT
         stash<H_ALL & ~H_DSG>();
 #endif
-        par = ParallelRiccati<SPT, DYN>::solve(P.N, P.withPn != 0, c);
+        par = ParallelRiccati<SPT, DYN>::solve(P.N, withPn(), c);
         c.red_slot++;        /* one block reduction inside */
 #if MSD_STASH_KKT
         fetch<H_ALL & ~H_DSG>();
@@ -1870,7 +1880,7 @@ struct Solver {
         if (par < 0) {       /* serial sweeps on one lane: the fallback of the scan (cold) or, with MSD_PARALLEL_RICCATI = 0, the only path */
             if (c.tid == 0) {
                 const unsigned long long t0 = __builtin_readcyclecounter();
-                c.misc[0] = riccati_solve<DYN>(P.N, P.withPn != 0, c.S, nullptr) ? 1.0 : 0.0;
+                c.misc[0] = riccati_solve<DYN>(P.N, withPn(), c.S, nullptr) ? 1.0 : 0.0;
                 c.misc[1] += (double)(__builtin_readcyclecounter() - t0);
             }
             __syncthreads();
@@ -1894,12 +1904,12 @@ struct Solver {
                 row_grads(j, ej, gb, gf, gp, gs, gb1, gd);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     const double lin = gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1 + gd[r]*dd;
                     /* Newton: slack step; least squares: nu = Sigma dsigma + (-zL + zU) with Sigma = 1, parked in dsg */
                     nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-nd.zLs[r] + nd.zUs[r]);
                 }
-                if (DYN == LOSS_INTEGRATED && U.rowOn[RLTR]) {
+                if (DYN == LOSS_INTEGRATED && rowOn(RLTR)) {
                     /* the sweeps solved the system with the running time folded into (b, f, p): their multiplier of the time equation is
                      * lam_t + sum_r (gd_r nu_r+ + nu_r d(grad_d row_r)); take the rows' share out again (fold_running_time) */
                     double corr = 0;
@@ -1949,10 +1959,10 @@ struct Solver {
             if (nd.ival()) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     const double d = nd.dsg[r];
-                    if (U.rL[r]) { if (d < 0) ap = fmin(ap, -tau_*(nd.sg[r] - U.dL[r])/d); const double dz = dzL_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zLs[r]/dz); }
-                    if (U.rU[r]) { if (d > 0) ap = fmin(ap, tau_*(U.dU[r] - nd.sg[r])/d); const double dz = dzU_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zUs[r]/dz); }
+                    if (rL(r)) { if (d < 0) ap = fmin(ap, -tau_*(nd.sg[r] - U.dL[r])/d); const double dz = dzL_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zLs[r]/dz); }
+                    if (rU(r)) { if (d > 0) ap = fmin(ap, tau_*(U.dU[r] - nd.sg[r])/d); const double dz = dzU_row(j, r, mu_); if (dz < 0) ad = fmin(ad, -tau_*nd.zUs[r]/dz); }
                 }
             }
         }
@@ -1971,7 +1981,7 @@ struct Solver {
 #pragma unroll
             for (int k = 0; k < NV; k++) xt[j][k] = n[j].x[k] + alpha*dd.dx[k];
 #pragma unroll
-            for (int r = 0; r < NR; r++) st[j][r] = n[j].sg[r] + (U.rowOn[r] ? alpha*n[j].dsg[r] : 0.0);
+            for (int r = 0; r < NR; r++) st[j][r] = n[j].sg[r] + (rowOn(r) ? alpha*n[j].dsg[r] : 0.0);
         }
     }
 
@@ -1990,16 +2000,16 @@ struct Solver {
             double prod = 1.0;
             if (nd.ival()) {
                 double cv[2], dv[NR]; Ev dummy;
-                eval_interval<false, DYN, GEN>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
+                eval_interval<false, DYN, GEN, FULL>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
                 th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     th += fabs(dv[r] - st[j][r]);
-                    if (U.rL[r]) { const double s = st[j][r] - U.dL[r]; if (s <= 0) bad = 1; else prod *= s; }
-                    if (U.rU[r]) { const double s = U.dU[r] - st[j][r]; if (s <= 0) bad = 1; else prod *= s; }
-                    if (U.rL[r] && !U.rU[r]) damp += st[j][r] - U.dL[r];
-                    if (!U.rL[r] && U.rU[r]) damp += U.dU[r] - st[j][r];
+                    if (rL(r)) { const double s = st[j][r] - U.dL[r]; if (s <= 0) bad = 1; else prod *= s; }
+                    if (rU(r)) { const double s = U.dU[r] - st[j][r]; if (s <= 0) bad = 1; else prod *= s; }
+                    if (rL(r) && !rU(r)) damp += st[j][r] - U.dL[r];
+                    if (!rL(r) && rU(r)) damp += U.dU[r] - st[j][r];
                 }
             }
             if (nd.node()) {
@@ -2010,7 +2020,7 @@ struct Solver {
                     if (hasU(k)) { const double s = ubv(j, k) - xt[j][k]; if (s <= 0) bad = 1; else prod *= s; }
                     else damp += xt[j][k] - lbv(k);
                 }
-                obj += objective_term<DYN == LOSS_INTEGRATED>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
+                obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
             }
             lsum.add(prod);
         }
@@ -2035,9 +2045,9 @@ struct Solver {
             for (int r = 0; r < NR; r++) td[j][r] = 0;
             if (n[j].ival()) {
                 double dv[NR]; Ev dummy;
-                eval_interval<false, DYN, GEN>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
+                eval_interval<false, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
 #pragma unroll
-                for (int r = 0; r < NR; r++) td[j][r] = U.rowOn[r] ? dv[r] - st[j][r] : 0.0;
+                for (int r = 0; r < NR; r++) td[j][r] = rowOn(r) ? dv[r] - st[j][r] : 0.0;
             }
         }
     }
@@ -2057,10 +2067,10 @@ struct Solver {
                 Ev ej;
 #pragma unroll
                 for (int k = 0; k < NV; k++) xl[k] = n[j].x[k];
-                eval_interval<true, DYN, GEN>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
+                eval_interval<true, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
                 resc[j][0] = cv[0]; resc[j][1] = cv[1];
 #pragma unroll
-                for (int r = 0; r < NR; r++) resd[j][r] = U.rowOn[r] ? dv[r] - n[j].sg[r] : 0.0;
+                for (int r = 0; r < NR; r++) resd[j][r] = rowOn(r) ? dv[r] - n[j].sg[r] : 0.0;
                 store_ev(j, ej);
             }
         }
@@ -2148,15 +2158,15 @@ struct Solver {
             const double vm = 0.5*(sqrt(bs0) + sqrt(bs1));
             const double f = (bs1 - bs0)/(2*nd.ds) + P.sr0 + P.sr1*vm + P.sr2*vm*vm + nd.G;
             double fel = fmin(fmax(f, P.fmin), P.fmax);
-            if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
+            if (hasPower()) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             double fpb = 0.0;
-            if (P.withPn) {
+            if (withPn()) {
                 /* the interior push will move Fpb at least this far below its upper bound 0: start there and let Fel make up for
                  * it, so that the pushed point still has the acceleration the profile needs (a start from standstill must not stall) */
                 const double pb = K_PUSH*fmin(1.0, fabs(P.fminPn));
                 fpb = fmin(fmin(fmax(f - fel, P.fminPn), 0.0), -pb);
                 fel = fmin(fmax(f - fpb, P.fmin), P.fmax);
-                if (P.hasPower) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
+                if (hasPower()) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             }
             double sl;
             if (DYN == LOSS_TABLE) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
@@ -2198,18 +2208,18 @@ struct Solver {
             if (nd.i >= 1 && node && t0 != tEnd) fl |= F_ON_T;
             if (nd.i >= 1 && nd.i < N && P.vminSq != bm) fl |= F_ON_B;
             if (ival && P.fmin != P.fmax) fl |= F_ON_F;
-            if (ival && P.withPn && P.fminPn != 0.0) fl |= F_ON_P;
+            if (ival && withPn() && P.fminPn != 0.0) fl |= F_ON_P;
             if (ival) fl |= F_ON_S;
             nd.flags = fl;
             nd.ubB = bm + K_BOUND_RELAX*fmax(1.0, fabs(bm));
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
-            nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = P.withPn ? -0.1 : 0.0; nd.x[VS] = 1;
+            nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = withPn() ? -0.1 : 0.0; nd.x[VS] = 1;
             if (ext && node) {
                 /* layout of z_out (ocp.py:166-272): [Fel,(Fpb),s,t,b] per interval, then t_N, b_N */
-                const int nu = 1 + P.withPn;
+                const int nu = 1 + withPn();
                 const double *q = guess + (nu + 3)*nd.i;
-                if (ival) { nd.x[VF] = q[0]; nd.x[VP] = P.withPn ? q[1] : 0.0; nd.x[VS] = q[nu]; nd.x[VT] = q[nu + 1]; nd.x[VB] = q[nu + 2]; }
+                if (ival) { nd.x[VF] = q[0]; nd.x[VP] = withPn() ? q[1] : 0.0; nd.x[VS] = q[nu]; nd.x[VT] = q[nu + 1]; nd.x[VB] = q[nu + 2]; }
                 else { nd.x[VT] = q[0]; nd.x[VB] = q[1]; }
             }
             if (nd.i == 0) { nd.x[VT] = t0; nd.x[VB] = v0sq; }
@@ -2230,9 +2240,9 @@ struct Solver {
         u.slo = -K_BOUND_RELAX;
 #pragma unroll
         for (int r = 0; r < NR; r++) { u.rowOn[r] = false; u.dL[r] = -INFINITY; u.dU[r] = INFINITY; u.rs[r] = 1.0; u.rL[r] = u.rU[r] = false; }
-        if (P.hasPower) { u.rowOn[RPW0] = u.rowOn[RPW1] = true; u.dL[RPW0] = u.dL[RPW1] = -fabs(P.pwL); u.dU[RPW0] = u.dU[RPW1] = fabs(P.pwU); }
+        if (hasPower()) { u.rowOn[RPW0] = u.rowOn[RPW1] = true; u.dL[RPW0] = u.dL[RPW1] = -fabs(P.pwL); u.dU[RPW0] = u.dU[RPW1] = fabs(P.pwU); }
         u.rowOn[RACC] = true; u.dL[RACC] = P.accMin; u.dU[RACC] = P.accMax;
-        if (P.energyOpt) { u.rowOn[RLTR] = u.rowOn[RLRG] = true; u.dL[RLTR] = u.dL[RLRG] = 0; }
+        if (energyOpt()) { u.rowOn[RLTR] = u.rowOn[RLRG] = true; u.dL[RLTR] = u.dL[RLRG] = 0; }
         u.sf = 1;
 
         commit_uniforms(u);
@@ -2269,7 +2279,7 @@ struct Solver {
                         if (nd.i < N - 1) m = fmax(m, fabs(gb1[r]));
                         rmax[r] = fmax(rmax[r], m);
                     }
-                } else if (nd.i == N && !P.energyOpt) gmax = fmax(gmax, 1.0/P.objDen);
+                } else if (nd.i == N && !energyOpt()) gmax = fmax(gmax, 1.0/P.objDen);
             }
             double v[6] = {gmax, rmax[0], rmax[1], rmax[2], rmax[3], rmax[4]};
             block_reduce<6>(v, OpMax(), c);
@@ -2311,10 +2321,10 @@ struct Solver {
             if (!n[j].ival()) continue;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                if (!U.rowOn[r]) continue;
-                n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], U.rL[r], U.rU[r], kp);
-                n[j].zLs[r] = U.rL[r] ? (warm ? mu_start/(n[j].sg[r] - U.dL[r]) : 1.0) : 0.0;
-                n[j].zUs[r] = U.rU[r] ? (warm ? mu_start/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
+                if (!rowOn(r)) continue;
+                n[j].sg[r] = push_in(resd[j][r], U.dL[r], U.dU[r], rL(r), rU(r), kp);
+                n[j].zLs[r] = rL(r) ? (warm ? mu_start/(n[j].sg[r] - U.dL[r]) : 1.0) : 0.0;
+                n[j].zUs[r] = rU(r) ? (warm ? mu_start/(U.dU[r] - n[j].sg[r]) : 1.0) : 0.0;
                 resd[j][r] -= n[j].sg[r];
             }
             if (dualStart) {
@@ -2322,10 +2332,10 @@ struct Solver {
                 n[j].lam[0] = q[0]; n[j].lam[1] = q[1];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (!U.rowOn[r]) continue;
+                    if (!rowOn(r)) continue;
                     n[j].nu[r] = q[2 + r];
-                    if (U.rL[r]) n[j].zLs[r] = fmax(q[17 + r], 1e-3*n[j].zLs[r]);
-                    if (U.rU[r]) n[j].zUs[r] = fmax(q[22 + r], 1e-3*n[j].zUs[r]);
+                    if (rL(r)) n[j].zLs[r] = fmax(q[17 + r], 1e-3*n[j].zLs[r]);
+                    if (rU(r)) n[j].zUs[r] = fmax(q[22 + r], 1e-3*n[j].zUs[r]);
                 }
             }
         }
@@ -2347,7 +2357,7 @@ struct Solver {
                 if (ok && n[j].ival()) {
                     lmax = fmax(lmax, fmax(fabs(dd[j].lt)/n[j].sct, fabs(dd[j].lb)/n[j].scb));
 #pragma unroll
-                    for (int r = 0; r < NR; r++) if (U.rowOn[r]) lmax = fmax(lmax, fabs(n[j].dsg[r]));
+                    for (int r = 0; r < NR; r++) if (rowOn(r)) lmax = fmax(lmax, fabs(n[j].dsg[r]));
                 }
             }
             double v[1] = {lmax};
@@ -2360,7 +2370,7 @@ struct Solver {
                 const bool tk = use && nd.ival();
                 nd.lam[0] = tk ? dd[j].lt : 0.0; nd.lam[1] = tk ? dd[j].lb : 0.0;
 #pragma unroll
-                for (int r = 0; r < NR; r++) { nd.nu[r] = (tk && U.rowOn[r]) ? nd.dsg[r] : 0.0; nd.dsg[r] = 0; }
+                for (int r = 0; r < NR; r++) { nd.nu[r] = (tk && rowOn(r)) ? nd.dsg[r] : 0.0; nd.dsg[r] = 0; }
             }
         }
 
@@ -2428,7 +2438,7 @@ struct Solver {
                     node_fence<9>();
                     double of = 0, op = 0, os = 0, oq = 0, off = 0, opp = 0;
                     if (n[j].node()) obj_grads(j, nb_q(j), of, op, os, oq, off, opp);
-                    og[j][VT] = (n[j].i == N && !P.energyOpt) ? U.sf/P.objDen : 0.0; og[j][VB] = 0; og[j][VF] = of; og[j][VP] = op; og[j][VS] = os;
+                    og[j][VT] = (n[j].i == N && !energyOpt()) ? U.sf/P.objDen : 0.0; og[j][VB] = 0; og[j][VF] = of; og[j][VP] = op; og[j][VS] = os;
                     /* d(obj)/dq of the next interval belongs to this node's f */
                     c.o1[n[j].i] = oq;
                 }
@@ -2463,21 +2473,21 @@ struct Solver {
                     if (nd.ival()) {
 #pragma unroll
                         for (int r_ = 0; r_ < NR; r_++) {
-                            if (!U.rowOn[r_]) continue;
+                            if (!rowOn(r_)) continue;
                             const double d = nd.dsg[r_];
                             double gp = 0;
-                            if (U.rL[r_]) {
+                            if (rL(r_)) {
                                 const double r = 1.0/(nd.sg[r_] - U.dL[r_]), z = nd.zLs[r_];
                                 gp -= mu*r; rp = fmax(rp, -d*r);
                                 rd = fmax(rd, -(r*(mu - z*d) - z)/z);
                             }
-                            if (U.rU[r_]) {
+                            if (rU(r_)) {
                                 const double r = 1.0/(U.dU[r_] - nd.sg[r_]), z = nd.zUs[r_];
                                 gp += mu*r; rp = fmax(rp, d*r);
                                 rd = fmax(rd, -(r*(mu + z*d) - z)/z);
                             }
-                            if (U.rL[r_] && !U.rU[r_]) gp += K_D*mu;
-                            if (!U.rL[r_] && U.rU[r_]) gp -= K_D*mu;
+                            if (rL(r_) && !rU(r_)) gp += K_D*mu;
+                            if (!rL(r_) && rU(r_)) gp -= K_D*mu;
                             gd += gp*d;
                             dn = fmax(dn, fabs(d)); rel = fmax(rel, fabs(d) - 10*DBL_EPSILON*(1 + fabs(nd.sg[r_])));
                         }
@@ -2593,15 +2603,15 @@ struct Solver {
                 if (nd.ival()) {
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        if (!U.rowOn[r]) continue;
-                        const double dzl = U.rL[r] ? dzL_row(j, r, mu) : 0.0, dzu = U.rU[r] ? dzU_row(j, r, mu) : 0.0;
+                        if (!rowOn(r)) continue;
+                        const double dzl = rL(r) ? dzL_row(j, r, mu) : 0.0, dzu = rU(r) ? dzU_row(j, r, mu) : 0.0;
                         /* new inequality multiplier nu+ = (Sigma + delta_w) dsigma + grad phi_sigma, at the old point */
                         double Sg, gphi; row_terms(j, r, mu, Sg, gphi);
                         const double dnu = (Sg + dw)*nd.dsg[r] + gphi - nd.nu[r];
                         nd.sg[r] += alpha_pr*nd.dsg[r];
                         nd.nu[r] += alpha_pr*dnu;
-                        if (U.rL[r]) { nd.zLs[r] += alpha_du*dzl; const double s = nd.sg[r] - U.dL[r]; nd.zLs[r] = sigma_clamp(nd.zLs[r], mu, s); }
-                        if (U.rU[r]) { nd.zUs[r] += alpha_du*dzu; const double s = U.dU[r] - nd.sg[r]; nd.zUs[r] = sigma_clamp(nd.zUs[r], mu, s); }
+                        if (rL(r)) { nd.zLs[r] += alpha_du*dzl; const double s = nd.sg[r] - U.dL[r]; nd.zLs[r] = sigma_clamp(nd.zLs[r], mu, s); }
+                        if (rU(r)) { nd.zUs[r] += alpha_du*dzu; const double s = U.dU[r] - nd.sg[r]; nd.zUs[r] = sigma_clamp(nd.zUs[r], mu, s); }
                     }
                     nd.lam[0] += alpha_pr*(dd.lt - nd.lam[0]); nd.lam[1] += alpha_pr*(dd.lb - nd.lam[1]);
                 }
@@ -2626,22 +2636,22 @@ struct Solver {
         }
 
         /* ---- outputs: z in the reference's layout (ocp.py:166-272), multipliers in the reference's row order ---- */
-        const int stp = 4 + P.withPn;
+        const int stp = 4 + withPn();
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<11>();
             const NodeT &nd = n[j];
             if (nd.ival()) {
                 double *zi = z_out + stp*nd.i; int k = 0;
-                zi[k++] = nd.x[VF]; if (P.withPn) zi[k++] = nd.x[VP];
+                zi[k++] = nd.x[VF]; if (withPn()) zi[k++] = nd.x[VP];
                 zi[k++] = nd.x[VS]; zi[k++] = nd.x[VT]; zi[k++] = nd.x[VB];
                 if (lam_out) {
-                    const int rpi = (P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0);
+                    const int rpi = (hasPower() ? 2 : 0) + 3 + (energyOpt() ? 2 : 0);
                     double *l = lam_out + rpi*nd.i; int m = 0;
-                    if (P.hasPower) { l[m++] = nd.nu[RPW0]*U.rs[RPW0]/U.sf; l[m++] = nd.nu[RPW1]*U.rs[RPW1]/U.sf; }
+                    if (hasPower()) { l[m++] = nd.nu[RPW0]*U.rs[RPW0]/U.sf; l[m++] = nd.nu[RPW1]*U.rs[RPW1]/U.sf; }
                     l[m++] = nd.nu[RACC]*U.rs[RACC]/U.sf;
                     l[m++] = nd.lam[0]/U.sf; l[m++] = nd.lam[1]/U.sf;
-                    if (P.energyOpt) { l[m++] = nd.nu[RLTR]*U.rs[RLTR]/U.sf; l[m++] = nd.nu[RLRG]*U.rs[RLRG]/U.sf; }
+                    if (energyOpt()) { l[m++] = nd.nu[RLTR]*U.rs[RLTR]/U.sf; l[m++] = nd.nu[RLRG]*U.rs[RLRG]/U.sf; }
                 }
             } else if (nd.i == N) { z_out[stp*N] = nd.x[VT]; z_out[stp*N + 1] = nd.x[VB]; }
         }
@@ -2665,7 +2675,7 @@ struct Solver {
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
  * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
  */
-template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false>
+template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
@@ -2719,7 +2729,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         __syncthreads();
         if (c.tid == 0) *Pl = Ps;
         __syncthreads();
-        Solver<NT, SPT, DYN, STREAM, GEN> s(*Pl, c, wg_work, *Ul);
+        Solver<NT, SPT, DYN, STREAM, GEN, FULL> s(*Pl, c, wg_work, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
         const double *dual_in = (guess && P.dualIn) ? P.dualIn + (size_t)P.dualInStride*sidx + (size_t)MSD_DUAL_STRIDE*P.dualShift : nullptr;

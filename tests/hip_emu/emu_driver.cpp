@@ -16,7 +16,7 @@
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
 
-template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false>
+template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
 static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
@@ -31,7 +31,7 @@ static void run_blocks(msd::DevProb P, int nscen, const double *scen, const doub
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -99,6 +99,12 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
         return 0;
     }
     if (NT*SPT < nodes) return -3;
+    /* the kernels with the structure of the NLP compiled in (msd_kernels_full.hip), chosen like msd_api.hip does; EMU_NO_FULL=1: the general ones */
+    const char *nofull = getenv("EMU_NO_FULL");
+    const bool full = !dyn && P.withPn && P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && !(nofull && *nofull == '1');
+    if (full && NT == 64 && SPT == 1) { run_blocks<64, 1, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
+    if (full && NT == 64 && SPT == 2) { run_blocks<64, 2, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
+    if (full && NT == 128 && SPT == 2) { run_blocks<128, 2, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
     if (NT == 64 && SPT == 1) { if (dyn) run_blocks<64, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
     else if (NT == 64 && SPT == 2) { if (dyn) run_blocks<64, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
     else if (NT == 128 && SPT == 1) { if (dyn) run_blocks<128, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<128, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
