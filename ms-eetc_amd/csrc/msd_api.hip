@@ -166,7 +166,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     const bool full = d->with_pn_brake != 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                       && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
     msd::Geometry geo = gen ? msd::pick_geometry_general(N) : intloss ? msd::pick_geometry_intloss(N) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full);
-    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide) : 0;
+    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
     if ((gen || intloss) && (!geo.fn || lds > 160*1024))
         return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " with the collocation or adaptive shooting integrator or with integrateLosses does not fit the LDS-resident kernel (the streamed kernel runs 'RK' with the mid-point loss rows)");
     if (!geo.fn || lds > 160*1024) {

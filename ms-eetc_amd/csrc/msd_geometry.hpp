@@ -11,7 +11,12 @@ namespace msd {
 using KernelFn = void (*)(DevProb, int, const double *, const double *, double *, double *, double *, double *, int, double *);
 
 /* NT threads per workgroup, SPT shooting nodes per thread (NT*SPT >= N + 1) */
-struct Geometry { int NT, SPT; KernelFn fn; bool stream = false; };     /* stream: stage blocks in device memory (long horizons) */
+struct Geometry {
+    int NT, SPT; KernelFn fn;
+    bool stream = false;                 /* stage blocks in device memory (long horizons) */
+    int xch = XCH_GENERAL;               /* exchange arrays in LDS and cross-wave reduction scratch (lds_doubles) */
+    int red = RED_DOUBLES;
+};
 
 Geometry pick_geometry_static(int N, bool full);     /* full: both brakes, power rows, energy objective -- the kernels with that structure compiled in */
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */

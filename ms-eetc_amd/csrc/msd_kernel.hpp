@@ -85,6 +85,9 @@
 #ifndef MSD_PARK_STATE
 #define MSD_PARK_STATE 0            /* pin the iterate in accumulation registers across the stage-parallel KKT solve */
 #endif
+#ifndef MSD_TELEMETRY
+#define MSD_TELEMETRY 0             /* per-phase cycle counters of the logged scenario (Ctx::mark) */
+#endif
 #ifndef MSD_PARALLEL_RICCATI
 #define MSD_PARALLEL_RICCATI 1      /* stage-parallel KKT solve (scan over the lanes, msd_scan.hpp); 0: serial sweep on one lane */
 #endif
@@ -168,9 +171,13 @@ constexpr int S_EB = 28, S_ES = 29;
 /* LDS of the streamed kernel: filter, reduction scratch, misc, uniform records */
 __host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96; }
 
-__host__ __device__ __forceinline__ int lds_doubles(int N, int NT, bool dyn)
+/* exchange arrays over the node slots: neighbour t, b, Fel and three outgoing contributions; the fused iteration of the kernels with the
+ * problem structure compiled in (Solver::FAST) publishes sqrt(b) too and sends seven contributions in one pass */
+constexpr int XCH_GENERAL = 6, XCH_FAST = 11;
+constexpr int RED_DOUBLES = RED_SLOTS*MAX_WAVES*RED_K;      /* cross-wave reduction scratch; a single-wave FAST kernel has none */
+__host__ __device__ __forceinline__ int lds_doubles(int N, int NS, bool dyn, int nxch = XCH_GENERAL, int red = RED_DOUBLES)
 {
-    return stage_stride(dyn)*(N + 1) + 6*NT + 2*FILT_CAP + RED_SLOTS*MAX_WAVES*RED_K + 32 + CONST_DOUBLES;
+    return stage_stride(dyn)*(N + 1) + nxch*NS + 2*FILT_CAP + red + 32 + CONST_DOUBLES;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -228,6 +235,17 @@ template <class T> __device__ __forceinline__ T rk4_b(const DevProb &P, T b, T w
 template <class T> __device__ __forceinline__ void interval_map(const DevProb &P, double b0, double w0, double G, double ds, T &tau, T &bplus)
 {
     T b = make_var(T(), b0, 0), w = make_var(T(), w0, 1);
+    if (P.numApprox == 1 && P.numSteps == 1) {
+        /* the integrator of simulations/config.json (one RK4 step, one trapezoid: every BASELINE config), straight-line */
+        T k1 = ode_b(P, b, w, G, ds);
+        T k2 = ode_b(P, b + k1*0.5, w, G, ds);
+        T k3 = ode_b(P, b + k2*0.5, w, G, ds);
+        T k4 = ode_b(P, b + k3*1.0, w, G, ds);
+        T cur = b + ((k1 + k2*2.0) + (k3*2.0 + k4))*(1.0/6);
+        tau = xrecip(xsqrt(b) + xsqrt(cur))*(2*ds*(1.0 - 0.0));
+        bplus = cur;
+        return;
+    }
     if (P.numApprox == 0) {
         double h = 1.0/P.numSteps;
         T t = make_zero(T());
@@ -367,12 +385,14 @@ __device__ __forceinline__ double track_resistance(const DevProb &P, double grad
  * ---------------------------------------------------------------------------------------- */
 struct Ctx {
     double *S, *xt, *xb, *xf, *o1, *o2, *o3, *filt, *red, *misc;
+    double *xs, *o4, *o5, *o6, *o7;      /* FAST kernels only: sqrt(b) of the published point, four more outgoing contributions */
     int tid, lane, wave, nw, nt, red_slot;
     unsigned long long tmark;
-    /* telemetry: thread 0 accumulates the shader cycles spent since the previous mark into misc[2 + phase] */
+    /* telemetry (tuning builds, -DMSD_TELEMETRY=1: tools/phase_cycles.py): thread 0 accumulates the shader cycles spent since the previous
+     * mark into misc[2 + phase].  A mark drains the wave's outstanding memory operations, so the product build has none */
     __device__ __forceinline__ void mark(int phase)
     {
-        if (tid == 0) {
+        if (MSD_TELEMETRY && tid == 0) {
             const unsigned long long t = __builtin_readcyclecounter();
             misc[2 + phase] += (double)(t - tmark);
             tmark = t;
@@ -575,6 +595,7 @@ struct Uni {
     double tlo, thi, blo, flo, fhi, plo, phi, slo;     /* relaxed variable bounds */
     bool rowOn[NR], rL[NR], rU[NR];
     double dL[NR], dU[NR], rs[NR];                     /* relaxed (scaled) row bounds, row scaling */
+    double irs[NR];                                    /* 1/rs */
     double sf;                                         /* objective scaling */
 };
 
@@ -2176,7 +2197,483 @@ struct Solver {
         __syncthreads();
     }
 
-    /* one solve; startKind: MSD_START_* (ignored with an external guess); returns the status, iters_out = iterations spent */
+    /* ------------------------------------------------------------------------------------------
+     * FAST: the iteration of the kernels with the problem structure compiled in (FULL, constant efficiencies, explicit
+     * Runge-Kutta shooting, LDS-resident).  Same algorithm, same formulas, arranged so that a point is looked at once:
+     *   fused_pass       evaluation with derivatives + optimality error + condensed stage blocks in one pass over the nodes
+     *                    (kkt_pass + assemble of the general path; one reciprocal per bound; the jets never leave the pass);
+     *                    the barrier parameter is chosen after the pass, so the gradient side of the blocks is kept as h0 + mu h1
+     *   post_direction   slack steps + directional derivative + fraction-to-the-boundary ratios (one reciprocal per bound)
+     *   merit_fast       the trial point: its theta, barrier sums and objective become those of the next current point
+     *   update_fast      accepted step
+     * Anything rare -- wrong inertia, scan breakdown, a rejected first trial point (backtracking, second-order correction) --
+     * repeats the iteration on the general path (run()).
+     * ---------------------------------------------------------------------------------------- */
+    static constexpr bool FAST = FULL && DYN == LOSS_STATIC && !STREAM && !GEN && !MSD_MEM_X && !MSD_MEM_SG && !MSD_MEM_LAM && !MSD_MEM_NU && !MSD_MEM_Z
+                                 && !MSD_MEM_DSG && !MSD_MEM_RES && MSD_PARALLEL_RICCATI;
+    static constexpr int HV = 6;      /* gradient side of a stage block: t, b, q, f, p and the slack row */
+    double cnt_lam = 0, cnt_z = 0;    /* numbers of constraint and of bound multipliers (fused_pass) */
+
+    __device__ static __forceinline__ double step_to(double x, double alpha, double d) { return fma(alpha, d, x); }
+
+    /* (t, b, sqrt(b), Fel) of a point into the exchange arrays */
+    __device__ __forceinline__ void publish_fast(const double (&x)[SPT][NV])
+    {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) { const int i = n[j].i; c.xt[i] = x[j][VT]; c.xb[i] = x[j][VB]; c.xs[i] = sqrt(x[j][VB]); c.xf[i] = x[j][VF]; }
+        __syncthreads();
+    }
+
+    /* the rows' non-zero gradient entries at (f, sb, sb1), scaled (ocp.py:189-229 with constant efficiencies) */
+    struct RowG { double g0f, g0b, g1f, g1b1, g2f, g2b, g3f, g3s, g4f, g4s; };
+    __device__ __forceinline__ RowG row_grads_fast(double f, double sb, double sb1, double isb, double isb1) const
+    {
+        RowG g;
+        const double r0 = U.rs[RPW0], r1 = U.rs[RPW1], r2 = U.rs[RACC], r3 = U.rs[RLTR], r4 = U.rs[RLRG];
+        g.g0f = r0*sb; g.g0b = r0*(0.5*f*isb);
+        g.g1f = r1*sb1; g.g1b1 = r1*(0.5*f*isb1);
+        g.g2f = r2; g.g2b = -r2*(0.5*P.sr1*isb + P.sr2);
+        g.g3f = -r3*P.ct; g.g3s = r3; g.g4f = r4*P.cr; g.g4s = r4;
+        return g;
+    }
+
+    /*
+     * One pass over the current point (published in the exchange arrays): constraint values and derivatives, optimality error
+     * (W&B eq. (5)), condensed stage blocks (W&B eq. (13)) with the gradient side split as h0 + mu h1.  MERIT: also theta, the
+     * barrier sums and the objective (first iteration, or after an iteration on the general path); otherwise E keeps the values
+     * the accepted trial point left there.
+     */
+    __device__ __forceinline__ void fused_pass(const bool MERIT, Err &E, double (&h0)[SPT][HV], double (&h1)[SPT][HV])
+    {
+        const int N = P.N;
+        double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;      /* (nlam, nz: MERIT passes only) */
+        double th = 0, damp = 0, obj = 0;
+        LogSum lsum;
+        double gl[SPT][NV], Hbb_[SPT], Hbq_[SPT];
+        const double sc = U.sf/P.objDen;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<0>();
+            NodeT &nd = n[j];
+            const int i = nd.i;
+            double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
+            double a0[HV] = {0, 0, 0, 0, 0, 0}, a1[HV] = {0, 0, 0, 0, 0, 0};      /* t b q f p s */
+            double nHbb = 0, nHbq = 0, nhb0 = 0, nhb1 = 0, out_q = 0, out_t1 = 0, out_b1 = 0, prod = 1.0;
+            double tb = 0, tw = 0, Bb = 0, Bw = 0, rt = 0, rb = 0;
+#pragma unroll
+            for (int k = 0; k < NV; k++) gl[j][k] = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) resd[j][r] = 0;
+            if (nd.ival()) {
+                const double t = nd.x[VT], b = nd.x[VB], f = nd.x[VF], p = nd.x[VP], s = nd.x[VS];
+                const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
+                const double q = (i > 0) ? c.xf[i - 1] : 0.0;
+                Jet tau, bp;
+                interval_map<Jet>(P, b, f + p, nd.G, nd.ds, tau, bp);
+                const double cv0 = t1 - (t + tau.v), cv1 = b1 - bp.v;
+                tb = tau.g0; tw = tau.g1; Bb = bp.g0; Bw = bp.g1; rt = -cv0; rb = -cv1;
+                const double isb = 1.0/sb, isb1 = 1.0/sb1;
+                const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
+                /* rows d(x), scaled (eval_interval) */
+                double dv[NR];
+                dv[RPW0] = U.rs[RPW0]*f*sb; dv[RPW1] = U.rs[RPW1]*f*sb1;
+                dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nd.G);
+                dv[RLTR] = U.rs[RLTR]*(s - P.ct*f); dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);
+                /* objective (obj_grads) */
+                double of = sc*nd.ds, oq = 0, off = 0;
+                const double os = sc*nd.ds;
+                if (i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
+                /* gradient of the Lagrangian wrt the interval's own variables, and what belongs to the neighbours */
+                const double l0 = nd.lam[0], l1 = nd.lam[1];
+                const double dyn_w = l0*tw + l1*Bw;
+                gl[j][VT] = -l0;
+                gl[j][VB] = nd.nu[RPW0]*g.g0b + nd.nu[RACC]*g.g2b - (l0*tb + l1*Bb);
+                gl[j][VF] = of + nd.nu[RPW0]*g.g0f + nd.nu[RPW1]*g.g1f + nd.nu[RACC]*g.g2f + nd.nu[RLTR]*g.g3f + nd.nu[RLRG]*g.g4f - dyn_w;
+                gl[j][VP] = nd.nu[RACC]*g.g2f - dyn_w;
+                gl[j][VS] = os + nd.nu[RLTR]*g.g3s + nd.nu[RLRG]*g.g4s;
+                out_q = oq; out_t1 = l0; out_b1 = nd.nu[RPW1]*g.g1b1 + l1;
+                prim = fmax(prim, fmax(nd.sct*fabs(cv0), nd.scb*fabs(cv1)));
+                prim_u = fmax(prim_u, fmax(fabs(cv0), fabs(cv1)));
+                if (MERIT) th += nd.sct*fabs(cv0) + nd.scb*fabs(cv1);
+                sumlam += fabs(l0)/nd.sct + fabs(l1)/nd.scb; if (MERIT) nlam += 2;
+                /* Hessian of the Lagrangian: objective, dynamics, power and acceleration rows (assemble) */
+                a0[2] = oq; a0[3] = of; a0[5] = os;
+                Hff = off;
+                if (i > 0) { Hqq = off; Hqf = -off; }
+                {
+                    const double hbb = -(l0*tau.h00 + l1*bp.h00), hbw = -(l0*tau.h01 + l1*bp.h01), hww = -(l0*tau.h11 + l1*bp.h11);
+                    Hbb += hbb; Hbf += hbw; Hff += hww; Hbp += hbw; Hfp += hww; Hpp += hww;
+                }
+                {
+                    const double ib = isb*isb, ib1 = isb1*isb1;
+                    Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5*isb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f*(ib*isb));
+                    nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5*isb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f*(ib1*isb1));
+                    Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1*(ib*isb);
+                }
+                /* rows: residuals, slack bounds (one reciprocal each), condensation */
+                double Sg[NR], c0[NR], c1[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const double rd_ = dv[r] - nd.sg[r];
+                    resd[j][r] = rd_;
+                    const double viol = fabs(rd_);
+                    prim = fmax(prim, viol); prim_u = fmax(prim_u, viol*U.irs[r]);
+                    if (MERIT) th += viol;
+                    sumlam += fabs(nd.nu[r]); if (MERIT) nlam += 1;
+                    double gsl = -nd.nu[r], S_, g1_;
+                    {
+                        const double sl = nd.sg[r] - U.dL[r], z = nd.zLs[r], ri = 1.0/sl, cp = sl*z;
+                        gsl -= z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= sl;
+                        S_ = z*ri; g1_ = -ri;
+                    }
+                    if (r <= RACC) {
+                        const double su = U.dU[r] - nd.sg[r], z = nd.zUs[r], ri = 1.0/su, cp = su*z;
+                        gsl += z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= su;
+                        S_ += z*ri; g1_ += ri;
+                    } else { g1_ += K_D; if (MERIT) damp += nd.sg[r] - U.dL[r]; }
+                    dual = fmax(dual, fabs(gsl));
+                    Sg[r] = S_; c0[r] = S_*rd_; c1[r] = g1_;
+                }
+                /* h += coef grad(row), H += Sigma grad grad^T over the rows' non-zeros */
+                a0[1] += c0[RPW0]*g.g0b + c0[RACC]*g.g2b;                       a1[1] += c1[RPW0]*g.g0b + c1[RACC]*g.g2b;
+                a0[3] += c0[RPW0]*g.g0f + c0[RPW1]*g.g1f + c0[RACC]*g.g2f + c0[RLTR]*g.g3f + c0[RLRG]*g.g4f;
+                a1[3] += c1[RPW0]*g.g0f + c1[RPW1]*g.g1f + c1[RACC]*g.g2f + c1[RLTR]*g.g3f + c1[RLRG]*g.g4f;
+                a0[4] += c0[RACC]*g.g2f;                                         a1[4] += c1[RACC]*g.g2f;
+                a0[5] += c0[RLTR]*g.g3s + c0[RLRG]*g.g4s;                        a1[5] += c1[RLTR]*g.g3s + c1[RLRG]*g.g4s;
+                nhb0 = c0[RPW1]*g.g1b1; nhb1 = c1[RPW1]*g.g1b1;
+                Hbb += Sg[RPW0]*g.g0b*g.g0b + Sg[RACC]*g.g2b*g.g2b;
+                Hbf += Sg[RPW0]*g.g0b*g.g0f + Sg[RACC]*g.g2b*g.g2f;
+                Hbp += Sg[RACC]*g.g2b*g.g2f;
+                Hff += Sg[RPW0]*g.g0f*g.g0f + Sg[RPW1]*g.g1f*g.g1f + Sg[RACC]*g.g2f*g.g2f + Sg[RLTR]*g.g3f*g.g3f + Sg[RLRG]*g.g4f*g.g4f;
+                Hfp += Sg[RACC]*g.g2f*g.g2f; Hpp += Sg[RACC]*g.g2f*g.g2f;
+                Hfs += Sg[RLTR]*g.g3f*g.g3s + Sg[RLRG]*g.g4f*g.g4s;
+                Hss += Sg[RLTR]*g.g3s*g.g3s + Sg[RLRG]*g.g4s*g.g4s;
+                nHbq += Sg[RPW1]*g.g1f*g.g1b1; nHbb += Sg[RPW1]*g.g1b1*g.g1b1;
+            }
+            /* bounds of the node's own variables */
+            if (nd.node()) {
+                double Sv[NV], g1v[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    Sv[k] = 0; g1v[k] = 0;
+                    if (!nd.on(k)) continue;
+                    {
+                        const double sl = nd.x[k] - lbv(k), z = nd.zL[k], ri = 1.0/sl, cp = sl*z;
+                        gl[j][k] -= z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= sl;
+                        Sv[k] = z*ri; g1v[k] = -ri;
+                    }
+                    if (hasU(k)) {
+                        const double su = ubv(j, k) - nd.x[k], z = nd.zU[k], ri = 1.0/su, cp = su*z;
+                        gl[j][k] += z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= su;
+                        Sv[k] += z*ri; g1v[k] += ri;
+                    } else { g1v[k] += K_D; if (MERIT) damp += nd.x[k] - lbv(k); }
+                }
+                Htt += Sv[VT]; a1[0] += g1v[VT]; Hbb += Sv[VB]; a1[1] += g1v[VB]; Hff += Sv[VF]; a1[3] += g1v[VF]; Hpp += Sv[VP]; a1[4] += g1v[VP];
+                Hss += Sv[VS]; a1[5] += g1v[VS];
+                if (MERIT) {
+                    double xl[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
+                    obj += objective_term<false, true>(P, nd, xl, (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
+                }
+                double *sB = c.S + i*S_STRIDE;
+                if (nd.ival()) {
+                    sB[S_TB] = tb; sB[S_TW] = tw; sB[S_BB] = Bb; sB[S_BW] = Bw; sB[S_RT] = rt; sB[S_RB] = rb;
+                    /* the slack variable is eliminated here (pivot Hss), except in the last interval (assemble) */
+                    const bool last = i == N - 1;
+                    const double is = (Hss > 0) ? 1.0/Hss : NAN;
+                    if (!last) {
+                        const double wf = Hfs*is;
+                        Hff -= Hfs*wf; a0[3] -= wf*a0[5]; a1[3] -= wf*a1[5];
+                    }
+                    sB[S_GFS] = Hfs; sB[S_IS] = is;
+                }
+                sB[S_HTT] = Htt; sB[S_HBF] = Hbf; sB[S_HBP] = Hbp; sB[S_HQQ] = Hqq; sB[S_HQF] = Hqf; sB[S_HFF] = Hff; sB[S_HFP] = Hfp; sB[S_HPP] = Hpp;
+            }
+            Hbb_[j] = Hbb; Hbq_[j] = Hbq;
+#pragma unroll
+            for (int k = 0; k < HV; k++) { h0[j][k] = a0[k]; h1[j][k] = a1[k]; }
+            if (MERIT) lsum.add(prod);
+            c.o1[i] = nHbb; c.o2[i] = nHbq; c.o3[i] = nhb0; c.o4[i] = nhb1; c.o5[i] = out_q; c.o6[i] = out_t1; c.o7[i] = out_b1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<0>();
+            const NodeT &nd = n[j];
+            if (!nd.node()) continue;
+            const int i = nd.i;
+            double Hbb = Hbb_[j], Hbq = Hbq_[j];
+            if (i > 0) {
+                Hbb += c.o1[i - 1]; Hbq += c.o2[i - 1]; h0[j][1] += c.o3[i - 1]; h1[j][1] += c.o4[i - 1];
+                gl[j][VT] += c.o6[i - 1]; gl[j][VB] += c.o7[i - 1];
+            }
+            if (i + 1 < N) gl[j][VF] += c.o5[i + 1];
+            double *sB = c.S + i*S_STRIDE;
+            sB[S_HBB] = Hbb; sB[S_HBQ] = Hbq;
+#pragma unroll
+            for (int k = 0; k < NV; k++) if (nd.on(k)) dual = fmax(dual, fabs(gl[j][k]));
+        }
+        double vm[5] = {dual, prim, prim_u, cmax, -cmin};
+        block_reduce<5>(vm, OpMax(), c);
+        E.dual = uni(vm[0]); E.primal = uni(vm[1]); E.primal_u = uni(vm[2]); E.cmax = uni(vm[3]); E.cmin = -uni(vm[4]);
+        if (MERIT) {
+            double vs[8] = {sumlam, sumz, nlam, nz, th, lsum.value(), damp, obj};
+            block_reduce<8>(vs, OpSum(), c);
+            E.sd = uni(fmax(K_SMAX, (vs[0] + vs[1])/fmax(1.0, vs[2] + vs[3]))/K_SMAX);
+            E.sc = uni(fmax(K_SMAX, vs[1]/fmax(1.0, vs[3]))/K_SMAX);
+            E.theta = uni(vs[4]); E.L = uni(vs[5]); E.D = uni(vs[6]); E.obj = uni(vs[7]);
+            cnt_lam = uni(vs[2]); cnt_z = uni(vs[3]);      /* constants of the scenario */
+        } else {
+            double vs[2] = {sumlam, sumz};
+            block_reduce<2>(vs, OpSum(), c);
+            E.sd = uni(fmax(K_SMAX, (vs[0] + vs[1])/fmax(1.0, cnt_lam + cnt_z))/K_SMAX);
+            E.sc = uni(fmax(K_SMAX, vs[1]/fmax(1.0, cnt_z))/K_SMAX);
+        }
+    }
+
+    /* gradient side of the stage blocks for the barrier parameter of this iteration */
+    __device__ __forceinline__ void finish_blocks(const double (&h0)[SPT][HV], const double (&h1)[SPT][HV], double mu_)
+    {
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const NodeT &nd = n[j];
+            if (!nd.node()) continue;
+            double *sB = c.S + nd.i*S_STRIDE;
+            sB[S_HT] = h0[j][0] + mu_*h1[j][0]; sB[S_HB] = h0[j][1] + mu_*h1[j][1]; sB[S_HQ] = h0[j][2] + mu_*h1[j][2];
+            sB[S_HF] = h0[j][3] + mu_*h1[j][3]; sB[S_HP] = h0[j][4] + mu_*h1[j][4];
+            if (nd.ival()) sB[S_GS] = h0[j][5] + mu_*h1[j][5];
+        }
+        __syncthreads();
+    }
+
+    /*
+     * After the KKT solve: slack steps, directional derivative of the barrier function, step norms, fraction-to-the-boundary
+     * ratios.  Per bound one reciprocal, w = 1/(slack z): 1/slack = z w, 1/z = slack w.
+     */
+    __device__ __forceinline__ void post_direction(double mu_, double tau_, double &gphid, double &dnorm, bool &tiny_step, double &amax, double &adu)
+    {
+        const int N = P.N;
+        finish_direction();
+        const double sc = U.sf/P.objDen;
+        double gd = 0, dn = 0, rel = -1.0, rp = 0, rd = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<9>();
+            NodeT &nd = n[j];
+#pragma unroll
+            for (int r = 0; r < NR; r++) nd.dsg[r] = 0;
+            if (!nd.node()) continue;
+            const int i = nd.i;
+            Dir d; load_dir(j, d);
+            double og[NV] = {0, 0, 0, 0, 0};
+            if (nd.ival()) {
+                const double f = nd.x[VF], sb = c.xs[i], sb1 = c.xs[i + 1];
+                const double q = (i > 0) ? c.xf[i - 1] : 0.0;
+                og[VF] = sc*nd.ds; og[VS] = sc*nd.ds;
+                if (i > 0) og[VF] += sc*2e-3*(f - q);
+                if (i + 1 < N) og[VF] += c.o5[i + 1];       /* d(obj)/dq of the next interval (fused_pass left it there) */
+                const double isb = 1.0/sb, isb1 = 1.0/sb1;
+                const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
+                const double db1 = c.S[(i + 1)*S_STRIDE + S_DB];
+                nd.dsg[RPW0] = resd[j][RPW0] + (g.g0b*d.dx[VB] + g.g0f*d.dx[VF]);
+                nd.dsg[RPW1] = resd[j][RPW1] + (g.g1f*d.dx[VF] + g.g1b1*db1);
+                nd.dsg[RACC] = resd[j][RACC] + (g.g2b*d.dx[VB] + g.g2f*d.dx[VF] + g.g2f*d.dx[VP]);
+                nd.dsg[RLTR] = resd[j][RLTR] + (g.g3f*d.dx[VF] + g.g3s*d.dx[VS]);
+                nd.dsg[RLRG] = resd[j][RLRG] + (g.g4f*d.dx[VF] + g.g4s*d.dx[VS]);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if (!nd.on(k)) continue;
+                const double dk = d.dx[k];
+                double gp;
+                {
+                    const double s = nd.x[k] - lbv(k), z = nd.zL[k], w = 1.0/(s*z), r = z*w, iz = s*w;
+                    gp = -mu_*r; rp = fmax(rp, -dk*r);
+                    rd = fmax(rd, -(r*(mu_ - z*dk) - z)*iz);
+                }
+                if (hasU(k)) {
+                    const double s = ubv(j, k) - nd.x[k], z = nd.zU[k], w = 1.0/(s*z), r = z*w, iz = s*w;
+                    gp += mu_*r; rp = fmax(rp, dk*r);
+                    rd = fmax(rd, -(r*(mu_ + z*dk) - z)*iz);
+                } else gp += K_D*mu_;
+                gd += (og[k] + gp)*dk;
+                dn = fmax(dn, fabs(dk)); rel = fmax(rel, fabs(dk) - 10*DBL_EPSILON*(1 + fabs(nd.x[k])));
+            }
+            if (nd.ival()) {
+#pragma unroll
+                for (int r_ = 0; r_ < NR; r_++) {
+                    const double dk = nd.dsg[r_];
+                    double gp;
+                    {
+                        const double s = nd.sg[r_] - U.dL[r_], z = nd.zLs[r_], w = 1.0/(s*z), r = z*w, iz = s*w;
+                        gp = -mu_*r; rp = fmax(rp, -dk*r);
+                        rd = fmax(rd, -(r*(mu_ - z*dk) - z)*iz);
+                    }
+                    if (r_ <= RACC) {
+                        const double s = U.dU[r_] - nd.sg[r_], z = nd.zUs[r_], w = 1.0/(s*z), r = z*w, iz = s*w;
+                        gp += mu_*r; rp = fmax(rp, dk*r);
+                        rd = fmax(rd, -(r*(mu_ + z*dk) - z)*iz);
+                    } else gp += K_D*mu_;
+                    gd += gp*dk;
+                    dn = fmax(dn, fabs(dk)); rel = fmax(rel, fabs(dk) - 10*DBL_EPSILON*(1 + fabs(nd.sg[r_])));
+                }
+            }
+        }
+        double v1[1] = {gd}; block_reduce<1>(v1, OpSum(), c);
+        double v2[4] = {dn, rel, rp, rd}; block_reduce<4>(v2, OpMax(), c);
+        gphid = uni(v1[0]); dnorm = uni(v2[0]); tiny_step = uni(v2[1]) < 0;
+        const double rpm = uni(v2[2]), rdm = uni(v2[3]);
+        amax = (rpm > tau_) ? tau_/rpm : 1.0;
+        adu = (rdm > tau_) ? tau_/rdm : 1.0;
+    }
+
+    /* the point x + alpha d: published, theta / barrier sums / objective into T (which become the next current point's when it is accepted) */
+    __device__ __forceinline__ void merit_fast(double alpha, double mu_, Err &T, double &phi, bool &ok)
+    {
+        double xt[SPT][NV], st[SPT][NR];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<4>();
+            Dir dd; load_dir(j, dd);
+#pragma unroll
+            for (int k = 0; k < NV; k++) xt[j][k] = step_to(n[j].x[k], alpha, dd.dx[k]);
+#pragma unroll
+            for (int r = 0; r < NR; r++) st[j][r] = step_to(n[j].sg[r], alpha, n[j].dsg[r]);
+        }
+        publish_fast(xt);
+        double th = 0, damp = 0, bad = 0, obj = 0;
+        LogSum lsum;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<5>();
+            const NodeT &nd = n[j];
+            const int i = nd.i;
+            double prod = 1.0;
+            if (nd.ival()) {
+                const double t = xt[j][VT], b = xt[j][VB], f = xt[j][VF], p = xt[j][VP], s = xt[j][VS];
+                const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
+                double tau, bp;
+                interval_map<double>(P, b, f + p, nd.G, nd.ds, tau, bp);
+                th += nd.sct*fabs(t1 - (t + tau)) + nd.scb*fabs(b1 - bp);
+                double dv[NR];
+                dv[RPW0] = U.rs[RPW0]*f*sb; dv[RPW1] = U.rs[RPW1]*f*sb1;
+                dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nd.G);
+                dv[RLTR] = U.rs[RLTR]*(s - P.ct*f); dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    th += fabs(dv[r] - st[j][r]);
+                    { const double sl = st[j][r] - U.dL[r]; if (sl <= 0) bad = 1; else prod *= sl; }
+                    if (r <= RACC) { const double su = U.dU[r] - st[j][r]; if (su <= 0) bad = 1; else prod *= su; }
+                    else damp += st[j][r] - U.dL[r];
+                }
+            }
+            if (nd.node()) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    { const double sl = xt[j][k] - lbv(k); if (sl <= 0) bad = 1; else prod *= sl; }
+                    if (hasU(k)) { const double su = ubv(j, k) - xt[j][k]; if (su <= 0) bad = 1; else prod *= su; }
+                    else damp += xt[j][k] - lbv(k);
+                }
+                obj += objective_term<false, true>(P, nd, xt[j], (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
+            }
+            lsum.add(prod);
+        }
+        double v[5] = {th, lsum.value(), damp, obj, bad};
+        block_reduce<5>(v, OpSum(), c);
+        T.theta = uni(v[0]); T.L = uni(v[1]); T.D = uni(v[2]); T.obj = uni(v[3]);
+        phi = T.obj - mu_*T.L + K_D*mu_*T.D;
+        ok = (uni(v[4]) == 0.0) && isfinite(T.theta) && isfinite(phi);
+    }
+
+    /* accept x + alpha d (the point merit_fast published); multipliers like the general path's update.  The safeguard that keeps
+     * Sigma = z/slack within [mu/(kappa_Sigma slack), kappa_Sigma mu/slack] (W&B eq. (16)) is tested on the product z slack; the division it
+     * needs when it acts (kappa_Sigma = 1e10: next to never) is left to a second pass that runs only then */
+    __device__ __forceinline__ void update_fast(double apr, double adu, double mu_)
+    {
+        const double hi = K_SIGMA*mu_, lo = mu_*(1.0/K_SIGMA);
+        bool clamp = false;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            node_fence<10>();
+            NodeT &nd = n[j];
+            if (!nd.node()) continue;
+            Dir dd; load_dir(j, dd);
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if (!nd.on(k)) continue;
+                const double dk = dd.dx[k], xo = nd.x[k], xn = step_to(xo, apr, dk);
+                {
+                    const double s = xo - lbv(k), z = nd.zL[k], r = 1.0/s;
+                    const double zn = z + adu*(r*(mu_ - z*dk) - z), cn = zn*(xn - lbv(k));
+                    clamp |= !(cn <= hi && cn >= lo);
+                    nd.zL[k] = zn;
+                }
+                if (hasU(k)) {
+                    const double s = ubv(j, k) - xo, z = nd.zU[k], r = 1.0/s;
+                    const double zn = z + adu*(r*(mu_ + z*dk) - z), cn = zn*(ubv(j, k) - xn);
+                    clamp |= !(cn <= hi && cn >= lo);
+                    nd.zU[k] = zn;
+                }
+                nd.x[k] = xn;
+            }
+            if (nd.ival()) {
+#pragma unroll
+                for (int r_ = 0; r_ < NR; r_++) {
+                    const double dk = nd.dsg[r_], so = nd.sg[r_], sn_ = step_to(so, apr, dk);
+                    double Sg, gphi;
+                    {
+                        const double s = so - U.dL[r_], z = nd.zLs[r_], r = 1.0/s;
+                        Sg = z*r; gphi = -mu_*r;
+                        const double zn = z + adu*(r*(mu_ - z*dk) - z), cn = zn*(sn_ - U.dL[r_]);
+                        clamp |= !(cn <= hi && cn >= lo);
+                        nd.zLs[r_] = zn;
+                    }
+                    if (r_ <= RACC) {
+                        const double s = U.dU[r_] - so, z = nd.zUs[r_], r = 1.0/s;
+                        Sg += z*r; gphi += mu_*r;
+                        const double zn = z + adu*(r*(mu_ + z*dk) - z), cn = zn*(U.dU[r_] - sn_);
+                        clamp |= !(cn <= hi && cn >= lo);
+                        nd.zUs[r_] = zn;
+                    } else gphi += K_D*mu_;
+                    /* new inequality multiplier nu+ = Sigma dsigma + grad phi_sigma, at the old point */
+                    nd.nu[r_] += apr*(Sg*dk + gphi - nd.nu[r_]);
+                    nd.sg[r_] = sn_;
+                }
+                nd.lam[0] += apr*(dd.lt - nd.lam[0]); nd.lam[1] += apr*(dd.lb - nd.lam[1]);
+            }
+        }
+        double v[1] = {clamp ? 1.0 : 0.0};
+        block_reduce<1>(v, OpMax(), c);
+        if (uni(v[0]) != 0.0) {
+            /* (every index a compile-time constant: a run-time index into the nodes' fields would move the whole iterate into scratch memory) */
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                NodeT &nd = n[j];
+                if (!nd.node()) continue;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if (!nd.on(k)) continue;
+                    nd.zL[k] = sigma_clamp(nd.zL[k], mu_, nd.x[k] - lbv(k));
+                    if (hasU(k)) nd.zU[k] = sigma_clamp(nd.zU[k], mu_, ubv(j, k) - nd.x[k]);
+                }
+                if (!nd.ival()) continue;
+#pragma unroll
+                for (int r_ = 0; r_ < NR; r_++) {
+                    nd.zLs[r_] = sigma_clamp(nd.zLs[r_], mu_, nd.sg[r_] - U.dL[r_]);
+                    if (r_ <= RACC) nd.zUs[r_] = sigma_clamp(nd.zUs[r_], mu_, U.dU[r_] - nd.sg[r_]);
+                }
+            }
+        }
+    }
+
+    /* one solve; startKind: MSD_START_* (ignored with an external guess); returns the status, iters_out = iterations spent.
+     * FL: the fused iteration of the FAST kernels (no least-squares multiplier estimate: profile start or primal-dual warm start only);
+     * it returns STATUS_GENERAL when something rare asks for the general iteration, and the caller solves the scenario again with FL = false */
+    static constexpr int STATUS_GENERAL = -100;
+    template <bool FL>
     __device__ __forceinline__ int run(const double *scen, const double *guess, const double *dual_in, int startKind, int iter_offset, int &iters_out,
                                        double *z_out, double *lam_out, double *dual_out, double *stats, double *hist, int hist_cap)
     {
@@ -2239,7 +2736,7 @@ struct Solver {
         u.plo = P.fminPn - K_BOUND_RELAX*fmax(1.0, fabs(P.fminPn)); u.phi = K_BOUND_RELAX;
         u.slo = -K_BOUND_RELAX;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { u.rowOn[r] = false; u.dL[r] = -INFINITY; u.dU[r] = INFINITY; u.rs[r] = 1.0; u.rL[r] = u.rU[r] = false; }
+        for (int r = 0; r < NR; r++) { u.rowOn[r] = false; u.dL[r] = -INFINITY; u.dU[r] = INFINITY; u.rs[r] = 1.0; u.irs[r] = 1.0; u.rL[r] = u.rU[r] = false; }
         if (hasPower()) { u.rowOn[RPW0] = u.rowOn[RPW1] = true; u.dL[RPW0] = u.dL[RPW1] = -fabs(P.pwL); u.dU[RPW0] = u.dU[RPW1] = fabs(P.pwU); }
         u.rowOn[RACC] = true; u.dL[RACC] = P.accMin; u.dU[RACC] = P.accMax;
         if (energyOpt()) { u.rowOn[RLTR] = u.rowOn[RLRG] = true; u.dL[RLTR] = u.dL[RLRG] = 0; }
@@ -2290,7 +2787,7 @@ struct Solver {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             if (!u.rowOn[r]) continue;
-            u.dL[r] *= u.rs[r]; u.dU[r] *= u.rs[r];
+            u.dL[r] *= u.rs[r]; u.dU[r] *= u.rs[r]; u.irs[r] = 1.0/u.rs[r];
             u.rL[r] = isfinite(u.dL[r]); u.rU[r] = isfinite(u.dU[r]);
             if (u.rL[r]) u.dL[r] -= K_BOUND_RELAX*fmax(1.0, fabs(u.dL[r]));
             if (u.rU[r]) u.dU[r] += K_BOUND_RELAX*fmax(1.0, fabs(u.dU[r]));
@@ -2343,6 +2840,7 @@ struct Solver {
         double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
+        if constexpr (!FL)
         if (!dualStart)
 #if MSD_PROFILE_SKIP_LSQ
         if (ext || startKind != MSD_START_PROFILE)
@@ -2384,10 +2882,24 @@ struct Solver {
 
         for (iter = 0;; iter++) {
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
-            if (iter > 0) evaluate_current();
-            c.mark(PH_EVAL); phase_fence(PH_EVAL);
-            kkt_pass(E);
-            c.mark(PH_KKT); phase_fence(PH_KKT);
+            double h0[SPT][HV], h1[SPT][HV];
+            if constexpr (FL) {
+                if (iter == 0) {
+                    double xc[SPT][NV];
+#pragma unroll
+                    for (int j = 0; j < SPT; j++)
+#pragma unroll
+                        for (int k = 0; k < NV; k++) xc[j][k] = n[j].x[k];
+                    publish_fast(xc);
+                }
+                fused_pass(iter == 0, E, h0, h1);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
+                c.mark(PH_KKT); phase_fence(PH_KKT);
+            } else {
+                if (iter > 0) evaluate_current();
+                c.mark(PH_EVAL); phase_fence(PH_EVAL);
+                kkt_pass(E);
+                c.mark(PH_KKT); phase_fence(PH_KKT);
+            }
             objv = E.obj/U.sf;
             if (iter == 0) { theta_max = 1e4*fmax(1.0, E.theta); theta_min = 1e-4*fmax(1.0, E.theta); }
             if (hist && c.tid == 0 && iter < hist_cap) {
@@ -2413,6 +2925,61 @@ struct Solver {
                 if (changed) nfilt = 0;
             }
             const double theta = E.theta, phi = E.obj - mu*E.L + K_D*mu*E.D;
+
+            if constexpr (FL) {
+                c.mark(PH_OTHER); phase_fence(PH_OTHER);
+                finish_blocks(h0, h1, mu);
+                c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
+                const int par = ParallelRiccati<SPT, DYN>::solve(P.N, true, c);
+                c.red_slot++;
+                c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
+                if (par != 1) { status = STATUS_GENERAL; break; }      /* wrong inertia or scan breakdown (never seen on the benchmark batches) */
+                double gphid, amax;
+                bool tiny_step;
+                post_direction(mu, tau, gphid, dnorm, tiny_step, amax, alpha_du);
+                c.mark(PH_GPHID); phase_fence(PH_GPHID);
+                if (tiny_step) { status = STATUS_GENERAL; break; }
+                tiny_count = 0;
+                double amin = G_THETA;
+                if (gphid < 0) {
+                    amin = fmin(amin, G_PHI*theta/(-gphid));
+                    if (theta <= theta_min) amin = fmin(amin, K_DELTA*hpow(theta, S_THETA)/hpow(-gphid, S_PHI));
+                }
+                amin *= ALPHA_MIN_FRAC;
+                double alpha = amax;
+                bool accepted = false, ftype_armijo = false, general = false;
+                Err T = E;
+                for (int ls = 0;; ls++) {
+                    double ph_t; bool okt;
+                    merit_fast(alpha, mu, T, ph_t, okt);
+                    bool ftype = false;
+                    if (gphid < 0) {
+                        double lhs = alpha*hpow(-gphid, S_PHI), rhs = K_DELTA*hpow(theta, S_THETA);
+                        if (fabs(lhs - rhs) <= 1e-4*fmax(lhs, rhs)) { lhs = alpha*pow(-gphid, S_PHI); rhs = K_DELTA*pow(theta, S_THETA); }
+                        ftype = lhs > rhs;
+                    }
+                    if (acceptable(okt, T.theta, ph_t, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
+                        accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
+                        break;
+                    }
+                    if (ls == 0 && okt && T.theta >= theta) { general = true; break; }      /* second-order correction: general path */
+                    alpha *= 0.5; n_back++;
+                    if (alpha < amin) break;
+                }
+                if (general) { status = STATUS_GENERAL; break; }
+                if (!accepted) { status = MSD_STATUS_LINESEARCH; break; }
+                alpha_pr = alpha;
+                c.mark(PH_MERIT); phase_fence(PH_MERIT);
+                if (!ftype_armijo && nfilt < FILT_CAP) {      /* filter augmentation (W&B eq. (22)) */
+                    __syncthreads();
+                    if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; }
+                    nfilt++;
+                    __syncthreads();
+                }
+                update_fast(alpha_pr, alpha_du, mu);
+                E.theta = T.theta; E.L = T.L; E.D = T.D; E.obj = T.obj;
+                c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
+            } else {
 
             /* search direction with inertia correction (W&B Algorithm IC); one call site */
             double dw = 0;
@@ -2617,7 +3184,9 @@ struct Solver {
                 }
             }
             c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
+            }      /* (general iteration) */
         }
+        if (FL && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path solves the scenario */
 
         /* ---- the multipliers for a later primal-dual warm start ---- */
         if (dual_out) {
@@ -2696,8 +3265,12 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     }
     c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
-    if (!STREAM) c.filt = c.o3 + NS;
-    c.red = c.filt + 2*FILT_CAP; c.misc = c.red + RED_SLOTS*MAX_WAVES*RED_K;
+    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL>;
+    constexpr bool FASTK = SolverT::FAST;
+    c.xs = c.o4 = c.o5 = c.o6 = c.o7 = nullptr;
+    if (FASTK) { c.xs = c.o3 + NS; c.o4 = c.xs + NS; c.o5 = c.o4 + NS; c.o6 = c.o5 + NS; c.o7 = c.o6 + NS; }
+    if (!STREAM) c.filt = c.o3 + NS + (FASTK ? (XCH_FAST - XCH_GENERAL)*NS : 0);
+    c.red = c.filt + 2*FILT_CAP; c.misc = c.red + ((FASTK && NT == 64) ? 0 : RED_DOUBLES);      /* (a single wave reduces in registers) */
     /* the problem record and the scenario's uniform data live in LDS: phases read what they need (broadcast reads) instead of
      * carrying some eighty uniform values through the whole solve in registers */
     DevProb *Pl = reinterpret_cast<DevProb *>(c.misc + 32);
@@ -2729,7 +3302,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         __syncthreads();
         if (c.tid == 0) *Pl = Ps;
         __syncthreads();
-        Solver<NT, SPT, DYN, STREAM, GEN, FULL> s(*Pl, c, wg_work, *Ul);
+        SolverT s(*Pl, c, wg_work, *Ul);
         const double *guess = P.guess ? P.guess + (size_t)P.guessStride*sidx : nullptr;
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
         const double *dual_in = (guess && P.dualIn) ? P.dualIn + (size_t)P.dualInStride*sidx + (size_t)MSD_DUAL_STRIDE*P.dualShift : nullptr;
@@ -2739,9 +3312,19 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             int iters = 0;
-            const int st = s.run(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
-                                 lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                 (hist && sidx == 0) ? hist : nullptr, hist_cap);
+            int st = SolverT::STATUS_GENERAL;
+            if constexpr (FASTK) {
+                /* the fused iteration needs no least-squares multiplier estimate: profile start or primal-dual warm start */
+                if ((guess && dual_in) || (!guess && startKind == MSD_START_PROFILE))
+                    st = s.template run<true>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                              lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
+                                              (hist && sidx == 0) ? hist : nullptr, hist_cap);
+                __syncthreads();
+            }
+            if (st == SolverT::STATUS_GENERAL)
+                st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                           lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
+                                           (hist && sidx == 0) ? hist : nullptr, hist_cap);
             __syncthreads();
             if (st >= 0 || st == MSD_STATUS_MAXITER) break;
             spent = iters;
