@@ -201,7 +201,13 @@ __device__ __forceinline__ Jet chain(Jet a, double F, double f1, double f2)
 {
     return {F, f1*a.g0, f1*a.g1, f1*a.h00 + f2*a.g0*a.g0, f1*a.h01 + f2*a.g0*a.g1, f1*a.h11 + f2*a.g1*a.g1};
 }
-__device__ __forceinline__ Jet xsqrt(Jet a) { double s = sqrt(a.v); return chain(a, s, 0.5/s, -0.25/(a.v*s)); }
+/* sqrt and its two derivatives from one reciprocal square root: 1/(2 sqrt(v)) = r/2, -1/(4 v sqrt(v)) = -r^3/4 */
+#ifdef MSD_HOST_EMULATION
+__device__ __forceinline__ double rsqrt_(double v) { return 1.0/sqrt(v); }
+#else
+__device__ __forceinline__ double rsqrt_(double v) { return rsqrt(v); }
+#endif
+__device__ __forceinline__ Jet xsqrt(Jet a) { const double r = rsqrt_(a.v), f1 = 0.5*r; return chain(a, a.v*r, f1, -0.5*f1*(r*r)); }
 __device__ __forceinline__ Jet xrecip(Jet a) { double r = 1.0/a.v; return chain(a, r, -r*r, 2*r*r*r); }
 __device__ __forceinline__ double xsqrt(double a) { return sqrt(a); }
 __device__ __forceinline__ double xrecip(double a) { return 1.0/a; }
@@ -2250,7 +2256,7 @@ struct Solver {
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;      /* (nlam, nz: MERIT passes only) */
         double th = 0, damp = 0, obj = 0;
         LogSum lsum;
-        double gl[SPT][NV], Hbb_[SPT], Hbq_[SPT];
+        double gl[SPT][NV], Hbb_[SPT], Hbq_[SPT], resd[SPT][NR];      /* (resd: local, not the general path's field) */
         const double sc = U.sf/P.objDen;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
@@ -2415,6 +2421,14 @@ struct Solver {
 #pragma unroll
             for (int k = 0; k < NV; k++) if (nd.on(k)) dual = fmax(dual, fabs(gl[j][k]));
         }
+        /* the row residuals wait for post_direction in five exchange arrays that are free until the next pass: not in registers
+         * across the KKT solve */
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int i = n[j].i;
+            c.o1[i] = resd[j][RPW0]; c.o2[i] = resd[j][RPW1]; c.o3[i] = resd[j][RACC]; c.o4[i] = resd[j][RLTR]; c.o6[i] = resd[j][RLRG];
+        }
         double vm[5] = {dual, prim, prim_u, cmax, -cmin};
         block_reduce<5>(vm, OpMax(), c);
         E.dual = uni(vm[0]); E.primal = uni(vm[1]); E.primal_u = uni(vm[2]); E.cmax = uni(vm[3]); E.cmin = -uni(vm[4]);
@@ -2477,11 +2491,11 @@ struct Solver {
                 const double isb = 1.0/sb, isb1 = 1.0/sb1;
                 const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
                 const double db1 = c.S[(i + 1)*S_STRIDE + S_DB];
-                nd.dsg[RPW0] = resd[j][RPW0] + (g.g0b*d.dx[VB] + g.g0f*d.dx[VF]);
-                nd.dsg[RPW1] = resd[j][RPW1] + (g.g1f*d.dx[VF] + g.g1b1*db1);
-                nd.dsg[RACC] = resd[j][RACC] + (g.g2b*d.dx[VB] + g.g2f*d.dx[VF] + g.g2f*d.dx[VP]);
-                nd.dsg[RLTR] = resd[j][RLTR] + (g.g3f*d.dx[VF] + g.g3s*d.dx[VS]);
-                nd.dsg[RLRG] = resd[j][RLRG] + (g.g4f*d.dx[VF] + g.g4s*d.dx[VS]);
+                nd.dsg[RPW0] = c.o1[i] + (g.g0b*d.dx[VB] + g.g0f*d.dx[VF]);      /* (residuals: fused_pass left them in the exchange arrays) */
+                nd.dsg[RPW1] = c.o2[i] + (g.g1f*d.dx[VF] + g.g1b1*db1);
+                nd.dsg[RACC] = c.o3[i] + (g.g2b*d.dx[VB] + g.g2f*d.dx[VF] + g.g2f*d.dx[VP]);
+                nd.dsg[RLTR] = c.o4[i] + (g.g3f*d.dx[VF] + g.g3s*d.dx[VS]);
+                nd.dsg[RLRG] = c.o6[i] + (g.g4f*d.dx[VF] + g.g4s*d.dx[VS]);
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) {
