@@ -14,10 +14,16 @@ barrier and the max over ranks (weak scaling, no collective on the data path).  
 RANK in the environment starts the N ranks itself (torch.distributed.run as a child process, before anything touches the GPU);
 under an external launcher (RANK set) it is one of the ranks.
 
+`--single-process` drives the N devices from one process instead (one handle and one stream per device, SURVEY 8b `devices[]`,
+no torch.distributed): the other dispatch style of SURVEY 8e, same sharding.
+
 Prints ONE JSON line on rank 0.  `roofline` prices the solve kernel with the streaming model S of SURVEY.md section 8d
-(904 B per stage-iteration); `cpu_baseline` times the CPU oracle (a port, not the reference's CasADi/IPOPT, which cannot run
-here) on the host cores and on one thread; `alt` (N = 1 only) carries the other workloads of SURVEY 8(d): the reference's
-starting point on config 1, config 2, config 3 and config 4 at their per-GPU sizes.
+(904 B per stage-iteration) as the contract prescribes, and says next to it what the counters say: the compulsory bytes, the bytes
+the TCC counters saw (profiles/hbm_traffic.json, per workload, digest-checked against the running library) and what really bounds
+the kernel (`limiter`: the double-precision issue rate and exposed latency of one wave per SIMD).  `cpu_baseline` times the CPU
+oracle (a port, not the reference's CasADi/IPOPT, which cannot run here) on the host cores and on one thread; `alt` (N = 1 only)
+carries the other workloads of SURVEY 8(d): the reference's starting point on config 1, configs 2-4 at their per-GPU sizes, the
+other transcriptions.  `--workload c4` measures the shrinking-horizon loop itself (a step = 50 re-solves of every scenario).
 """
 
 import argparse
@@ -38,6 +44,13 @@ for p in (str(ROOT / 'ms-eetc_amd'), str(ROOT)):
 BYTES_PER_STAGE_ITER = 904.0   # SURVEY.md section 8d, streaming model S (nu = 2): 113 doubles
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector double precision = half of the 157.3 TFLOPS FP32 vector spec of MI355X_MICROARCH.md (~78 TF/s); secondary bound
+
+
+# the other transcriptions of the reference's options (ocp.py:26-28, train.py:303-322): solver options, integrator options
+TRANSCRIPTIONS = dict(rk=(dict(), None),
+                      integrate_losses=(dict(integrateLosses=True), dict(order=4, numSteps=1, numApproxSteps=1)),
+                      irk_radau2=(dict(integrationMethod='IRK'), dict(order=2, numSteps=1, numApproxSteps=1)),
+                      cvodes_tolerances=(dict(integrationMethod='CVODES'), dict()))
 
 
 def usable_cores():
@@ -73,8 +86,13 @@ def parse_args(argv=None):
     ap.add_argument('--no-build', action='store_true', help='never compile (profiled runs): exit non-zero when the library is stale')
     ap.add_argument('--start', default='profile', choices=['profile', 'reference'],
                     help="starting point of every solve: 'profile' (library default, built on the device from the scenario) or 'reference' (cold start of ocp.py:325-339)")
-    ap.add_argument('--workload', default='c1', choices=['c1', 'c2', 'c3'],
-                    help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil; c3: config 1 with per-scenario rolling stock')
+    ap.add_argument('--workload', default='c1', choices=['c1', 'c2', 'c3', 'c4'],
+                    help='c1: BASELINE configs[1] (the metric); c2: N=200 on CH_StGallen_Wil; c3: config 1 with per-scenario rolling stock; '
+                         'c4: shrinking-horizon MPC, 50 re-solves per scenario (a step = one whole loop, value = successful re-solves/s)')
+    ap.add_argument('--transcription', default='rk', choices=sorted(TRANSCRIPTIONS),
+                    help='the transcription of the reference\'s options the workload is solved with (default: RK4 + trapezoidal time, simulations/config.json)')
+    ap.add_argument('--single-process', action='store_true',
+                    help='one process drives all --gpus devices (one handle and stream per device), no torch.distributed')
     return ap.parse_args(argv)
 
 
@@ -99,7 +117,7 @@ def launch_ranks(args):
     return subprocess.call(rank_command(sys.argv[1:], args.gpus, free_port()), env=env)
 
 
-PER_GPU_BATCH = dict(c1=1024, c2=8192, c3=8192)
+PER_GPU_BATCH = dict(c1=1024, c2=8192, c3=8192, c4=512)
 
 
 def measure(solver, scen, overrides, steps, warmup, barrier=None):
@@ -146,7 +164,7 @@ def measure(solver, scen, overrides, steps, warmup, barrier=None):
     return elapsed, kernel_ms_total/steps, st
 
 
-def build_workload(name, B, N, rank, start, device):
+def build_workload(name, B, N, rank, start, device, transcription='rk'):
     "(solver, scenarios (B,4), overrides or None, description)"
 
     from mseetc import workloads as wl
@@ -154,7 +172,11 @@ def build_workload(name, B, N, rank, start, device):
 
     train, track, N0 = wl.config(name)
     N = N or N0
-    solver = casadiSolver(train, track, wl.options(N), device=device, startingPoint=start)
+    extra, io = TRANSCRIPTIONS[transcription]
+    opts = wl.options(N, **extra)
+    if io is not None:
+        opts['integrationOptions'] = dict(io)
+    solver = casadiSolver(train, track, opts, device=device, startingPoint=start)
     overrides = None
 
     if name == 'c1':
@@ -168,7 +190,89 @@ def build_workload(name, B, N, rank, start, device):
         overrides = solver._overrides(B, pert['mass'], pert['r0'], pert['r1'], pert['r2'])
         text = "config 3: B={} scenarios per GPU, N={}, as config 1 (seed 20260614+rank) with mass, r0, r1, r2 perturbed per scenario by 5 % (clipped normal)".format(B, N)
 
+    if transcription != 'rk':
+        text += ", transcription {} {}".format(extra, io)
+
     return solver, solver._scenarios(T, 0, 1, 1), overrides, text
+
+
+def measure_single_process(solver, scen, overrides, steps, warmup, ndev):
+    """
+    The other dispatch style of SURVEY 8e: this process drives `ndev` devices, one handle and one stream each, the batch of
+    every device resident in its HBM.  Returns (elapsed s, worst kernel ms per launch, stats of all devices stacked).
+    """
+
+    import numpy as np
+    from mseetc._device import ST, OV
+
+    first, others = solver._handles(list(range(ndev)))
+    probs = [first] + list(others)
+    B = scen.shape[0]
+    bufs = []
+    for k, prob in enumerate(probs):
+        # weak scaling: every device solves a batch of the per-GPU size (its own seed would only change the numbers, not the work)
+        d_scen, d_z, d_st = prob.alloc(scen.nbytes), prob.alloc(8*prob.nz*B), prob.alloc(8*ST['COUNT']*B)
+        prob.to_device(d_scen, scen)
+        d_ov = None
+        if overrides is not None:
+            ov = np.ascontiguousarray(overrides, dtype=np.float64).reshape(B, OV['COUNT'])
+            d_ov = prob.alloc(ov.nbytes)
+            prob.to_device(d_ov, ov)
+        bufs.append((d_scen, d_z, d_st, d_ov))
+    for _ in range(warmup):
+        for prob, (d_scen, d_z, d_st, d_ov) in zip(probs, bufs):
+            prob.solve_batch_device(B, d_scen, d_z, None, d_st, d_overrides=d_ov)
+    for prob in probs:
+        prob.synchronize()
+    t0 = time.perf_counter()
+    for prob in probs:
+        prob.timer_begin()
+    for _ in range(steps):
+        for prob, (d_scen, d_z, d_st, d_ov) in zip(probs, bufs):      # launches return at once: the devices run side by side
+            prob.solve_batch_device(B, d_scen, d_z, None, d_st, d_overrides=d_ov)
+    ms = [prob.timer_end() for prob in probs]
+    for prob in probs:
+        prob.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = np.zeros((len(probs), B, ST['COUNT']))
+    for k, (prob, b) in enumerate(zip(probs, bufs)):
+        prob.to_host(st[k], b[2])
+        for d in b:
+            if d is not None:
+                prob.free(d)
+    return elapsed, max(ms)/steps, st.reshape(-1, ST['COUNT'])
+
+
+def measure_mpc(train, track, N, T, steps, warmup, device, warm=True, barrier=None):
+    """
+    Config 4: `steps` shrinking-horizon loops (50 re-solves of every scenario each, stride 2 intervals, 1 % measurement noise).
+    Returns (elapsed s, dict of loop statistics of the last loop).
+    """
+
+    import numpy as np
+    from mseetc import workloads as wl
+    from mseetc.mpc import shrinkingHorizon
+
+    run = lambda: shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm, device=device)
+    for _ in range(max(1, warmup) if warmup else 0):
+        shrinkingHorizon(train, track, wl.options(N), T[:64], numResolves=2, noise=0.01, seed=1, warmStart=warm, device=device)
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    good = failed = relaxed = 0
+    for _ in range(steps):
+        log = run()
+        good += int(sum(int((l['status'] >= 0).sum()) for l in log))
+        failed += int(sum(int((l['status'] < 0).sum()) for l in log))
+        relaxed += int(sum(int(l['relaxed'].sum()) for l in log))
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    stage_iters = float(sum(l['numIntervals']*l['iterations'].sum() for l in log))
+    info = {"resolves_per_loop": len(log), "scenarios": len(T), "successful": good, "failed": failed, "arrival_time_relaxed": relaxed,
+            "ip_iterations_mean": float(np.mean([l['iterations'].mean() for l in log])),
+            "kernel_ms_per_loop": float(sum(l['kernel_ms'] for l in log)), "stage_iterations_per_loop": stage_iters}
+    return elapsed, info
 
 
 def summarize(B, N, steps, elapsed, launch_ms, st):
@@ -180,19 +284,49 @@ def summarize(B, N, steps, elapsed, launch_ms, st):
             "kkt_fallbacks": int(np.sum(st[:, ST['N_FALLBACK']]))}
 
 
-def hbm_traffic(entry):
-    "Measured HBM bytes per launch of the headline kernel, if the committed measurement belongs to the library that is running."
+def hbm_traffic(entry, key):
+    """
+    Measured HBM bytes per launch of workload `key` ('c1', 'c2', 'c3', 'c1/integrate_losses' ...), if the committed measurement
+    belongs to the library that is running: (record or None, note).
+    """
 
     tf = ROOT / 'profiles' / 'hbm_traffic.json'
     if not tf.exists():
-        return None, "no profiles/hbm_traffic.json", None
+        return None, "no profiles/hbm_traffic.json"
     try:
         rec = json.loads(tf.read_text())
     except Exception:
-        return None, "unreadable profiles/hbm_traffic.json", None
+        return None, "unreadable profiles/hbm_traffic.json"
     if rec.get('kernel_digest') != entry.hip_digest():
-        return None, "profiles/hbm_traffic.json was measured on another build of the kernel (digest mismatch): re-run tools/profile_round.sh", None
-    return rec.get('bytes_per_launch'), rec.get('source'), rec.get('issue')
+        return None, "profiles/hbm_traffic.json was measured on another build of the kernels (digest mismatch): re-run tools/profile_round.sh"
+    w = rec.get('workloads', {}).get(key)
+    if w is None:
+        return None, "profiles/hbm_traffic.json has no entry for workload " + key
+    return w, rec.get('source')
+
+
+def roofline_block(entry, key, B, N, nz, stage_iters, launch_ms, geo):
+    "The roofline object of the bench line for one launch of the solve kernel over B scenarios (stage_iters = N x sum of IP iterations)."
+
+    achieved = BYTES_PER_STAGE_ITER*stage_iters/(launch_ms*1e-3)/1e9
+    compulsory = float(B*(8*nz + 168))
+    rec, note = hbm_traffic(entry, key)
+    traffic = rec.get('bytes_per_launch') if rec else None
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_source": note,
+           "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d streaming model; frac = frac_model_S).  The iterate is LDS/register "
+                    "resident: the kernel never generates that traffic, so `bound: hbm` is the contract's pricing, not the limiter",
+           "frac_model_S": achieved/HBM_PEAK_GBS,
+           "frac_compulsory": compulsory/(launch_ms*1e-3)/1e9/HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory,
+           "frac_measured": (traffic/(launch_ms*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
+           "limiter": "fp64 VALU issue + exposed LDS/scratch latency of one wave per SIMD (SQ counters: `issue`), not HBM",
+           "kernel": "msd::solve_kernel<{},{}> (one workgroup of {} threads per scenario, {} shooting nodes per lane)".format(geo[0], geo[1], geo[0], geo[1]),
+           "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters,
+           "issue": rec.get('issue') if rec else None, "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+           "fp64_valu_frac_model": (400.0*stage_iters/(launch_ms*1e-3)/1e12)/FP64_VALU_PEAK_TFLOPS}
+    if rec and rec.get('issue'):
+        out["valu_instructions_per_stage_iteration"] = rec['issue'].get('valu_instructions_per_launch', 0)/max(rec.get('stage_iterations_per_launch', stage_iters), 1.0)
+    return out
 
 
 def main():
@@ -220,16 +354,19 @@ def main():
 
     if ndev < max(1, args.gpus) and not child and not (share and ndev >= 1):
         print("bench.py: {} HIP device(s) visible, {} requested -- nothing to measure here (the solver has no CPU fallback)".format(ndev, args.gpus), file=sys.stderr)
-        return 0
+        return 2      # not a success: no JSON line was produced
 
-    if args.gpus > 1 and not child:
+    if args.gpus > 1 and not child and not args.single_process:
         return launch_ranks(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
 
-    if world != args.gpus:
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("--single-process runs as one process (no launcher)")
+    elif world != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
 
     import numpy as np
@@ -245,7 +382,16 @@ def main():
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            except Exception as exc:
+                # the data path has no collective: RCCL only carries the barrier and two reductions, gloo does the same job
+                print("bench.py: RCCL process group failed on rank {} ({}: {}); falling back to gloo for the barrier and the reductions"
+                      .format(rank, type(exc).__name__, exc), file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+                red_dev = 'cpu'
 
     def barrier(sync_only=False):
         torch.cuda.synchronize()
@@ -256,10 +402,56 @@ def main():
     from mseetc._device import ST
 
     B = args.batch or PER_GPU_BATCH[args.workload]
-    solver, scen, overrides, text = build_workload(args.workload, B, args.intervals, rank, args.start, local_rank)
+    ndrive = args.gpus if args.single_process else 1      # devices this process drives
+
+    if args.workload == 'c4':
+        # the shrinking-horizon loop: a step = 50 re-solves of every scenario (warm-started on the device), value = successful re-solves/s
+        from mseetc import workloads as wl
+        train, track, N = wl.config('c4')
+        N = args.intervals or N
+        T = wl.c1_times(B, seed=20260615 + rank)
+        elapsed, info = measure_mpc(train, track, N, T, args.steps, args.warmup, local_rank, warm=True, barrier=barrier)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            cnt = torch.tensor([info['successful'], info['failed']], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            good_all, failed_all = int(cnt[0].item()), int(cnt[1].item())
+        else:
+            good_all, failed_all = info['successful'], info['failed']
+        if rank == 0:
+            from mseetc.ocp import casadiSolver
+            probe = casadiSolver(train, track, wl.options(N), device=local_rank)
+            geo, nz = probe.problem.geometry(), probe.problem.nz
+            probe.close()
+            launch_ms = info['kernel_ms_per_loop']
+            line = {
+                "metric": "OCP solves/sec (N=100, VIRM6, var-speed-limit track)",
+                "value": good_all/elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "config 4: {} scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals from N={}, 1 % measurement noise on t and v, "
+                                       "seed 20260615+rank), warm-started from the previous solution and multipliers on the device; value counts successful re-solves only; "
+                                       "wall time of the host loop including grids, transfers and re-configuration".format(B, N),
+                           "batch_per_gpu": B, "num_intervals": N, "resolves_failed": failed_all, "resolves_successful": good_all,
+                           "arrival_time_relaxed": info['arrival_time_relaxed'], "ip_iterations_mean": info['ip_iterations_mean'],
+                           "parallelism": "scenarios sharded, no collective"},
+                "roofline": roofline_block(entry, 'c4', B*info['resolves_per_loop'], N, nz, info['stage_iterations_per_loop'], launch_ms, geo),
+            }
+            line["roofline"]["launch_ms_note"] = "sum of the kernel times of the loop's launches (one per re-solve, shrinking horizons)"
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    solver, scen, overrides, text = build_workload(args.workload, B, args.intervals, rank, args.start, local_rank, args.transcription)
     N = solver.numIntervals
 
-    elapsed, launch_ms, st = measure(solver, scen, overrides, args.steps, args.warmup, barrier)
+    if args.single_process:
+        elapsed, launch_ms, st = measure_single_process(solver, scen, overrides, args.steps, args.warmup, ndrive)
+    else:
+        elapsed, launch_ms, st = measure(solver, scen, overrides, args.steps, args.warmup, barrier)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -278,43 +470,37 @@ def main():
 
     if rank == 0:
 
-        total_solves = B*world*args.steps
+        ngpu = world*ndrive
+        total_solves = B*ngpu*args.steps
         value = total_solves/elapsed
 
-        stage_iters = float(N*np.sum(iters))                 # units one launch processes (this rank)
-        achieved = BYTES_PER_STAGE_ITER*stage_iters/(launch_ms*1e-3)/1e9
-        traffic, traffic_source, issue = hbm_traffic(entry)
+        stage_iters = float(N*np.sum(iters))/ndrive          # units one launch processes (one device)
         geo = solver.problem.geometry()
+        key = args.workload + ('' if args.transcription == 'rk' else '/' + args.transcription) + ('' if args.start == 'profile' else '/reference_start')
 
         start_text = ("every solve starts from the device-built speed profile (no information from earlier solves; same optimum as the reference's cold start)"
                       if args.start == 'profile' else "every solve cold-starts from the reference's point (ocp.py:325-339)")
 
         line = {
             "metric": "OCP solves/sec (N=100, VIRM6, var-speed-limit track)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "solves/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": text + ", " + start_text + ", KKT<=1e-8",
-                       "batch_per_gpu": B, "num_intervals": N, "start": args.start, "converged": n_ok_all, "scenarios": B*world,
+                       "batch_per_gpu": B, "num_intervals": N, "start": args.start, "converged": n_ok_all, "scenarios": B*ngpu,
                        "kkt_fallbacks": int(np.sum(st[:, ST['N_FALLBACK']])), "cycles_per_solve_mean": float(np.mean(st[:, ST['CYC_TOTAL']])),
-                       "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)), "parallelism": "scenarios sharded, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d); iterate is LDS/register resident, so real HBM traffic is far below S",
-                         "kernel": "msd::solve_kernel<{},{}> (one workgroup of {} threads per scenario, {} shooting nodes per lane)".format(geo[0], geo[1], geo[0], geo[1]),
-                         "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters,
-                         # what bounds the kernel in practice (SQ counters of the profiling pass, same digest rule as `traffic`): a latency-bound
-                         # double-precision instruction stream, one wave per SIMD
-                         "issue": issue, "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                         "fp64_valu_frac_model": (400.0*stage_iters/(launch_ms*1e-3)/1e12)/FP64_VALU_PEAK_TFLOPS},
+                       "ip_iterations_mean": float(np.mean(iters)), "ip_iterations_max": float(np.max(iters)),
+                       "dispatch": "one process, {} device handle(s)".format(ndrive) if args.single_process else "one process per GPU",
+                       "parallelism": "scenarios sharded, no collective"},
+            "roofline": roofline_block(entry, key, B, N, solver.problem.nz, stage_iters, launch_ms, geo),
         }
 
         solver.close()
 
-        if world == 1 and not args.no_alt and args.workload == 'c1':
+        if world == 1 and not args.single_process and not args.no_alt and args.workload == 'c1' and args.transcription == 'rk':
             line["alt"] = alt_workloads(args, local_rank)
 
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.single_process and args.transcription == 'rk':
             line["cpu_baseline"] = cpu_baseline(solver, scen, args.start, overrides is not None)
 
         print(json.dumps(line), flush=True)
@@ -326,57 +512,42 @@ def main():
 
 
 def alt_workloads(args, device):
-    "The other workloads of SURVEY 8(d) at their per-GPU sizes, a few launches each (N = 1 runs only)."
+    "The other workloads of SURVEY 8(d) at their per-GPU sizes, ten timed launches each after two warm-ups (N = 1 runs only)."
 
     import numpy as np
     from mseetc import workloads as wl
-    from mseetc.mpc import shrinkingHorizon
 
     alt = {}
-    k = max(3, args.steps//4)
-    solver, scen, ov, text = build_workload('c1', PER_GPU_BATCH['c1'], 0, 0, 'reference', device)
-    e, ms, st = measure(solver, scen, ov, k, 1)
-    alt["reference_start"] = dict(summarize(scen.shape[0], solver.numIntervals, k, e, ms, st), workload=text + ", cold start of ocp.py:325-339")
-    solver.close()
+    k, w = 10, 2
 
-    solver, scen, ov, text = build_workload('c1', 8192, 0, 0, 'profile', device)
-    e, ms, st = measure(solver, scen, ov, 3, 1)
-    alt["c1_batch8192"] = dict(summarize(scen.shape[0], solver.numIntervals, 3, e, ms, st), workload=text)
-    solver.close()
-
-    for name in ('c2', 'c3'):
-        solver, scen, ov, text = build_workload(name, PER_GPU_BATCH[name], 0, 0, 'profile', device)
-        e, ms, st = measure(solver, scen, ov, 3, 1)
-        alt[name] = dict(summarize(scen.shape[0], solver.numIntervals, 3, e, ms, st), workload=text)
+    def one(name, workload, B, start='profile', transcription='rk', note=''):
+        solver, scen, ov, text = build_workload(workload, B, 0, 0, start, device, transcription)
+        e, ms, st = measure(solver, scen, ov, k, w)
+        alt[name] = dict(summarize(scen.shape[0], solver.numIntervals, k, e, ms, st), workload=text + note)
         solver.close()
 
-    # the other transcriptions of the reference's options on the config-1 batch (their own kernel instantiations, not tuned)
-    from mseetc.ocp import casadiSolver
-    train, track, N = wl.config('c1')
-    T = wl.c1_times(PER_GPU_BATCH['c1'], seed=20260612)
-    for name, extra, io in (("integrate_losses", dict(integrateLosses=True), dict(numSteps=1, numApproxSteps=1)),
-                            ("irk_radau2", dict(integrationMethod='IRK'), dict(order=2, numSteps=1, numApproxSteps=1)),
-                            ("cvodes_tolerances", dict(integrationMethod='CVODES'), dict())):
-        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationOptions=io, **extra), device=device, startingPoint='profile')
-        scen = solver._scenarios(T, 0, 1, 1)
-        e, ms, st = measure(solver, scen, None, 3, 1)
-        alt[name] = dict(summarize(scen.shape[0], N, 3, e, ms, st), workload="config 1 batch with {} {}".format(extra, io))
-        solver.close()
+    one("reference_start", 'c1', PER_GPU_BATCH['c1'], start='reference', note=", cold start of ocp.py:325-339")
+    one("c1_batch8192", 'c1', 8192)
+    one("c2", 'c2', PER_GPU_BATCH['c2'])
+    one("c3", 'c3', PER_GPU_BATCH['c3'])
+    # the other transcriptions of the reference's options on the config-1 batch (their own kernel instantiations)
+    for name in ('integrate_losses', 'irk_radau2', 'cvodes_tolerances'):
+        one(name, 'c1', PER_GPU_BATCH['c1'], transcription=name)
 
     # config 4: shrinking-horizon MPC, 512 scenarios per GPU (4096 over 8), 50 re-solves each: wall time of the whole loop
     train, track, N = wl.config('c4')
-    T = wl.c1_times(512, seed=20260615)
-    shrinkingHorizon(train, track, wl.options(N), T[:64], numResolves=2, noise=0.01, seed=1, device=device)      # warm up
+    T = wl.c1_times(PER_GPU_BATCH['c4'], seed=20260615)
     c4 = {}
     for warm in (False, True):
-        t0 = time.perf_counter()
-        log = shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm, device=device)
-        wall = time.perf_counter() - t0
-        n = sum(len(l['status']) for l in log)
-        c4["warm" if warm else "cold"] = {"resolves_per_s": n/wall, "wall_s": wall, "resolves": len(log), "scenarios": 512,
-                                          "ip_iterations_mean": float(np.mean([l['iterations'].mean() for l in log])),
-                                          "failed": int(sum(int((l['status'] < 0).sum()) for l in log))}
-    c4["workload"] = "config 4: 512 scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals, 1 % measurement noise), wall time of the host loop including transfers"
+        loops = 3
+        wall, info = measure_mpc(train, track, N, T, loops, 1, device, warm=warm)
+        c4["warm" if warm else "cold"] = {"resolves_per_s": info['successful']/wall, "wall_s": wall/loops, "loops": loops, "resolves": info['resolves_per_loop'],
+                                          "scenarios": len(T), "ip_iterations_mean": info['ip_iterations_mean'], "successful": info['successful']//loops,
+                                          "failed": info['failed']//loops, "arrival_time_relaxed": info['arrival_time_relaxed']//loops,
+                                          "kernel_ms_per_loop": info['kernel_ms_per_loop']}
+    c4["workload"] = ("config 4: 512 scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals, 1 % measurement noise), wall time of the host loop "
+                      "including transfers; resolves_per_s counts successful re-solves only; a re-solve whose measured state no longer allows the arrival time "
+                      "is repeated with the arrival time moved to its certified minimum (arrival_time_relaxed)")
     alt["c4"] = c4
     return alt
 

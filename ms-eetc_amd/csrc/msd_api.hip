@@ -165,7 +165,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     /* both brakes, power rows (finite by construction: ocp.py:186-187), energy objective, finite acceleration bounds (ocp.py:113-114) */
     const bool full = d->with_pn_brake != 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                       && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
-    msd::Geometry geo = gen ? msd::pick_geometry_general(N) : intloss ? msd::pick_geometry_intloss(N) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full);
+    msd::Geometry geo = gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full) : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full);
     size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
     if ((gen || intloss) && (!geo.fn || lds > 160*1024))
         return fail(MSD_E_UNSUPPORTED, "numIntervals = " + std::to_string(N) + " with the collocation or adaptive shooting integrator or with integrateLosses does not fit the LDS-resident kernel (the streamed kernel runs 'RK' with the mid-point loss rows)");
@@ -405,9 +405,24 @@ static int check_batch(msd_handle h, int nscen, const double *scen, const double
     return MSD_OK;
 }
 
-/* uploads, launch and downloads of one batch on the handle's stream, nothing waited for: finish_batch() completes it */
+/* the copies of a batch's results into the caller's arrays, on the handle's stream */
+static int enqueue_downloads(msd_handle h, int nscen, double *z_out, double *lam_out, double *stats)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
+    HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));
+    if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
+    if (h->d_hist && h->h_hist && h->hist_cap > 0)
+        HIP_TRY(hipMemcpyAsync(h->h_hist, h->d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
+    return MSD_OK;
+}
+
+/* uploads, launch and (unless deferred) downloads of one batch on the handle's stream, nothing waited for: finish_batch() completes it.
+ * defer_downloads: the caller issues enqueue_downloads() itself -- a copy into pageable host memory holds the calling thread until the
+ * kernel in front of it has finished, so a caller that drives several devices launches on all of them first */
 static int enqueue_batch(msd_handle h, int nscen, const double *scen, const double *overrides, const double *z_guess, double mu_init, double bound_push,
-                         double *z_out, double *lam_out, double *stats, int shift = -1)
+                         double *z_out, double *lam_out, double *stats, int shift = -1, bool defer_downloads = false)
 {
     HIP_TRY(hipSetDevice(h->device));
     const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
@@ -471,12 +486,11 @@ static int enqueue_batch(msd_handle h, int nscen, const double *scen, const doub
     int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap, ws);
     if (rc != MSD_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
-    HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));
-    if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
-    if (d_hist) HIP_TRY(hipMemcpyAsync(h->h_hist, d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
+    if (!d_hist && h->d_hist) { hipFree(h->d_hist); h->d_hist = nullptr; }      /* (enqueue_downloads copies a history only when this launch wrote one) */
     h->prev_nscen = nscen; h->prev_nz = (int)nz; h->prev_stp = 4 + h->P.withPn;
     h->prev_dual_nodes = h->keep_duals ? h->P.N + 1 : 0;
+    (void)nl;
+    if (!defer_downloads) return enqueue_downloads(h, nscen, z_out, lam_out, stats);
     return MSD_OK;
 }
 
@@ -548,8 +562,14 @@ int msd_solve_batch_multi(const msd_handle *handles, int nhandles, int nscen, co
         if (n < 1) continue;
         rc = enqueue_batch(handles[k], n, scen + (size_t)MSD_SC_COUNT*lo[k], overrides ? overrides + (size_t)MSD_OV_COUNT*lo[k] : nullptr,
                            z_guess ? z_guess + nz*lo[k] : nullptr, mu_init, bound_push, z_out + nz*lo[k], lam_out ? lam_out + nl*lo[k] : nullptr,
-                           stats + (size_t)MSD_ST_COUNT*lo[k]);
+                           stats + (size_t)MSD_ST_COUNT*lo[k], -1, true);
         if (rc != MSD_OK) { first_error = rc; first_msg = g_err; } else started[k] = 1;
+    }
+    /* every device is running: now the result copies (each one waits for its own device only) */
+    for (int k = 0; k < nhandles && first_error == MSD_OK; k++) {
+        if (!started[k]) continue;
+        rc = enqueue_downloads(handles[k], lo[k + 1] - lo[k], z_out + nz*lo[k], lam_out ? lam_out + nl*lo[k] : nullptr, stats + (size_t)MSD_ST_COUNT*lo[k]);
+        if (rc != MSD_OK) { first_error = rc; first_msg = g_err; }
     }
     float worst = 0;
     for (int k = 0; k < nhandles; k++) {

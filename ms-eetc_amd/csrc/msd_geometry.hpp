@@ -22,8 +22,10 @@ Geometry pick_geometry_static(int N, bool full);     /* full: both brakes, power
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
-Geometry pick_geometry_general(int N);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
-Geometry pick_geometry_intloss(int N);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
+Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
+Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
+Geometry pick_geometry_general_full(int N);  /* the same two families with the structure of the reference's rolling stock compiled in (msd_kernels_full2.hip) */
+Geometry pick_geometry_intloss_full(int N);
 
 template <int DYN> inline Geometry pick_geometry_t(int N)
 {

@@ -7,5 +7,9 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_geometry_intloss(int N) { return pick_geometry_t<LOSS_INTEGRATED>(N); }
+Geometry pick_geometry_intloss(int N, bool full)
+{
+    if (full) { const Geometry g = pick_geometry_intloss_full(N); if (g.fn) return g; }
+    return pick_geometry_t<LOSS_INTEGRATED>(N);
+}
 }

@@ -64,7 +64,7 @@ def transferSolution(z, positionsOld, positionsNew, withPnBrake):
 
 def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2, noise=0.0, seed=0,
                      initialTime=0.0, initialVelocity=1.0, terminalVelocity=1.0, device=0, solverFactory=None,
-                     warmStart=False, warmMu=1e-2, warmPush=1e-3, dualMu=1e-4):
+                     warmStart=False, warmMu=1e-2, warmPush=1e-3, dualMu=1e-4, relaxInfeasible=True, lateMargin=5e-3):
     """
     Re-solve `numResolves` times; after each solve the train advances `stride` intervals of the current grid, the
     measured time and speed at that node are perturbed by `noise` (relative, standard normal) and the remaining
@@ -73,14 +73,20 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     one (msd_solve_batch_shifted: primal point and multipliers, barrier parameter `dualMu`), through transferSolution otherwise (primal
     point only, `warmMu`); a warm start that breaks down is repeated cold inside the launch.
 
+    A re-solve that fails because the measured state no longer allows the arrival time (near the end of the horizon a
+    late measurement leaves less than the minimum running time) is repeated with the arrival time moved to the scenario's certified
+    minimum running time from there (casadiSolver.minimumTime, plus `lateMargin` relative): the train arrives late and keeps
+    being controlled (`relaxInfeasible`; off: such a scenario keeps its last measurement).  The moved arrival time stays for the
+    rest of the horizon; 'relaxed' in the log marks the scenarios it was applied to.
+
     terminalTime: array (B,) of arrival times (absolute).
-    Returns a list of dicts per re-solve: position [m], numIntervals, t0 (B,), v0 (B,), status, iterations, cost, z.
+    Returns a list of dicts per re-solve: position [m], numIntervals, t0 (B,), v0 (B,), T (B,), status, iterations, cost, z, relaxed (B,) bool.
     `solverFactory(train, track, opts)` lets tests substitute the solver (default: the device solver).
     """
 
     make = solverFactory or (lambda tr, tk, op: casadiSolver(tr, tk, op, device=device))
 
-    T = np.atleast_1d(np.asarray(terminalTime, dtype=float))
+    T = np.array(np.atleast_1d(np.asarray(terminalTime, dtype=float)), copy=True)
     B = T.shape[0]
     rng = np.random.default_rng(seed)
 
@@ -112,77 +118,114 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
 
     pending = None
 
-    for k in range(numResolves):
+    try:
+      for k in range(numResolves):
 
-        Nk = N - stride*k
+          Nk = N - stride*k
 
-        if Nk < 1:
-            break
+          if Nk < 1:
+              break
 
-        solver, following = pending.result() if pending is not None else prepare(current, Nk)
-        pending = None
-        if pool is not None and following is not None and k + 1 < numResolves:
-            pending = pool.submit(prepare, following, Nk - stride)
+          solver, following = pending.result() if pending is not None else prepare(current, Nk)
+          pending = None
+          if pool is not None and following is not None and k + 1 < numResolves:
+              pending = pool.submit(prepare, following, Nk - stride)
 
-        if hasattr(solver, 'adoptDevice'):
-            solver.adoptDevice(last)      # same device handle for every re-solve
-            if warmStart and solverFactory is None:
-                solver.problem.keep_duals(True)      # the multipliers of every solve stay on the device for the next re-solve
+          if hasattr(solver, 'adoptDevice'):
+              solver.adoptDevice(last)      # same device handle for every re-solve
+              twin = last.__dict__.pop('_twin', None) if last is not None else None
+              if twin is not None:
+                  if solver.__dict__.get('_twin') is None and hasattr(twin, 'adoptDevice'):
+                      # the time-optimal twin of the previous problem hands its device handle to the twin of this one
+                      opts = dict(solver._optsDict); opts['energyOptimal'] = False; opts.pop('integrateLosses', None)
+                      solver._twin = type(solver)(solver.train, solver.track, opts, device=solver._device, startingPoint='profile').adoptDevice(twin)
+                  twin.close()
+              if warmStart and solverFactory is None:
+                  solver.problem.keep_duals(True)      # the multipliers of every solve stay on the device for the next re-solve
 
-        common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
+          common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 
-        posNew = position + solver.points.index.values
-        tail = (warmStart and previous is not None and onDevice and hasattr(solver, 'adoptDevice') and solverFactory is None and
-                len(previous[1]) - len(posNew) == stride and np.allclose(posNew, previous[1][stride:], rtol=0, atol=1e-6))
+          posNew = position + solver.points.index.values
+          tail = (warmStart and previous is not None and onDevice and hasattr(solver, 'adoptDevice') and solverFactory is None and
+                  len(previous[1]) - len(posNew) == stride and np.allclose(posNew, previous[1][stride:], rtol=0, atol=1e-6))
 
-        if tail:
-            # the new grid is the tail of the old one and the previous solutions are still on the device (same handle): the re-solve
-            # warm-starts from them there -- no upload, and scenarios without a usable guess start cold inside the same launch
-            res = solver.solveBatch(T, shift=stride, warmMu=dualMu, warmPush=warmPush, classifyFailures=False, **common)
-            onDevice = True
-        elif warmStart and previous is not None:
-            zPrev, posPrev, okPrev = previous
-            guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
-            usable = okPrev & np.isfinite(guess).all(axis=1)
-            if usable.any():
-                # scenarios without a usable guess get another scenario's solution as a placeholder: a warm start that breaks down is
-                # repeated from the problem's own starting point inside the launch (solve_kernel), so no second launch is needed
-                if not usable.all():
-                    guess[~usable] = guess[np.flatnonzero(usable)[0]]
-                res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
-            else:
-                res = solver.solveBatch(T, classifyFailures=False, **common)
-            onDevice = True
-        else:
-            res = solver.solveBatch(T, classifyFailures=False, **common)
-            onDevice = True
+          if tail:
+              # the new grid is the tail of the old one and the previous solutions are still on the device (same handle): the re-solve
+              # warm-starts from them there -- no upload, and scenarios without a usable guess start cold inside the same launch
+              res = solver.solveBatch(T, shift=stride, warmMu=dualMu, warmPush=warmPush, classifyFailures=False, **common)
+              onDevice = True
+          elif warmStart and previous is not None:
+              zPrev, posPrev, okPrev = previous
+              guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
+              usable = okPrev & np.isfinite(guess).all(axis=1)
+              if usable.any():
+                  # scenarios without a usable guess get another scenario's solution as a placeholder: a warm start that breaks down is
+                  # repeated from the problem's own starting point inside the launch (solve_kernel), so no second launch is needed
+                  if not usable.all():
+                      guess[~usable] = guess[np.flatnonzero(usable)[0]]
+                  res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
+              else:
+                  res = solver.solveBatch(T, classifyFailures=False, **common)
+              onDevice = True
+          else:
+              res = solver.solveBatch(T, classifyFailures=False, **common)
+              onDevice = True
 
-        previous = (res['z'], position + solver.points.index.values, res['status'] >= 0)
+          relaxed = np.zeros(B, dtype=bool)
+          kernel_extra = 0.0
+          bad = np.flatnonzero(res['status'] < 0)
+          if relaxInfeasible and bad.size and hasattr(solver, 'minimumTime'):
+              # what stops these scenarios is their arrival time: the minimum running time from the measured state (time-optimal twin of
+              # this re-solve's problem) tells, and becomes the new arrival time where it is later than the one asked for
+              scenBad = solver._scenarios(T[bad], t_now[bad], terminalVelocity, v_now[bad])
+              tmin, okMin = solver.minimumTime(scenBad)
+              late = okMin & (tmin > (T[bad] - t_now[bad]))
+              if late.any():
+                  idx, tm = bad[late], tmin[late]
+                  relaxed[idx] = True
+                  margin = lateMargin
+                  for attempt in range(3):
+                      # (an interior-point solve needs some room above the minimum running time: a scenario that still breaks down gets four times the margin)
+                      T[idx] = t_now[idx] + tm*(1 + margin)
+                      again = solver.solveBatch(T[idx], initialTime=t_now[idx], terminalVelocity=terminalVelocity, initialVelocity=v_now[idx], classifyFailures=False)
+                      for key in ('z', 'status', 'iterations', 'cost'):
+                          res[key][idx] = again[key]
+                      kernel_extra += float(again.get('kernel_ms', 0.0))
+                      still = again['status'] < 0
+                      if not still.any():
+                          break
+                      idx, tm, margin = idx[still], tm[still], 4*margin
+                  onDevice = False      # the handle's last launch held these scenarios only: the next re-solve takes its guess from the host copy
 
-        log.append(dict(position=position, numIntervals=Nk, t0=t_now.copy(), v0=v_now.copy(), status=res['status'].copy(),
-                        iterations=res['iterations'].copy(), cost=res['cost'].copy(), z=res['z']))
+          previous = (res['z'], position + solver.points.index.values, res['status'] >= 0)
 
-        last = solver
+          log.append(dict(position=position, numIntervals=Nk, t0=t_now.copy(), v0=v_now.copy(), T=T.copy(), status=res['status'].copy(),
+                          iterations=res['iterations'].copy(), cost=res['cost'].copy(), z=res['z'], relaxed=relaxed,
+                          kernel_ms=float(res.get('kernel_ms', 0.0)) + kernel_extra))
 
-        if Nk - stride < 1:
-            break
+          last = solver
 
-        # state at node `stride` of this grid (layout ocp.py:376-405): t and b of stage `stride`
-        stp = 4 + int(solver.withPnBrake)
-        t_meas = res['z'][:, stp*stride + 2 + int(solver.withPnBrake)]
-        v_meas = np.sqrt(res['z'][:, stp*stride + 3 + int(solver.withPnBrake)])
+          if Nk - stride < 1:
+              break
 
-        # failed scenarios keep coasting on their last measurement
-        ok = res['status'] >= 0
-        n1, n2 = rng.standard_normal(B), rng.standard_normal(B)
-        t_now = np.where(ok, np.maximum(t_meas*(1 + noise*n1), 0.0), t_now)
-        v_now = np.where(ok, v_meas*(1 + noise*n2), v_now)
+          # state at node `stride` of this grid (layout ocp.py:376-405): t and b of stage `stride`
+          stp = 4 + int(solver.withPnBrake)
+          t_meas = res['z'][:, stp*stride + 2 + int(solver.withPnBrake)]
+          v_meas = np.sqrt(res['z'][:, stp*stride + 3 + int(solver.withPnBrake)])
 
-        position += float(solver.points.index.values[stride])
-        current = following
+          # failed scenarios keep coasting on their last measurement
+          ok = res['status'] >= 0
+          n1, n2 = rng.standard_normal(B), rng.standard_normal(B)
+          t_now = np.where(ok, np.maximum(t_meas*(1 + noise*n1), 0.0), t_now)
+          v_now = np.where(ok, v_meas*(1 + noise*n2), v_now)
 
-    if pool is not None:
-        pool.shutdown(wait=True)
+          position += float(solver.points.index.values[stride])
+          current = following
+
+    finally:
+        # also on an exception in a solve or a reconfigure: no worker thread (building the next problem on the shared train) is left behind
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
 
     if last is not None and hasattr(last, 'close'):
         last.close()

@@ -330,20 +330,52 @@ class casadiSolver():
         ST = _device.ST
 
         if self.energyOptimal and classifyFailures:
-            self._classify_failures(scen, st)
+            self._classify_failures(scen, st, self._overrides(B, mass, r0, r1, r2))
 
         cost = st[:, ST['OBJ']]*(1.0 if self.energyOptimal else self.scalingFactorObjective)   # ocp.py:361
 
         return dict(z=out['z'], status=st[:, ST['STATUS']].astype(int), iterations=st[:, ST['ITERS']].astype(int), cost=cost,
                     stats=st, kernel_ms=out['kernel_ms'], lam_g=out['lam_g'], scenarios=scen)
 
-    def _classify_failures(self, scen, st):
+    def minimumTime(self, scen, overrides=None):
+        """
+        Minimum running times of the scenarios `scen` (rows t0, T, v0^2, vN^2; T is ignored): the time-optimal twin of the problem
+        (same track, train, transcription and integrator, energyOptimal=False, ocp.py:146-150) solved on the device, with the
+        scenarios' own rolling stock (`overrides`, rows of _overrides()).  Returns (tmin (B,), ok (B,) bool).
+        """
+
+        twin = self.__dict__.get('_twin')
+
+        if twin is None:
+            opts = dict(self._optsDict)
+            opts['energyOptimal'] = False
+            opts.pop('integrateLosses', None)      # (the loss slacks do not exist in the time-optimal problem)
+            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile')
+
+        sub = np.atleast_2d(np.asarray(scen, dtype=float))
+        loose = sub.copy()
+        # a running time the twin can certainly meet: three times the run at top speed or three times the one asked for (a much looser
+        # bound only costs iterations: the profile start of the twin uses up the time it is given)
+        loose[:, 1] = sub[:, 0] + np.maximum(3*self.track.length/self._vmaxTrain, 3*(sub[:, 1] - sub[:, 0]))
+
+        ov = None
+        if overrides is not None:
+            # the twin's objective is scaled by a constant of the problem (ocp.py:282), not by the mass
+            ov = np.array(overrides, dtype=float, copy=True)
+            ov[:, _device.OV['OBJ_DEN']] = twin._desc.obj_den
+
+        out = twin.problem.solve_batch(loose, overrides=ov)
+        ok = out['stats'][:, _device.ST['STATUS']] >= 0
+
+        return out['z'][:, -2] - sub[:, 0], ok
+
+    def _classify_failures(self, scen, st, overrides=None):
         """
         IPOPT ends a solve whose constraints cannot be met in its restoration phase with 'Infeasible_Problem_Detected'
         (ocp.py:362-370 prints that status).  The device solver has no restoration phase; what it has is an exact certificate
         for the one infeasibility this problem class knows -- a running time below the minimum: the time-optimal twin of the
-        problem (same transcription, energyOptimal=False, ocp.py:146-150) is solved for the scenarios that broke down, and
-        those whose minimum running time exceeds their T are marked infeasible.  Everything else keeps its status.
+        problem is solved for the scenarios that broke down (with their own rolling stock), and those whose minimum running
+        time exceeds their T are marked infeasible.  Everything else keeps its status.
         """
 
         ST = _device.ST
@@ -352,21 +384,8 @@ class casadiSolver():
         if failed.size == 0:
             return
 
-        twin = self.__dict__.get('_twin')
-
-        if twin is None:
-            opts = dict(self._optsDict)
-            opts['energyOptimal'] = False
-            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile')
-
         sub = scen[failed]
-        loose = sub.copy()
-        # a running time the twin can certainly meet: three times the run at top speed or three times the one asked for (a much looser
-        # bound only costs iterations: the profile start of the twin uses up the time it is given)
-        loose[:, 1] = sub[:, 0] + np.maximum(3*self.track.length/self._vmaxTrain, 3*(sub[:, 1] - sub[:, 0]))
-        out = twin.problem.solve_batch(loose)
-        ok = out['stats'][:, ST['STATUS']] >= 0
-        tmin = out['z'][:, -2] - sub[:, 0]
+        tmin, ok = self.minimumTime(sub, None if overrides is None else overrides[failed])
         short = ok & (tmin > (sub[:, 1] - sub[:, 0])*(1 + 1e-8))
         st[failed[short], ST['STATUS']] = _device.STATUS_INFEASIBLE
 

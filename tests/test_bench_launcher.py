@@ -26,15 +26,17 @@ def _clean_env():
 
 
 @pytest.mark.parametrize('gpus', [1, 2, 8])
-def test_no_device_is_reported_not_raised(gpus):
+def test_no_device_is_reported_with_its_own_exit_code(gpus):
     import torch
     if torch.cuda.device_count() >= gpus:
         pytest.skip("this machine has the devices")
     r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(gpus), '--no-build'], capture_output=True, text=True, env=_clean_env(), timeout=600)
-    # --no-build exits with a message of its own when the library is stale: both are clean, explicit exits
-    assert r.returncode == 0 or 'stale' in r.stderr, r.stderr
-    assert 'WORLD_SIZE' not in r.stderr
-    if r.returncode == 0:
+    # no JSON line can be produced here: a non-zero exit code with an explicit message, never a stack trace and never a silent success
+    # (--no-build exits with a message of its own when the library is stale: also a clean, explicit exit)
+    assert r.returncode != 0, "nothing was measured: the exit code must say so"
+    assert r.returncode == 2 or 'stale' in r.stderr, r.stderr
+    assert 'WORLD_SIZE' not in r.stderr and 'Traceback' not in r.stderr
+    if r.returncode == 2:
         assert 'HIP device' in r.stderr and r.stdout.strip() == ''
 
 

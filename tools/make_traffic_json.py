@@ -1,6 +1,7 @@
 """
-HBM bytes per launch of the solve kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, stamped with the
-digest of the kernel sources it was measured on (bench.py reports `roofline.traffic` only when the digest matches the library).
+HBM bytes per launch of the solve kernel for every workload profiled by tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes) and the
+issue statistics of the SQ pass, stamped with the digest of the kernel sources they were measured on (bench.py reports
+`roofline.traffic` only when the digest matches the library it runs).
 usage: python tools/make_traffic_json.py gpurun_out/<tag>  > profiles/hbm_traffic.json
 """
 import csv, glob, json, os, sys
@@ -9,37 +10,42 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 
 out = sys.argv[1]
+KEYS = dict(c1='c1', c1ref='c1/reference_start', c1b8192='c1/batch8192', c2='c2', c3='c3', intloss='c1/integrate_losses', irk='c1/irk_radau2', cvodes='c1/cvodes_tolerances')
 
 
-def mean_counter(tag, counter):
+def mean_counter(d, counter):
     vals = []
-    for f in glob.glob(os.path.join(out, 'pmc_' + tag, '**', '*counter_collection.csv'), recursive=True):
+    for f in glob.glob(os.path.join(out, d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'solve_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
                 vals.append(float(r['Counter_Value']))
     return (sum(vals)/len(vals), len(vals)) if vals else (None, 0)
 
 
-fetch_kb, nf = mean_counter('fetch', 'FETCH_SIZE')
-write_kb, nw = mean_counter('write', 'WRITE_SIZE')
-if fetch_kb is None or write_kb is None:
+rec = {"kernel_digest": entry.hip_digest(),
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (tools/profile_round.sh), means over the solve-kernel launches of a pass; "
+                 "FETCH_SIZE as reported (the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; this kernel's traffic is 8 B/lane "
+                 "scratch and result stores, a width the guide calls uncalibrated; bytes_per_launch_with_fetch_doubled applies it anyway -- WRITE_SIZE dominates either way)",
+       "workloads": {}}
+for name, key in KEYS.items():
+    fetch_kb, nf = mean_counter('pmc_fetch_' + name, 'FETCH_SIZE')
+    write_kb, nw = mean_counter('pmc_write_' + name, 'WRITE_SIZE')
+    if fetch_kb is None or write_kb is None:
+        continue
+    line = json.load(open(os.path.join(out, 'pmc_fetch_' + name + '.json')))
+    w = {"bytes_per_launch": int(1024*(fetch_kb + write_kb)), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+         "bytes_per_launch_with_fetch_doubled": int(1024*(2*fetch_kb + write_kb)), "launches_measured": [nf, nw],
+         "launch": "{}; {} scenarios, {:.2f} IP iterations per solve".format(line['roofline']['kernel'], line['config']['batch_per_gpu'], line['config']['ip_iterations_mean']),
+         "compulsory_bytes_per_launch": line['roofline']['compulsory_bytes_per_launch'],
+         "stage_iterations_per_launch": line['roofline']['stage_iterations_per_launch']}
+    # issue statistics of the same kernel from the SQ pass (units of four cycles per wave, summed over the waves of a launch)
+    sq = {k: mean_counter('pmc_sq_' + name, k)[0] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU')}
+    if all(v is not None for v in sq.values()):
+        w["issue"] = {"valu_instructions_per_launch": sq['SQ_INSTS_VALU'], "lds_instructions_per_launch": sq['SQ_INSTS_LDS'], "salu_instructions_per_launch": sq['SQ_INSTS_SALU'],
+                      "valu_instructions_per_stage_iteration": sq['SQ_INSTS_VALU']/w['stage_iterations_per_launch'],
+                      "wave_life_executing": sq['SQ_ACTIVE_INST_ANY']/sq['SQ_WAVE_CYCLES'], "wave_life_waiting_on_counters": sq['SQ_WAIT_ANY']/sq['SQ_WAVE_CYCLES'],
+                      "wave_life_waiting_for_instructions": sq['SQ_WAIT_INST_ANY']/sq['SQ_WAVE_CYCLES']}
+    rec["workloads"][key] = w
+if not rec["workloads"]:
     raise SystemExit("no solve_kernel rows in the counter files under " + out)
-line = json.load(open(os.path.join(out, 'pmc_fetch.json')))
-rec = {
-    "bytes_per_launch": int(1024*(fetch_kb + write_kb)),
-    "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-    "bytes_per_launch_with_fetch_doubled": int(1024*(2*fetch_kb + write_kb)),      # upper reading: the guide's x2 for 16 B/lane streams applied anyway
-    "kernel_digest": entry.hip_digest(),
-    "launch": "{}; {} scenarios, {:.2f} IP iterations per solve".format(line['roofline']['kernel'], line['config']['batch_per_gpu'], line['config']['ip_iterations_mean']),
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_round.sh), mean of {} / {} solve-kernel launches; FETCH_SIZE as reported "
-              "(the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; the kernel's traffic is 8 B/lane scratch and result stores, a width the guide calls uncalibrated; bytes_per_launch_with_fetch_doubled is the reading with the correction applied anyway -- WRITE_SIZE dominates either way)".format(nf, nw),
-    "compulsory_bytes_per_launch": int(line['config']['batch_per_gpu']*(8*(5*line['config']['num_intervals'] + 2) + 168)),
-}
-# issue statistics of the same kernel from the SQ pass (units of four cycles per wave, summed over the waves of a launch)
-sq = {k: mean_counter('sq', k)[0] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU')}
-if all(v is not None for v in sq.values()):
-    rec["issue"] = {"valu_instructions_per_launch": sq['SQ_INSTS_VALU'], "lds_instructions_per_launch": sq['SQ_INSTS_LDS'], "salu_instructions_per_launch": sq['SQ_INSTS_SALU'],
-                    "wave_life_executing": sq['SQ_ACTIVE_INST_ANY']/sq['SQ_WAVE_CYCLES'], "wave_life_waiting_on_counters": sq['SQ_WAIT_ANY']/sq['SQ_WAVE_CYCLES'],
-                    "wave_life_waiting_for_instructions": sq['SQ_WAIT_INST_ANY']/sq['SQ_WAVE_CYCLES'],
-                    "source": "rocprofv3 --pmc SQ_* pass of tools/profile_round.sh (one wave per SIMD: nothing hides a wave's own latencies)"}
 print(json.dumps(rec, indent=1))

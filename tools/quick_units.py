@@ -1,6 +1,8 @@
 """
-Tuning aid: recompile only msd_kernels_full.hip (and msd_api.hip with --api) into the product library and stamp it as current.
-The other units keep their objects: only valid while the edit does not change what they compile (run __graft_entry__.build(force=True) before committing).
+Tuning aid: recompile the named units (default: msd_kernels_full.hip) into the product library and stamp it as current, e.g.
+    python tools/quick_units.py msd_kernels_full2.hip msd_api.hip
+The other units keep their objects: only valid while the edit does not change what they compile (run
+`python __graft_entry__.py --force` before committing).
 """
 import subprocess, sys
 from pathlib import Path
@@ -9,7 +11,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as e
 csrc = e.PKG / 'csrc'
 objdir = e.PKG / 'lib' / 'obj'
-units = ['msd_kernels_full.hip'] + (['msd_api.hip'] if '--api' in sys.argv else [])
+units = [a for a in sys.argv[1:] if a.endswith('.hip')] or ['msd_kernels_full.hip']
 flags = [f for f in e.HIP_FLAGS if f != '-shared']
 jobs = []
 for u in units:
