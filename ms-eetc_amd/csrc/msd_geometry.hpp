@@ -48,11 +48,29 @@ template <int DYN> inline Geometry pick_geometry_t(int N)
     return {0, 0, nullptr};
 }
 
-/* horizons whose stage blocks do not fit the LDS of a compute unit: 1024 threads x 5 nodes, stage blocks streamed through L2 */
-template <bool DYN> inline Geometry pick_stream_geometry_t(int N)
+/* horizons whose stage blocks do not fit the LDS of a compute unit: node fields, stage blocks and exchange arrays live in device memory, a
+ * lane's nodes are worked off one after the other.  512 threads (two waves per SIMD, 256 registers each) with the stage-parallel KKT solve
+ * and as few nodes per lane as the horizon allows (N = 1000: two; 38 -> 11 ms per solve against round 2's 1024 x 5 with serial sweeps);
+ * MSD_STREAM_GEOMETRY=1024 selects that kernel for every horizon (tuning runs).  The instantiations are spread over two translation
+ * units (msd_kernels_stream.hip, msd_kernels_stream2.hip) */
+template <bool DYN> inline Geometry pick_stream_geometry_short_t(int N)      /* N <= 2047 */
 {
+    const char *g = getenv("MSD_STREAM_GEOMETRY");
+    if (g && !strcmp(g, "1024")) return {0, 0, nullptr};
+    if (N + 1 <= 1024) return {512, 2, solve_kernel<512, 2, 2, DYN, true>, true};
+    if (N + 1 <= 2048) return {512, 4, solve_kernel<512, 4, 2, DYN, true>, true};
+    return {0, 0, nullptr};
+}
+template <bool DYN> inline Geometry pick_stream_geometry_long_t(int N)       /* N <= 5119 */
+{
+    const char *g = getenv("MSD_STREAM_GEOMETRY");
+    if (!(g && !strcmp(g, "1024"))) {
+        if (N + 1 <= 3072) return {512, 6, solve_kernel<512, 6, 2, DYN, true>, true};
+        if (N + 1 <= 5120) return {512, 10, solve_kernel<512, 10, 2, DYN, true>, true};
+    }
     if (N + 1 <= 5120) return {1024, 5, solve_kernel<1024, 5, 1, DYN, true>, true};
     return {0, 0, nullptr};
 }
+Geometry pick_stream_geometry_static_long(int N);
 
 }  // namespace msd

@@ -170,14 +170,17 @@ __device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds
             const double eb = h*(e1*jval(kb[0]) + e3*jval(kb[2]) + e4*jval(kb[3]) + e5*jval(kb[4]) + e6*jval(kb[5]) + e7*jval(kb[6]));
             err = fmax(fabs(et/sct), fabs(eb/scb));
         }
-        if (finite && (err <= 1.0 || h < 1e-14)) {
+        if (finite && err <= 1.0) {
             sig += h;
             yt = nt; yb = nb; kt[0] = kt[6]; kb[0] = kb[6];     /* first same as last */
         }
         const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
-        if (h < 1e-300) break;
+        if (h < 1e-14) break;      /* the step control has collapsed (the state left the model's domain) */
     }
+    /* an integration that did not reach the end of the interval is no interval map: NaN, so that the line search rejects the point
+     * (like the collocation step, irk_b) instead of taking a partially integrated state for it */
+    if (!(sig >= 1.0)) { yt = jconst(T(), NAN); yb = jconst(T(), NAN); }
     tau = yt; bplus = yb;
 }
 

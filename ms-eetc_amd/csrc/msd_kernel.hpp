@@ -44,6 +44,9 @@
 #ifndef MSD_FENCE_PHASES
 #define MSD_FENCE_PHASES 0x155      /* bit k: fence after phase k (enum PH_*): evaluation, assembly, read-back, step lengths, update (tools/ab.sh, round 2) */
 #endif
+#ifndef MSD_FENCE_MAX_NT
+#define MSD_FENCE_MAX_NT 256        /* largest workgroup the phase fences are applied to (see Solver::phase_fence) */
+#endif
 #ifndef MSD_FENCE_DUALS
 #define MSD_FENCE_DUALS 1           /* also fence multipliers and residuals, not only the primal point */
 #endif
@@ -1438,11 +1441,11 @@ struct Solver {
     {
 #if MSD_PHASE_FENCE
         if (!((MSD_FENCE_PHASES >> phase) & 1)) return;
-        /* one or two waves per workgroup only (N <= 255: BASELINE configs 1-4; +20 % on config 2).  With three and more waves hipcc
-         * (ROCm 7.2, iterative-ilp scheduling) has produced wrong code around the fenced multipliers -- 192 x 2: the iterate of
-         * the last wave corrupted, reproduced with tools/debug_history.py -- and tests/test_gpu_parity.py::
-         * test_every_launch_geometry_vs_oracle guards every geometry against a recurrence */
-        if (NT > 128 || STREAM) return;
+        /* Up to four waves per workgroup (+30 ... 38 % at 192 x 2 and 256 x 2; the five-wave 320 x 2 kernel with its 256-register budget loses
+         * 11 % to them).  Round 2 had switched them off above two waves after wrong results at 192 x 2 under the iterative-ilp scheduler it
+         * used then; under the plain -O3 scheduling in use since, every geometry agrees with the oracle with the fences on (tools/
+         * geometry_sweep.py: 64 scenarios per horizon, horizons that leave idle node slots in the last wave; profiles/r03) */
+        if (NT > MSD_FENCE_MAX_NT || STREAM) return;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             NodeT &nd = n[j];
@@ -1888,7 +1891,9 @@ struct Solver {
         c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
         int par = -1;
 #if MSD_PARALLEL_RICCATI
-        if (!STREAM) {
+        /* (the scan keeps its wave totals for up to eight waves: the streamed kernels of 512 threads take it too, on their stage blocks in
+         * device memory -- a serial sweep there pays a memory round trip per stage) */
+        if (!STREAM || NT <= 512) {
         park_state();
 #if MSD_STASH_KKT
         stash<H_ALL & ~H_DSG>();
@@ -1902,7 +1907,7 @@ struct Solver {
             assemble(mode, mu_, dw);
             if (c.tid == 0) c.misc[MISC_FALLBACKS] += 1.0;
         }
-        }      /* (the streamed long-horizon kernel takes the serial sweeps: its stage blocks live in device memory) */
+        }      /* (the 1024-thread streamed kernels take the serial sweeps) */
 #endif
         if (par < 0) {       /* serial sweeps on one lane: the fallback of the scan (cold) or, with MSD_PARALLEL_RICCATI = 0, the only path */
             if (c.tid == 0) {

@@ -16,6 +16,12 @@ Geometry pick_geometry_full(int N)
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, true>, false, XCH_FAST, 0};
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, true>, false, XCH_FAST, 0};     /* the benchmark geometry */
     if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, LOSS_STATIC, false, false, true>, false, XCH_FAST, RED_DOUBLES};
+#ifndef MSD_MINIMAL_GEOMETRIES
+    /* longer horizons while the five additional exchange arrays still fit the LDS of a compute unit next to the stage blocks */
+    const auto fits = [&](int ns) { return sizeof(double)*(size_t)lds_doubles(N, ns, false, XCH_FAST, RED_DOUBLES) <= 160*1024; };
+    if (nodes <= 384 && fits(384)) return {192, 2, solve_kernel<192, 2, 1, LOSS_STATIC, false, false, true>, false, XCH_FAST, RED_DOUBLES};
+    if (nodes <= 512 && fits(512)) return {256, 2, solve_kernel<256, 2, 1, LOSS_STATIC, false, false, true>, false, XCH_FAST, RED_DOUBLES};
+#endif
     return {0, 0, nullptr};
 }
 }

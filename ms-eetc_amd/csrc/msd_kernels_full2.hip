@@ -10,17 +10,22 @@
 namespace msd {
 
 static bool no_full() { const char *nf = getenv("MSD_NO_FULL"); return nf && *nf == '1'; }
-static bool one_node_per_lane() { const char *g = getenv("MSD_GEOMETRY2"); return g && !strcmp(g, "128x1"); }      /* tuning runs */
-static bool one_node_per_lane_w1() { const char *g = getenv("MSD_GEOMETRY2"); return g && !strcmp(g, "128x1w1"); }
+static bool two_nodes_per_lane() { const char *g = getenv("MSD_GEOMETRY2"); return g && !strcmp(g, "64x2"); }      /* tuning runs */
 
+/*
+ * 65 ... 128 nodes: two waves per scenario with one node per lane and the whole register file of a SIMD each.  The jets through the
+ * Newton solve of a collocation step, through the adaptive steps, or through the integrated loss distance are the bulk of an iteration
+ * here, and a lane that carries two nodes runs them one after the other with twice the state to keep (1 400 ... 1 600 spilled registers
+ * at 64 x 2 against 250 ... 400 at 128 x 1): measured on the config-1 batch 346k against 284k solves/s (integrateLosses), 186k against
+ * 166k (Radau, two points), 133k against 124k (adaptive at CVODES' tolerances); profiles/r03.
+ */
 Geometry pick_geometry_general_full(int N)
 {
     const int nodes = N + 1;
     if (no_full()) return {0, 0, nullptr};
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, true, true>};
-    if (nodes <= 128 && one_node_per_lane()) return {128, 1, solve_kernel<128, 1, 2, LOSS_STATIC, false, true, true>};
-    if (nodes <= 128 && one_node_per_lane_w1()) return {128, 1, solve_kernel<128, 1, 1, LOSS_STATIC, false, true, true>};
-    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, true, true>};
+    if (nodes <= 128 && two_nodes_per_lane()) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, true, true>};
+    if (nodes <= 128) return {128, 1, solve_kernel<128, 1, 1, LOSS_STATIC, false, true, true>};
     return {0, 0, nullptr};
 }
 
@@ -29,9 +34,8 @@ Geometry pick_geometry_intloss_full(int N)
     const int nodes = N + 1;
     if (no_full()) return {0, 0, nullptr};
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_INTEGRATED, false, false, true>};
-    if (nodes <= 128 && one_node_per_lane()) return {128, 1, solve_kernel<128, 1, 2, LOSS_INTEGRATED, false, false, true>};
-    if (nodes <= 128 && one_node_per_lane_w1()) return {128, 1, solve_kernel<128, 1, 1, LOSS_INTEGRATED, false, false, true>};
-    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_INTEGRATED, false, false, true>};
+    if (nodes <= 128 && two_nodes_per_lane()) return {64, 2, solve_kernel<64, 2, 1, LOSS_INTEGRATED, false, false, true>};
+    if (nodes <= 128) return {128, 1, solve_kernel<128, 1, 1, LOSS_INTEGRATED, false, false, true>};
     return {0, 0, nullptr};
 }
 

@@ -1,4 +1,4 @@
-/* solve-kernel instantiation for long horizons (stage blocks in device memory); see msd_geometry.hpp */
+/* solve-kernel instantiations for long horizons (stage blocks in device memory), up to 2047 intervals; see msd_geometry.hpp */
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -7,5 +7,9 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_stream_geometry_static(int N) { return pick_stream_geometry_t<false>(N); }
+Geometry pick_stream_geometry_static(int N)
+{
+    const Geometry g = pick_stream_geometry_short_t<false>(N);
+    return g.fn ? g : pick_stream_geometry_static_long(N);
+}
 }

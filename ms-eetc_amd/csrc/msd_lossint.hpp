@@ -88,13 +88,14 @@ __device__ inline T loss_distance(const DevProb &P, double v0, double dt0, doubl
             const double ex = h*(e1*j3val(kx[0]) + e3*j3val(kx[2]) + e4*j3val(kx[3]) + e5*j3val(kx[4]) + e6*j3val(kx[5]) + e7*j3val(kx[6]));
             err = fmax(fabs(ev/scv), fabs(ex/scx));
         }
-        if (finite && (err <= 1.0 || h < 1e-14)) {
+        if (finite && err <= 1.0) {
             sig += h;
             yv = nv; yx = nx; kv[0] = kv[6]; kx[0] = kx[6];     /* first same as last */
         }
         const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
-        if (h < 1e-300) break;
+        if (h < 1e-14) break;      /* the step control has collapsed */
     }
+    if (!(sig >= 1.0)) yx = j3const(T(), NAN);      /* not integrated to the end: no value (the line search rejects the point) */
     return yx;
 }

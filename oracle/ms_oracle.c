@@ -389,15 +389,17 @@ static void dopri_tb(const Prob *P, jet b0, jet w, double G, double ds, jet *tau
                 err = fmax(err, fabs(h*(e1*k[0][m].v + e3*k[2][m].v + e4*k[3][m].v + e5*k[4][m].v + e6*k[5][m].v + e7*k[6][m].v)/sc));
             }
         }
-        if (finite && (err <= 1.0 || h < 1e-14)) {
+        if (finite && err <= 1.0) {
             sig += h;
             for (int m = 0; m < 2; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }     /* first same as last */
         }
         const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
-        if (h < 1e-300) break;
+        if (h < 1e-14) break;      /* the step control has collapsed (the state left the model's domain) */
     }
 #undef RHS
+    /* not integrated to the end of the interval: no interval map (NaN: the line search rejects the point) */
+    if (!(sig >= 1.0)) { y[0] = j_const(NAN); y[1] = j_const(NAN); }
     *tau = y[0]; *bplus = y[1];
 }
 
@@ -457,15 +459,16 @@ static jet3 loss_distance(const Prob *P, double v0, double dt0, double w0, doubl
                 err = fmax(err, fabs(h*(e1*k[0][m].v + e3*k[2][m].v + e4*k[3][m].v + e5*k[4][m].v + e6*k[5][m].v + e7*k[6][m].v)/sc));
             }
         }
-        if (finite && (err <= 1.0 || h < 1e-14)) {
+        if (finite && err <= 1.0) {
             sig += h;
             for (int m = 0; m < 2; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }
         }
         const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
-        if (h < 1e-300) break;
+        if (h < 1e-14) break;
     }
 #undef LRHS
+    if (!(sig >= 1.0)) y[1] = j3_const(NAN);
     return y[1];
 }
 

@@ -1,7 +1,17 @@
 #!/bin/sh
-# TEST-ONLY: host emulation build of the device header (optionally with sanitizers: SAN=1)
+# TEST-ONLY: host emulation build of the device header, one translation unit per kernel family in parallel
+# (optionally with sanitizers: SAN=1; output: OUT=<path>, default libmsd_emu.so here)
 set -e
 cd "$(dirname "$0")"
 FLAGS="-O1 -g"
 [ -n "$SAN" ] && FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
-g++ -std=c++17 $FLAGS -fPIC -shared -pthread -ffp-contract=off -I. -o libmsd_emu.so emu_driver.cpp
+OUT=${OUT:-libmsd_emu.so}
+OBJ=${OBJDIR:-obj${SAN:+_san}}
+mkdir -p "$OBJ"
+pids=""
+for u in emu_driver emu_k_static emu_k_full emu_k_dynamic emu_k_general emu_k_intloss emu_k_stream; do
+  g++ -std=c++17 $FLAGS -fPIC -pthread -ffp-contract=off -I. -c -o "$OBJ/$u.o" $u.cpp &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+g++ -std=c++17 $FLAGS -fPIC -shared -pthread -o "$OUT" "$OBJ"/emu_driver.o "$OBJ"/emu_k_*.o

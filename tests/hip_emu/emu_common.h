@@ -1,0 +1,49 @@
+/*
+ * TEST-ONLY: shared part of the host emulation (see emu_driver.cpp).  run_blocks<...> runs one instantiation of msd::solve_kernel on host
+ * threads; the instantiations are spread over one translation unit per kernel family (emu_k_*.cpp) so that they compile in parallel --
+ * an AddressSanitizer build of a single unit took twenty minutes.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
+
+
+template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
+void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
+{
+    for (int b = 0; b < nscen; b++) {
+        emu_block blk;
+        blk.nthreads = NT;
+        pthread_barrier_init(&blk.bar, nullptr, NT);
+        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, FULL ? msd::XCH_FAST : msd::XCH_GENERAL));
+        blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
+        std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
+        std::vector<std::thread> th;
+        for (int t = 0; t < NT; t++)
+            th.emplace_back([&, t]() {
+                threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
+                emu_blk = &blk;
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+            });
+        for (auto &t : th) t.join();
+        pthread_barrier_destroy(&blk.bar);
+    }
+}
+
+
+/* family dispatchers (emu_k_*.cpp): false when the family has no instantiation for (NT, SPT) */
+struct EmuArgs { msd::DevProb P; int nscen; const double *scen, *ovr; double *z, *lam, *stats, *hist; int cap; };
+bool emu_run_static(int NT, int SPT, const EmuArgs &a);
+bool emu_run_full(int NT, int SPT, const EmuArgs &a);
+bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a);
+bool emu_run_general(int NT, int SPT, const EmuArgs &a);
+bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);
+bool emu_run_stream(const EmuArgs &a);
+#define EMU_CALL(...) run_blocks<__VA_ARGS__>(a.P, a.nscen, a.scen, a.ovr, a.z, a.lam, a.stats, a.hist, a.cap)

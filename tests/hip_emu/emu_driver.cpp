@@ -3,40 +3,10 @@
  * (see hip/hip_runtime.h in this directory).  Build: tests/hip_emu/build.sh.  Used by
  * tests/test_kernel_emulation.py to compare the kernel's logic with the oracle without a GPU.
  */
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <thread>
-#include <vector>
-
-#include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
+#include "emu_common.h"
 
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_block *emu_blk;
-
-template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
-static void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
-{
-    for (int b = 0; b < nscen; b++) {
-        emu_block blk;
-        blk.nthreads = NT;
-        pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, FULL ? msd::XCH_FAST : msd::XCH_GENERAL));
-        blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
-        std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
-        std::vector<std::thread> th;
-        for (int t = 0; t < NT; t++)
-            th.emplace_back([&, t]() {
-                threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
-                emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
-            });
-        for (auto &t : th) t.join();
-        pthread_barrier_destroy(&blk.bar);
-    }
-}
 
 /* primal-dual warm starts in the emulation: buffers for the next emu_solve_batch* call (dual_in already points at the first node used) */
 static const double *g_dual_in = nullptr;
@@ -72,44 +42,31 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;
     const bool dyn = d->loss_kind == 2;
     const int nodes = P.N + 1;
+    const EmuArgs a = {P, nscen, scen, ovr, z, lam, stats, hist, cap};
     if (d->integrate_losses) {      /* loss slacks from the integrated loss power (msd_lossint.hpp) */
         if (dyn || d->integrator != 0) return -3;
-        if (nodes <= 64) run_blocks<64, 1, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-        else if (nodes <= 128) run_blocks<64, 2, 2>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-        else return -3;
-        return 0;
+        return emu_run_intloss(64, nodes <= 64 ? 1 : 2, a) && nodes <= 128 ? 0 : -3;
     }
     if (d->integrator != 0) {       /* the kernels with the collocation / adaptive shooting integrators: two geometries are enough here */
-        if (dyn) return -3;
-        if (nodes <= 64) run_blocks<64, 1, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-        else if (nodes <= 128) run_blocks<64, 2, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-        else return -3;
-        return 0;
+        if (dyn || nodes > 128) return -3;
+        return emu_run_general(64, nodes <= 64 ? 1 : 2, a) ? 0 : -3;
     }
     const char *force = getenv("EMU_GEOMETRY");     /* "NTxSPT" to test other geometries */
     int NT = 0, SPT = 0;
+    if (force && !strcmp(force, "stream")) {      /* the long-horizon kernel (stage blocks in memory) at a thread count the emulation can afford */
+        if (dyn || nodes > 128*5) return -3;
+        return emu_run_stream(a) ? 0 : -3;
+    }
     if (force) sscanf(force, "%dx%d", &NT, &SPT);
     else if (nodes <= 64) { NT = 64; SPT = 1; }
     else if (nodes <= 128) { NT = 64; SPT = 2; }
     else if (nodes <= 256) { NT = 128; SPT = 2; }
-    else { NT = 192; SPT = 2; }
-    if (force && !strcmp(force, "stream")) {      /* the long-horizon kernel (stage blocks in memory) at a thread count the emulation can afford */
-        if (dyn || nodes > 128*5) return -3;
-        run_blocks<128, 5, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap);
-        return 0;
-    }
+    else if (nodes <= 384) { NT = 192; SPT = 2; }
+    else { NT = 320; SPT = 2; }
     if (NT*SPT < nodes) return -3;
     /* the kernels with the structure of the NLP compiled in (msd_kernels_full.hip), chosen like msd_api.hip does; EMU_NO_FULL=1: the general ones */
     const char *nofull = getenv("EMU_NO_FULL");
     const bool full = !dyn && P.withPn && P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && !(nofull && *nofull == '1');
-    if (full && NT == 64 && SPT == 1) { run_blocks<64, 1, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
-    if (full && NT == 64 && SPT == 2) { run_blocks<64, 2, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
-    if (full && NT == 128 && SPT == 2) { run_blocks<128, 2, false, false, false, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); return 0; }
-    if (NT == 64 && SPT == 1) { if (dyn) run_blocks<64, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
-    else if (NT == 64 && SPT == 2) { if (dyn) run_blocks<64, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<64, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
-    else if (NT == 128 && SPT == 1) { if (dyn) run_blocks<128, 1, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<128, 1, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
-    else if (NT == 128 && SPT == 2) { if (dyn) run_blocks<128, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<128, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
-    else if (NT == 192 && SPT == 2) { if (dyn) run_blocks<192, 2, true>(P, nscen, scen, ovr, z, lam, stats, hist, cap); else run_blocks<192, 2, false>(P, nscen, scen, ovr, z, lam, stats, hist, cap); }
-    else return -3;
-    return 0;
+    if (full && emu_run_full(NT, SPT, a)) return 0;
+    return (dyn ? emu_run_dynamic(NT, SPT, a) : emu_run_static(NT, SPT, a)) ? 0 : -3;
 }

@@ -1,0 +1,10 @@
+/* TEST-ONLY: host emulation, kernel family "full" (see emu_common.h) */
+#include "emu_common.h"
+
+bool emu_run_full(int NT, int SPT, const EmuArgs &a)
+{
+    if (NT == 64 && SPT == 1) { EMU_CALL(64, 1, false, false, false, true); return true; }
+    if (NT == 64 && SPT == 2) { EMU_CALL(64, 2, false, false, false, true); return true; }
+    if (NT == 128 && SPT == 2) { EMU_CALL(128, 2, false, false, false, true); return true; }
+    return false;
+}

@@ -1,0 +1,13 @@
+/* TEST-ONLY: host emulation, kernel family "static" (see emu_common.h) */
+#include "emu_common.h"
+
+bool emu_run_static(int NT, int SPT, const EmuArgs &a)
+{
+    if (NT == 64 && SPT == 1) { EMU_CALL(64, 1, false); return true; }
+    if (NT == 64 && SPT == 2) { EMU_CALL(64, 2, false); return true; }
+    if (NT == 128 && SPT == 1) { EMU_CALL(128, 1, false); return true; }
+    if (NT == 128 && SPT == 2) { EMU_CALL(128, 2, false); return true; }
+    if (NT == 192 && SPT == 2) { EMU_CALL(192, 2, false); return true; }
+    if (NT == 320 && SPT == 2) { EMU_CALL(320, 2, false); return true; }
+    return false;
+}

@@ -213,7 +213,7 @@ def test_long_horizons_streamed_kernel_vs_oracle(N):
     from oracle import oracle
     train, track = cases.train_fig10(), cases.track_00()       # table3.py uses the figure-10 train
     s = _solver(train, track, N, start='profile', maxIterations=1000)
-    assert s.problem.geometry() == (1024, 5)
+    assert s.problem.geometry() == {700: (512, 2), 1000: (512, 2), 5000: (512, 10)}[N]
     res = s.solveBatch([1541.0, 1620.0])
     assert np.all(res['status'] == 0), res['status']
     prob = cases.oracle_problem(train, track, N, maxIterations=1000)

@@ -19,8 +19,8 @@ EMU = Path(__file__).resolve().parent / 'hip_emu'
 
 def load_emulation():
     "Build (when out of date) and load the host emulation of the kernels."
-    src = [EMU / 'emu_driver.cpp', EMU / 'hip' / 'hip_runtime.h'] + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) \
-        + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
+    src = sorted(EMU.glob('*.cpp')) + sorted(EMU.glob('*.h')) + [EMU / 'build.sh', EMU / 'hip' / 'hip_runtime.h'] \
+        + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
     import os
     if os.environ.get('MSD_EMU_LIB'):      # a sanitizer build made by tests/hip_emu/run_sanitizers.sh
         so = Path(os.environ['MSD_EMU_LIB'])
