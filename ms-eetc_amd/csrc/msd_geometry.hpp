@@ -24,6 +24,12 @@ Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
 Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
+Geometry pick_geometry_general_dynamic(int N);      /* collocation / adaptive shooting integrators with the dynamic loss model (msd_kernels_compose.hip) */
+/* the other transcriptions beyond the LDS-resident horizons, up to 1023 intervals (msd_kernels_stream3.hip): dynamic loss model, collocation /
+ * adaptive shooting integrators, integrateLosses on the streamed kernel */
+Geometry pick_stream_geometry_dynamic(int N);
+Geometry pick_stream_geometry_general(int N);
+Geometry pick_stream_geometry_intloss(int N);
 Geometry pick_geometry_general_full(int N);  /* the same two families with the structure of the reference's rolling stock compiled in (msd_kernels_full2.hip) */
 Geometry pick_geometry_intloss_full(int N);
 

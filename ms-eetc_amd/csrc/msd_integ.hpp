@@ -61,6 +61,158 @@ __device__ inline void lu_solve_comps(int n, const double (&A)[COLL_MAX][COLL_MA
 }
 
 /*
+ * The same factorisation and solves for a compile-time dimension D <= 4 (OptionsIRK.order 1 ... 4; the default is 2, train.py:485): every
+ * index is a constant after unrolling, so the Newton system of a collocation step lives in registers -- with the run-time dimension
+ * above it lives in scratch memory.  The pivot search bubbles the largest entry of the column up by compare-and-swap of neighbouring
+ * candidates (same pivot as the search for the maximum; the order of the rows below it may differ, which changes nothing but rounding).
+ */
+template <int D> struct LuSmall { double A[D][D]; bool sw[D][D]; };
+
+template <int D> __device__ __forceinline__ bool lu_factor_small(LuSmall<D> &L)
+{
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+#pragma unroll
+        for (int r = c + 1; r < D; r++) {
+            const bool s = fabs(L.A[r][c]) > fabs(L.A[c][c]);
+            L.sw[c][r] = s;
+#pragma unroll
+            for (int m = 0; m < D; m++) { const double x = L.A[c][m], y = L.A[r][m]; L.A[c][m] = s ? y : x; L.A[r][m] = s ? x : y; }
+        }
+        if (!(fabs(L.A[c][c]) > 0)) ok = false;
+        const double ip = 1.0/L.A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < D; r++) {
+            L.A[r][c] *= ip;
+#pragma unroll
+            for (int m = c + 1; m < D; m++) L.A[r][m] -= L.A[r][c]*L.A[c][m];
+        }
+    }
+    return ok;
+}
+template <int D> __device__ __forceinline__ void lu_solve_small(const LuSmall<D> &L, double (&x)[D])
+{
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+#pragma unroll
+        for (int r = c + 1; r < D; r++) { const double a = x[c], b = x[r]; x[c] = L.sw[c][r] ? b : a; x[r] = L.sw[c][r] ? a : b; }
+#pragma unroll
+        for (int r = c + 1; r < D; r++) x[r] -= L.A[r][c]*x[c];
+    }
+#pragma unroll
+    for (int c = D - 1; c >= 0; c--) {
+#pragma unroll
+        for (int m = c + 1; m < D; m++) x[c] -= L.A[c][m]*x[m];
+        x[c] /= L.A[c][c];
+    }
+}
+/* components first ... of an array of jets (or the value of doubles) */
+template <int D> __device__ __forceinline__ void lu_solve_small_comps(const LuSmall<D> &L, Jet (&R)[D], int first)
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < first) continue;
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) x[j] = (k == 0) ? R[j].v : (k == 1) ? R[j].g0 : (k == 2) ? R[j].g1 : (k == 3) ? R[j].h00 : (k == 4) ? R[j].h01 : R[j].h11;
+        lu_solve_small<D>(L, x);
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            if (k == 0) R[j].v = x[j]; else if (k == 1) R[j].g0 = x[j]; else if (k == 2) R[j].g1 = x[j]; else if (k == 3) R[j].h00 = x[j]; else if (k == 4) R[j].h01 = x[j]; else R[j].h11 = x[j];
+        }
+    }
+}
+template <int D> __device__ __forceinline__ void lu_solve_small_comps(const LuSmall<D> &L, double (&R)[D], int first)
+{
+    if (first == 0) lu_solve_small<D>(L, R);
+}
+
+/* irk_b (below) for a compile-time number of collocation points */
+template <class T, int D>
+__device__ __forceinline__ T irk_b_small(const DevProb &P, T b0, T w, double G, double ds, double H, T *t)
+{
+    constexpr int ld = D + 1;
+    const double *Cg = P.coll;
+    double C[ld][ld], Dv[ld];      /* C[r][j], D[r]: uniform, read once */
+#pragma unroll
+    for (int r = 0; r < ld; r++) {
+        Dv[r] = Cg[ld*ld + r];
+#pragma unroll
+        for (int j = 0; j < ld; j++) C[r][j] = Cg[r*ld + j];
+    }
+    const double dt = H/P.numSteps, wv = jval(w);
+    T xb = b0, xt = t ? *t : jconst(T(), 0.0);
+    for (int k = 0; k < P.numSteps; k++) {
+        double v[D], F[D];
+        LuSmall<D> L;
+        const double xv = jval(xb);
+        bool valid = true;
+#pragma unroll
+        for (int j = 0; j < D; j++) v[j] = xv;
+        for (int it = 0; it <= P.newtonIters; it++) {
+            double fmaxabs = 0;
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const double sv = sqrt(v[j]);
+                const double f = 2*ds*(wv - (P.sr0 + P.sr1*sv + P.sr2*v[j]) - G), df = -2*ds*(0.5*P.sr1/sv + P.sr2);
+                double p = C[0][j + 1]*xv;
+#pragma unroll
+                for (int r = 0; r < D; r++) { p += C[r + 1][j + 1]*v[r]; L.A[j][r] = -C[r + 1][j + 1]; }
+                L.A[j][j] += dt*df;
+                F[j] = dt*f - p;
+                fmaxabs = fmax(fmaxabs, fabs(F[j]));
+            }
+            if (!lu_factor_small<D>(L)) { valid = false; break; }
+            if (it == P.newtonIters || !isfinite(fmaxabs) || fmaxabs <= 1e-13*fmax(1.0, fabs(xv))) break;
+            lu_solve_small<D>(L, F);
+#pragma unroll
+            for (int j = 0; j < D; j++) v[j] -= F[j];
+        }
+        if (!valid) { if (t) *t = jconst(T(), NAN); return jconst(T(), NAN); }
+        T V[D], R[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) V[j] = jconst(T(), v[j]);
+        if (jcomps(xb) > 1) {
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    T p = xb*C[0][j + 1];
+#pragma unroll
+                    for (int r = 0; r < D; r++) p = p + V[r]*C[r + 1][j + 1];
+                    R[j] = ode_b(P, V[j], w, G, ds)*dt - p;
+                }
+                lu_solve_small_comps<D>(L, R, 1);
+#pragma unroll
+                for (int j = 0; j < D; j++) { jcomp(R[j], 0) = 0.0; V[j] = V[j] - R[j]; }
+            }
+        }
+        T nb = xb*Dv[0];
+#pragma unroll
+        for (int r = 0; r < D; r++) nb = nb + V[r]*Dv[r + 1];
+        if (t) {
+            LuSmall<D> M;
+#pragma unroll
+            for (int j = 0; j < D; j++)
+#pragma unroll
+                for (int r = 0; r < D; r++) M.A[j][r] = C[r + 1][j + 1];
+            lu_factor_small<D>(M);
+#pragma unroll
+            for (int j = 0; j < D; j++) R[j] = xrecip(xsqrt(V[j]))*(dt*ds) - xt*C[0][j + 1];
+            lu_solve_small_comps<D>(M, R, 0);
+            T nt = xt*Dv[0];
+#pragma unroll
+            for (int r = 0; r < D; r++) nt = nt + R[r]*Dv[r + 1];
+            xt = nt;
+        }
+        xb = nb;
+    }
+    if (t) *t = xt;
+    return xb;
+}
+
+/*
  * casadi.simpleIRK(ode, numSteps, d, scheme, 'fast_newton') over [0, H] (train.py:310): per step of length dt = H/numSteps the d stage
  * values v solve  dt f(v_j) - (C[0][j] x + sum_r C[r][j] v_r) = 0  (x = start of the step; first guess v_j = x), the step ends at
  * D[0] x + sum_r D[r] v_r.  Newton's method runs on the values (at most OptionsIRK.maxIter iterations; like error_on_fail = False the
@@ -72,6 +224,13 @@ __device__ inline void lu_solve_comps(int n, const double (&A)[COLL_MAX][COLL_MA
 template <class T>
 __device__ inline T irk_b(const DevProb &P, T b0, T w, double G, double ds, double H, T *t)
 {
+    /* the usual orders with their Newton systems in registers */
+    switch (P.collD) {
+    case 1: return irk_b_small<T, 1>(P, b0, w, G, ds, H, t);
+    case 2: return irk_b_small<T, 2>(P, b0, w, G, ds, H, t);
+    case 3: return irk_b_small<T, 3>(P, b0, w, G, ds, H, t);
+    default: break;
+    }
     const int d = P.collD, ld = d + 1;
     const double *C = P.coll, *D = P.coll + ld*ld;
     const double dt = H/P.numSteps, wv = jval(w);

@@ -149,12 +149,11 @@ class casadiSolver():
         else:
             integrator = None
 
-        if integrator is not None and lossKind == LOSS_DYNAMIC:
-            raise NotImplementedError("The 'IRK' and 'CVODES' transcriptions run with constant efficiencies; the dynamic loss model needs 'RK'.")
-
         # loss slacks from the loss power integrated over the running time of the interval (ocp.py:231-241)
         integrateLosses = bool(opts.integrateLosses) and bool(opts.energyOptimal)
         if integrateLosses and (lossKind == LOSS_DYNAMIC or integrator is not None):
+            # (the loss rows of ocp.py:231-241 integrate the loss power along the time-domain model: with constant efficiencies that is a multiple
+            # of the distance covered, which is what the device integrates; the dynamic loss table or another shooting integrator next to it is not built)
             raise NotImplementedError("integrateLosses=True runs with constant efficiencies and the 'RK' transcription.")
         if integrateLosses and lossKind == LOSS_NONE:
             integrateLosses = False      # perfect efficiency: both loss integrals vanish and the rows reduce to s >= 0

@@ -65,6 +65,33 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
 
 
+@pytest.mark.parametrize('N,variant', [(300, 'fig10'), (300, 'both'), (530, 'fig10')])
+def test_emulated_multiwave_geometries_match_oracle(emu, N, variant):
+    """
+    The multi-wave geometries of the round-2 fence question -- 192 x 2 (three waves, N = 300: the last wave has idle node slots) and
+    320 x 2 (five waves) -- as host threads: same iterates as the oracle.  Also what the sanitizer run (tests/hip_emu/run_sanitizers.sh)
+    sees of them: uninitialised or out-of-bounds reads of a node slot nobody owns would show here.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train = cases.train_default() if variant == 'both' else cases.train_fig10()
+    track = cases.track_00()
+    T = 1600.0
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(prob, prob.scenario(T), start='profile')
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert abs(int(st[0, ST['ITERS']]) - int(ref['stats']['ITERS'])) <= 1
+    assert int(st[0, ST['N_FALLBACK']]) == 0
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
+
+
 def test_emulated_streamed_kernel_matches_oracle(emu, monkeypatch):
     "The long-horizon variant (node fields, stage blocks and exchange arrays in device memory, serial sweeps) at a thread count the emulation can afford."
     from mseetc.ocp import casadiSolver
