@@ -77,8 +77,8 @@ def usable_cores():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default per workload: c1 500, c2 50, c3 100, c4 5 -- about a second of launches)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default 10; c4: 1)')
     ap.add_argument('--batch', type=int, default=0, help='scenarios per GPU (default: the workload\'s per-GPU size)')
     ap.add_argument('--intervals', type=int, default=0, help='shooting intervals (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -93,7 +93,12 @@ def parse_args(argv=None):
                     help='the transcription of the reference\'s options the workload is solved with (default: RK4 + trapezoidal time, simulations/config.json)')
     ap.add_argument('--single-process', action='store_true',
                     help='one process drives all --gpus devices (one handle and stream per device), no torch.distributed')
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = dict(c1=500, c2=50, c3=100, c4=5)[args.workload]
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == 'c4' else 10
+    return args
 
 
 def free_port():

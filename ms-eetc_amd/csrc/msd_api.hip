@@ -48,6 +48,7 @@ struct msd_problem {
     double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
     double *h_stage = nullptr; size_t cap_stage = 0;  /* pinned staging buffer for the profile upload */
     double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
+    double *d_eval = nullptr; size_t cap_eval = 0;    /* msd_stage_eval: inputs and outputs of n intervals (17 n doubles), grown on demand */
     int *d_queue = nullptr;                           /* scenario counters of the launches (a ring: launches in flight on the stream each own one) */
     int queue_slot = 0;
     size_t cap_work = 0;
@@ -294,7 +295,7 @@ int msd_problem_destroy(msd_handle h)
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
-    hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess);
+    hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess); hipFree(h->d_eval);
     hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
     if (h->h_stage) hipHostFree(h->h_stage);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -635,9 +636,12 @@ int msd_stage_eval(msd_handle h, int n, const double *b, const double *w, const 
 {
     if (!h || n < 1 || !b || !w || !ds || !grad || !curv || !out12) return fail(MSD_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    double *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_in, sizeof(double)*5*n));
-    if (hipMalloc((void **)&d_out, sizeof(double)*12*n) != hipSuccess) { hipFree(d_in); return fail(MSD_E_HIP, "hipMalloc failed"); }
+    if ((size_t)17*n > h->cap_eval) {      /* kept with the handle: no allocation per call */
+        hipFree(h->d_eval); h->d_eval = nullptr; h->cap_eval = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_eval, sizeof(double)*17*(size_t)n));
+        h->cap_eval = (size_t)17*n;
+    }
+    double *d_in = h->d_eval, *d_out = h->d_eval + 5*(size_t)n;
     const double *src[5] = {b, w, ds, grad, curv};
     for (int k = 0; k < 5; k++) hipMemcpyAsync(d_in + (size_t)k*n, src[k], sizeof(double)*n, hipMemcpyHostToDevice, h->stream);
     hipLaunchKernelGGL(msd::stage_eval_kernel<0>, dim3((n + 255)/256), dim3(256), 0, h->stream, h->P, n, d_in, d_in + n, d_in + 2*(size_t)n, d_in + 3*(size_t)n,
@@ -645,7 +649,6 @@ int msd_stage_eval(msd_handle h, int n, const double *b, const double *w, const 
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out12, d_out, sizeof(double)*12*n, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d_in); hipFree(d_out);
     if (e != hipSuccess) return fail(MSD_E_HIP, hipGetErrorString(e));
     return MSD_OK;
 }

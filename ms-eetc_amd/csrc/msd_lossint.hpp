@@ -67,7 +67,7 @@ __device__ inline T loss_distance(const DevProb &P, double v0, double dt0, doubl
         const T acc = ((vj*(-P.sr1) + (vj*vj)*(-P.sr2)) + w) + (-P.sr0 - G);
         ov = dt*acc; ox = dt*vj;
     };
-    double sig = 0, h = 0.05;
+    double sig = 0, h = 1.0;      /* first try: the whole interval in one step (accepted on most intervals: the distance is smooth in its arguments; round 2 started at 0.05, three steps at least) */
     rhs(yv, kv[0], kx[0]);
     for (int step = 0; step < 100000 && sig < 1.0; step++) {
         if (sig + h > 1.0) h = 1.0 - sig;

@@ -438,7 +438,7 @@ static jet3 loss_distance(const Prob *P, double v0, double dt0, double w0, doubl
     /* d(v, X)/dsigma = dt (w - rr(v) - G, v) on the unit interval */
 #define LRHS(vj, out) do { jet3 acc_ = j3_axpy(-P->sr1, (vj), j3_axpy(-P->sr2, j3_mul((vj), (vj)), j3_axpy(1.0, w, j3_const(-P->sr0 - G)))); \
                            (out)[0] = j3_mul(dt, acc_); (out)[1] = j3_mul(dt, (vj)); } while (0)
-    double sig = 0, h = 0.05;
+    double sig = 0, h = 1.0;      /* first try: the whole interval in one step */
     LRHS(y[0], k[0]);
     for (int step = 0; step < 100000 && sig < 1.0; step++) {
         if (sig + h > 1.0) h = 1.0 - sig;

@@ -164,6 +164,83 @@ def test_gpu_other_integrators_vs_oracle(method, io, integration, N, crop, T):
             assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
 
 
+def _dynamic_train():
+    "figure5.py's train with the dynamic loss model of efficiency.py (no pneumatic brake)"
+    from mseetc.train import Train
+    from mseetc.efficiency import totalLossesFunction
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    train.forceMinPn = 0
+    train.powerLosses = totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+    return train
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method,io,integration', [('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2), ('CVODES', dict(), ADAPT)])
+def test_gpu_other_integrators_with_dynamic_losses_vs_oracle(method, io, integration):
+    """
+    The reference builds any integrationMethod with any loss model (ocp.py:92 next to efficiency.py:101-141): collocation and
+    tolerance-controlled shooting together with the dynamic loss table, figure5.py's problem (8.5 km, v0 = 1, vN = 100 km/h).
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc.track import computeDiscretizationPoints
+    from mseetc.train import collocationTables
+    train, track, N = _dynamic_train(), cases.track_00(8500), 60
+    oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+    if method == 'IRK':
+        oracle.set_collocation(*collocationTables(integration['order'], integration['collMethod']))
+    pts = computeDiscretizationPoints(track, N)
+    opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0))
+    opts.update(integration)
+    prob = oracle.pack_problem(train, pts, opts, 2, 0.0, 0.0, track.length)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationMethod=method, integrationOptions=io), startingPoint='profile')
+    T = [272.4726*r for r in (1.1, 1.2, 1.3)]
+    res = solver.solveBatch(T, terminalVelocity=100/3.6, initialVelocity=1)
+    assert np.all(res['status'] == 0), res['status']
+    for k, t in enumerate(T):
+        ref = oracle.solve(prob, prob.scenario(t, terminalVelocity=100/3.6, initialVelocity=1), start='profile')
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+        assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('what', ['irk', 'cvodes', 'integrate_losses', 'dynamic'])
+def test_gpu_other_transcriptions_on_the_streamed_kernel(what):
+    """
+    Beyond 560 intervals the stage blocks leave LDS (simulations/table3.py:34 sweeps numIntervals up to 5000 with 'RK'; the reference
+    builds the other transcriptions at any N too): the streamed kernels of the other shooting integrators, of integrateLosses and of
+    the dynamic loss model (up to 1023 intervals) against the oracle at N = 700.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc.track import computeDiscretizationPoints
+    N = 700
+    if what == 'dynamic':
+        train, track = _dynamic_train(), cases.track_00(8500)
+        oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+        pts = computeDiscretizationPoints(track, N)
+        prob = oracle.pack_problem(train, pts, dict(numIntervals=N, maxIterations=1000, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1), 2, 0.0, 0.0, track.length)
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=1000, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+        T, kw = [272.4726*1.2], dict(terminalVelocity=100/3.6, initialVelocity=1)
+    else:
+        train, track = cases.train_fig10(), cases.track_00()
+        extra, io, integration = {'irk': (dict(integrationMethod='IRK'), dict(order=2, numSteps=1, numApproxSteps=1), IRK2),
+                                  'cvodes': (dict(integrationMethod='CVODES'), dict(), ADAPT),
+                                  'integrate_losses': (dict(integrateLosses=True), dict(numSteps=1, numApproxSteps=1), dict(integrateLosses=True))}[what]
+        prob = cases.oracle_problem(train, track, N, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), maxIterations=1000, integration=integration)
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=1000, integrationOptions=io, **extra), startingPoint='profile')
+        T, kw = [1600.0], {}
+    assert solver.problem.geometry() == (512, 2)
+    res = solver.solveBatch(T, **kw)
+    assert np.all(res['status'] == 0), res['status']
+    ref = oracle.solve(prob, prob.scenario(T[0], **kw), start='profile')
+    assert ref['stats']['STATUS'] == 0
+    assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+    assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+    assert abs(int(res['iterations'][0]) - int(ref['stats']['ITERS'])) <= 6
+    solver.close()
+
+
 @pytest.mark.gpu
 def test_gpu_stage_function_of_other_integrators_vs_oracle_and_standalone_kernels():
     """
@@ -203,11 +280,11 @@ def test_gpu_other_integrators_surface_and_limits():
     rk = casadiSolver(train, track, dict(numIntervals=100, integrationOptions=dict(numApproxSteps=1)))
     assert abs(stats['Cost'] - rk.solve(1541)[1]['Cost']) < 1e-3*stats['Cost']      # both integrate b accurately on this grid
     with pytest.raises(DeviceError):
-        casadiSolver(train, track, dict(numIntervals=700, integrationMethod='CVODES')).solve(1541)      # beyond the LDS-resident kernels
+        casadiSolver(train, track, dict(numIntervals=1100, integrationMethod='CVODES')).solve(1541)      # beyond the streamed kernels of the other integrators
     with pytest.raises(NotImplementedError):
         casadiSolver(train, track, dict(numIntervals=50, integrateLosses=True, integrationMethod='IRK'))
     with pytest.raises(DeviceError):
-        casadiSolver(train, track, dict(numIntervals=700, integrateLosses=True)).solve(1541)
+        casadiSolver(train, track, dict(numIntervals=1100, integrateLosses=True)).solve(1541)
     # integrateLosses through the reference's surface: same optimum as the mid-point rows to about 1e-4 (X = ds up to the RK4 error)
     il = casadiSolver(train, track, dict(numIntervals=100, integrateLosses=True, integrationOptions=dict(numApproxSteps=1)))
     dfi, sti = il.solve(1541)
