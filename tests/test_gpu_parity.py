@@ -773,6 +773,28 @@ def test_dynamic_losses_with_per_scenario_rolling_stock():
     assert abs(res['cost'][1] - res['cost'][0]) > 1e-3*res['cost'][0]      # the perturbation is visible in the energy
 
 
+def test_multi_handle_launches_overlap():
+    """
+    msd_solve_batch_multi launches on every handle before it copies any result back (a copy into pageable host memory holds the
+    calling thread until the kernel in front of it has finished).  Two handles on the one visible device, 256 scenarios each -- both
+    launches fit the device side by side --: the pair must take clearly less than two single launches.
+    """
+    import time
+    train, track = cases.train_default(), cases.track_00()
+    s = _solver(train, track, 100, start='profile')
+    T1, T2 = cases.c1_times(256), cases.c1_times(512)
+    s.solveBatch(T1); s.solveBatch(T2, devices=[0, 0])      # handles, buffers, first launches
+    def best(f, n=7):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    t_one = best(lambda: s.solveBatch(T1, classifyFailures=False))
+    t_two = best(lambda: s.solveBatch(T2, devices=[0, 0], classifyFailures=False))
+    assert t_two < 1.7*t_one, (t_one, t_two)
+    s.close()
+
+
 def test_single_process_multi_device_dispatch():
     """
     SURVEY 8(b)/(e): `devices[]` -- one handle and one stream per device from a single process, contiguous slices of the batch,
