@@ -1,30 +1,34 @@
 /*
  * msd_kernel.hpp -- device code of the MI355X (gfx950) batched multiple-shooting solver.
  *
- * One workgroup solves one OCP scenario from cold start to convergence in a single launch
- * (persistent over scenarios: workgroups stride through the batch).  Thread i of the workgroup
- * owns shooting node i: its state (t_i, b_i), its controls (Fel_i, Fpb_i, s_i), the slacks and
- * multipliers of interval i -- all in registers for the whole solve.  Per interior-point iteration
- *   (a) every thread integrates its interval (RK4 + first/second sensitivities by forward-mode
- *       jets) and condenses its inequality rows and bounds into a stage block     [parallel over stages]
- *   (b) the stage blocks meet in LDS where the block-tridiagonal KKT system is solved by a
- *       Riccati sweep that exploits the sparsity of the 3-state/3-control stage     [serial over stages]
- *   (c) step lengths, filter line search and updates run again one thread per stage, with
- *       wave-shuffle + LDS reductions for the norms.
- * Nothing but the scenario record, the (shared, L2-resident) track profile and the final z*
- * touches HBM.  All arithmetic is IEEE double, like the reference's CasADi/IPOPT path.
+ * One workgroup solves one OCP scenario from its starting point to convergence in a single launch (persistent over scenarios:
+ * workgroups pull scenarios from a device-wide counter).  The benchmark geometry is one wavefront per scenario with two shooting
+ * nodes per lane (solve_kernel<64, 2>): four single-wave workgroups per compute unit, one per SIMD, each with the SIMD's whole
+ * register file.  A lane owns its nodes' states (t_i, b_i), controls (Fel_i, Fpb_i, s_i), slacks and multipliers -- in registers for
+ * the whole solve; stage blocks and neighbour exchange go through LDS.  Per interior-point iteration
+ *   (a) every lane integrates its intervals (RK4 + first/second sensitivities by forward-mode jets), evaluates rows, optimality
+ *       error and filter quantities, and condenses its inequality rows and bounds into a stage block            [parallel over stages]
+ *   (b) the block-tridiagonal KKT system is solved by a stage-parallel Riccati recursion: value functions at the lanes' chunk
+ *       boundaries from an associative scan over the lanes, the ordinary recursion inside the chunks (ParallelRiccati, msd_scan.hpp);
+ *       a serial sweep on one lane remains as the fallback                                                      [log depth over stages]
+ *   (c) step lengths, filter line search and updates run per node again, with DPP wave reductions for the norms.
+ * Kernels instantiated with FULL have the structure of the reference's rolling stock compiled in and, with constant efficiencies and
+ * explicit Runge-Kutta shooting, run (a) and (c) as the fused passes of Solver::FAST (fused_pass, post_direction, merit_fast,
+ * update_fast).  Nothing but the scenario record, the (shared, L2-resident) track profile and the final z* touches HBM -- apart from
+ * register spills.  All arithmetic is IEEE double, like the reference's CasADi/IPOPT path.
  *
  * What it computes (reference = dkouzoup/ms-eetc):
  *   NLP        mseetc/ocp.py:134-284 (variables, bounds, rows, objective), cold start :325-339
- *   integrator mseetc/train.py:225-277 (ODE), :294-301 (RK4 = casadi.simpleRK), :324-344 (trapezoidal time)
- *   losses     mseetc/train.py:199-216 + mseetc/utils.py:197-220 (static efficiencies -> two linear rows)
- *   NLP solver casadi.nlpsol('ipopt') (ocp.py:290,359): IPOPT's published algorithm (Waechter & Biegler,
- *              Math. Prog. 106(1), 2006) with IPOPT's default options: monotone barrier update, filter line
- *              search with second-order correction, inertia correction, gradient-based scaling.
+ *   integrator mseetc/train.py:225-277 (ODE), :294-301 (RK4 = casadi.simpleRK), :324-344 (trapezoidal time); :303-322 (IRK, CVODES: msd_integ.hpp)
+ *   losses     mseetc/train.py:199-216 + mseetc/utils.py:197-220 (static efficiencies -> two linear rows), mseetc/efficiency.py (table),
+ *              mseetc/ocp.py:231-241 (integrateLosses: msd_lossint.hpp)
+ *   NLP solver casadi.nlpsol('ipopt') (ocp.py:290,359): IPOPT's published algorithm (Waechter & Biegler, Math. Prog. 106(1), 2006)
+ *              with IPOPT's default options: monotone barrier update, filter line search with second-order correction, inertia
+ *              correction, gradient-based scaling.
  *
- * The state of a stage is (t, b, q) with q_i := Fel_{i-1}: the control-smoothing term
- * 1e-3 (Fel_i - Fel_{i-1})^2 (ocp.py:245) and the end-of-interval power row Fel_i sqrt(b_{i+1})
- * (ocp.py:189) then are stage-local, which keeps the KKT system block tridiagonal with 3x3 blocks.
+ * The state of a stage is (t, b, q) with q_i := Fel_{i-1}: the control-smoothing term 1e-3 (Fel_i - Fel_{i-1})^2 (ocp.py:245) and
+ * the end-of-interval power row Fel_i sqrt(b_{i+1}) (ocp.py:189) then are stage-local, which keeps the KKT system block tridiagonal
+ * with 3x3 blocks.
  */
 #pragma once
 #include <type_traits>

@@ -83,3 +83,32 @@ def test_two_ranks_on_the_gpu_box():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['scenarios'] == 2048 and line['config']['converged'] == 2048
     assert line['value'] > 1e5 and 'alt' not in line and 'cpu_baseline' not in line
+
+
+def test_default_step_counts_and_options():
+    "about a second of launches per workload without flags; explicit flags win; the transcriptions map onto the reference's options"
+    a = bench.parse_args([])
+    assert (a.workload, a.steps, a.warmup, a.gpus, a.transcription, a.single_process) == ('c1', 500, 10, 1, 'rk', False)
+    assert bench.parse_args(['--workload', 'c4']).steps == 5 and bench.parse_args(['--workload', 'c4']).warmup == 1
+    assert bench.parse_args(['--workload', 'c2']).steps == 50
+    b = bench.parse_args(['--gpus', '8', '--steps', '20', '--warmup', '3', '--single-process', '--transcription', 'irk_radau2'])
+    assert (b.gpus, b.steps, b.warmup, b.single_process, b.transcription) == (8, 20, 3, True, 'irk_radau2')
+    extra, io = bench.TRANSCRIPTIONS['cvodes_tolerances']
+    assert extra == dict(integrationMethod='CVODES') and io == {}
+    assert bench.TRANSCRIPTIONS['integrate_losses'][0] == dict(integrateLosses=True)
+    assert set(bench.PER_GPU_BATCH) == {'c1', 'c2', 'c3', 'c4'} and bench.PER_GPU_BATCH['c4']*8 == 4096 and bench.PER_GPU_BATCH['c3']*8 == 65536
+
+
+def test_roofline_block_fields():
+    "the roofline object carries the contract's fields and the three fractions; without a matching traffic record the measured one is null"
+    class E:
+        @staticmethod
+        def hip_digest():
+            return 'no such digest'
+    r = bench.roofline_block(E, 'c1', 1024, 100, 502, 100*1024*20.6, 1.15, (64, 2))
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_model_S', 'frac_compulsory', 'frac_measured', 'limiter', 'launch_ms'):
+        assert key in r
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['achieved'] - 904*100*1024*20.6/1.15e-3/1e9) < 1e-6*r['achieved'] and abs(r['frac'] - r['achieved']/8000.0) < 1e-12
+    assert r['traffic'] is None and r['frac_measured'] is None
+    assert abs(r['compulsory_bytes_per_launch'] - 1024*(8*502 + 168)) < 1e-9

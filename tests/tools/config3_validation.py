@@ -4,7 +4,7 @@ success rate, iteration statistics, scan fallbacks, and the objective of a rando
 """
 import os, sys, time
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R, R + '/ms-eetc_amd']
 from mseetc import workloads as wl
 from mseetc.ocp import casadiSolver

@@ -1,7 +1,7 @@
 """Single-thread rate of the CPU oracle on config 1 (SURVEY.md 8d asks for it next to the all-core figure of bench.py)."""
 import os, sys, time
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R + '/tests', R, R + '/ms-eetc_amd']
 import cases
 from oracle import oracle

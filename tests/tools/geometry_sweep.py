@@ -1,9 +1,9 @@
 """
 Every launch geometry against the oracle on batches whose horizon is not a multiple of the slot count (the last wave has idle node
-slots): tools/geometry_sweep.py [scenarios per horizon]      (MSD_LIB selects a tuning build)
+slots): tests/tools/geometry_sweep.py [scenarios per horizon]      (MSD_LIB selects a tuning build)
 """
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R + '/tests', R, R + '/ms-eetc_amd']
 import numpy as np, cases
 from mseetc.ocp import casadiSolver
