@@ -22,6 +22,7 @@ Geometry pick_geometry_static(int N, bool full);     /* full: both brakes, power
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
+Geometry pick_geometry_general_long(int N);      /* 257 ... 640 nodes of the same family (msd_kernels_general2.hip) */
 Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
 Geometry pick_geometry_general_dynamic(int N);      /* collocation / adaptive shooting integrators with the dynamic loss model (msd_kernels_compose.hip) */
@@ -36,9 +37,6 @@ Geometry pick_geometry_intloss_full(int N);
 template <int DYN> inline Geometry pick_geometry_t(int N)
 {
     const int nodes = N + 1;
-    /* MSD_GEOMETRY=128x1 selects the one-node-per-thread variant (tuning experiments only) */
-    const char *g = getenv("MSD_GEOMETRY");
-    if constexpr (DYN != LOSS_INTEGRATED) { if (g && !strcmp(g, "128x1") && nodes <= 128) return {128, 1, solve_kernel<128, 1, 2, DYN>}; }
 #ifdef MSD_ONLY_192X2              /* debugging builds */
     return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN>} : Geometry{0, 0, nullptr};
 #endif
@@ -56,25 +54,18 @@ template <int DYN> inline Geometry pick_geometry_t(int N)
 
 /* horizons whose stage blocks do not fit the LDS of a compute unit: node fields, stage blocks and exchange arrays live in device memory, a
  * lane's nodes are worked off one after the other.  512 threads (two waves per SIMD, 256 registers each) with the stage-parallel KKT solve
- * and as few nodes per lane as the horizon allows (N = 1000: two; 38 -> 11 ms per solve against round 2's 1024 x 5 with serial sweeps);
- * MSD_STREAM_GEOMETRY=1024 selects that kernel for every horizon (tuning runs).  The instantiations are spread over two translation
- * units (msd_kernels_stream.hip, msd_kernels_stream2.hip) */
+ * and as few nodes per lane as the horizon allows (N = 1000: two; 38 -> 11 ms per solve against round 2's 1024 x 5 with serial sweeps).
+ * The instantiations are spread over two translation units (msd_kernels_stream.hip, msd_kernels_stream2.hip) */
 template <bool DYN> inline Geometry pick_stream_geometry_short_t(int N)      /* N <= 2047 */
 {
-    const char *g = getenv("MSD_STREAM_GEOMETRY");
-    if (g && !strcmp(g, "1024")) return {0, 0, nullptr};
     if (N + 1 <= 1024) return {512, 2, solve_kernel<512, 2, 2, DYN, true>, true};
     if (N + 1 <= 2048) return {512, 4, solve_kernel<512, 4, 2, DYN, true>, true};
     return {0, 0, nullptr};
 }
 template <bool DYN> inline Geometry pick_stream_geometry_long_t(int N)       /* N <= 5119 */
 {
-    const char *g = getenv("MSD_STREAM_GEOMETRY");
-    if (!(g && !strcmp(g, "1024"))) {
-        if (N + 1 <= 3072) return {512, 6, solve_kernel<512, 6, 2, DYN, true>, true};
-        if (N + 1 <= 5120) return {512, 10, solve_kernel<512, 10, 2, DYN, true>, true};
-    }
-    if (N + 1 <= 5120) return {1024, 5, solve_kernel<1024, 5, 1, DYN, true>, true};
+    if (N + 1 <= 3072) return {512, 6, solve_kernel<512, 6, 2, DYN, true>, true};
+    if (N + 1 <= 5120) return {512, 10, solve_kernel<512, 10, 2, DYN, true>, true};
     return {0, 0, nullptr};
 }
 Geometry pick_stream_geometry_static_long(int N);

@@ -19,10 +19,7 @@ Geometry pick_geometry_general(int N, bool full)
 #ifdef MSD_MINIMAL_GEOMETRIES
     return {0, 0, nullptr};
 #endif
-    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, false, false, true>};
-    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, false, false, true>};
-    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, false, false, true>};
-    return {0, 0, nullptr};
+    return pick_geometry_general_long(N);
 }
 
 }  // namespace msd
