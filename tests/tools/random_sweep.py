@@ -39,11 +39,16 @@ for seed in range(first, last):
                 pe = cases.oracle_problem(train, track, N)
                 ref = oracle.solve(pe, pe.scenario(float(T[1]), 0.0, vN, v0), start='profile')
                 dev = abs(res['cost'][1] - ref['stats']['OBJ'])/max(abs(ref['stats']['OBJ']), 1.0)      # (kWh; loose schedules on downhill tracks cost nothing)
-                if ref['stats']['STATUS'] != 0 or dev > 1e-7:
+                # two solves that end on different barrier parameters (the last barrier test looks at rounding noise: tests/test_gpu_parity.py)
+                # differ by about mu times the number of active bounds
+                same_mu = abs(res['stats'][1, 4] - ref['stats']['MU']) <= 1e-3*ref['stats']['MU']
+                if ref['stats']['STATUS'] != 0 or dev > (1e-7 if same_mu else 1e-6):
                     print('seed', seed, 'N', N, 'oracle status', ref['stats']['STATUS'], 'objective deviation', dev); bad += 1
-                cost_p = res['cost']
+                cost_p, mu_p = res['cost'], res['stats'][:, 4]
             else:
-                dev = np.max(np.abs(res['cost'] - cost_p)/np.maximum(np.abs(cost_p), 1.0))
+                rel = np.abs(res['cost'] - cost_p)/np.maximum(np.abs(cost_p), 1.0)
+                same = np.abs(res['stats'][:, 4] - mu_p) <= 1e-3*mu_p
+                dev = float(np.max(np.where(same, rel, rel/10)))      # 1e-6 on the same final barrier parameter, 1e-5 across
                 if dev > 1e-6:
                     print('seed', seed, 'N', N, 'starts disagree', dev); bad += 1
 print('seeds', first, '...', last - 1, ':', bad, 'findings')
