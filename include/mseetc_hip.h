@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 4
+#define MSD_ABI_VERSION 5
 
 /* error codes */
 #define MSD_OK 0
@@ -38,16 +38,18 @@ extern "C" {
 #define MSD_STATUS_REGULARIZATION (-3)
 #define MSD_STATUS_NUMERIC (-4)
 #define MSD_STATUS_TINY_STEP (-5)
-/* set by the host layer only (mseetc/ocp.py: _classify_failures), from the minimum-running-time certificate of a failed scenario:
- * IPOPT's 'Infeasible_Problem_Detected' */
+/* IPOPT's 'Infeasible_Problem_Detected': the feasibility restoration phase (ocp.py:290,359 -> IPOPT; msd_resto.hpp) converged to a stationary
+ * point of the infeasibility.  Also set by the host layer (mseetc/ocp.py: _classify_failures) from the minimum-running-time certificate of a
+ * scenario that failed in another way (MSD_STATUS_LINESEARCH = IPOPT's 'Restoration_Failed': the restoration phase itself broke down) */
 #define MSD_STATUS_INFEASIBLE (-6)
 
 /*
  * Starting point of a solve.  REFERENCE: the reference's cold start (ocp.py:325-339: Fel 0.5, Fpb -0.1, s 1, t linear,
  * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
  * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the
- * iterations.  A scenario that breaks down from its starting point (any failure but the iteration limit) is solved again from the
- * other one inside the same launch: where IPOPT would enter its restoration phase, the solver restarts.
+ * iterations.  A scenario whose line search breaks down enters the feasibility restoration phase like in IPOPT (msd_resto.hpp; kernels
+ * with static loss rows, N <= 560, unless no_restoration is set); one that still ends with a breakdown (any failure but the iteration
+ * limit and MSD_STATUS_INFEASIBLE) is solved again from the other starting point inside the same launch.
  */
 #define MSD_START_REFERENCE 0
 #define MSD_START_PROFILE 1
@@ -64,6 +66,7 @@ enum {
     MSD_ST_CYC_TOTAL,    /* shader clock cycles the scenario's workgroup spent in the solve (telemetry)       */
     MSD_ST_CYC_KKT,      /* ... of which inside the serial stage recursion of the KKT solves (fallback path)  */
     MSD_ST_N_FALLBACK,   /* KKT solves that fell back from the stage-parallel scan to the serial sweep        */
+    MSD_ST_N_RESTO,      /* restoration phases entered                                                        */
     MSD_ST_COUNT
 };
 
@@ -111,7 +114,9 @@ typedef struct msd_problem_desc {
     int newton_iterations;   /* 'IRK': OptionsIRK.maxIter (train.py:493)                       */
     int integrate_losses;    /* OptionsCasadiSolver.integrateLosses (ocp.py:28,231-241): loss slacks [J/kg per interval] bound the loss power integrated
                               * over the running time of the interval; constant efficiencies (loss_kind 1), 'RK' shooting                          */
-    int reserved_i[2];
+    int no_restoration;      /* 1: no feasibility restoration phase -- a solve whose line search breaks down ends with MSD_STATUS_LINESEARCH (after the
+                              * restart from the other starting point), like ABI 4.  0 (default): IPOPT's behaviour                                         */
+    int reserved_i[1];
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
     double g, rho;
     double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */

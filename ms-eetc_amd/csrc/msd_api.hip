@@ -233,6 +233,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
     P.coll = (d->integrator == MSD_INTEGRATOR_COLLOCATION) ? h->d_coll : nullptr;
+    P.resto = d->no_restoration ? 0 : 1;
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
 
     int per_cu = 0, cus = 0;

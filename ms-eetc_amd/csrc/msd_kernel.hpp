@@ -126,6 +126,7 @@ struct DevProb {
     int collD, newtonIters;  /* collocation points per step, Newton iterations (OptionsIRK.order, .maxIter) */
     double intAtol, intRtol; /* OptionsCVODES.absTol, .relTol */
     const double *coll;      /* C[(collD+1)^2], D[collD+1] of casadi.simpleIRK */
+    int resto;               /* feasibility restoration phase where the line search breaks down (IPOPT's behaviour; msd_resto.hpp) */
 };
 
 /* IPOPT default option values */
@@ -571,12 +572,19 @@ template <int CNT, int NS> struct Field<CNT, NS, true> {
 
 /* layout of the work area, in fields of NS doubles */
 constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_ZLS = 27, W_ZUS = 32, W_DSG = 37, W_RESC = 42, W_RESD = 44,
-              W_EV = 49, W_LG = 62, W_FIELDS = 72;
+              W_EV = 49, W_LG = 62, W_FIELDS_ITERATE = 72;
+/* behind the iterate: what the feasibility restoration phase keeps (msd_resto.hpp; kernels whose horizon fits the LDS only).  Row scaling of the
+ * dynamics (2), the relaxation variables n, p and their multipliers per relaxed row (4 x 7), their steps (4 x 7), the reference point (x 5,
+ * sigma 5), the bound multipliers of the original problem (20), D of the two dynamics rows (2), the steps of the row multipliers (5), the filter of
+ * the restoration problem (2 fields >= 2 FILT_CAP doubles), one field of scalars handed between the two iterations and five fields (>= 320
+ * doubles) for the dense temporaries of riccati_resto -- on the stack they would size the scratch memory of every launch of the kernel */
+constexpr int W_SC = 72, W_RN = 74, W_RP = 81, W_RZN = 88, W_RZP = 95, W_RDN = 102, W_RDP = 109, W_RDZN = 116, W_RDZP = 123, W_XR = 130, W_SGR = 135,
+              W_OZL = 140, W_OZU = 145, W_OZLS = 150, W_OZUS = 155, W_RD = 160, W_DNU = 162, W_RFILT = 167, W_SCAL = 169, W_RTMP = 170, W_FIELDS = 175;
 __host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
 /* work area of a workgroup of the streamed (long-horizon) kernel: node fields, stage blocks, six exchange arrays */
 __host__ __device__ constexpr size_t stream_doubles(int N, int node_slots, bool dyn)
 {
-    return (size_t)W_FIELDS*node_slots + (size_t)(dyn ? 31 : 27)*(N + 1) + 6*(size_t)node_slots;
+    return (size_t)W_FIELDS_ITERATE*node_slots + (size_t)(dyn ? 31 : 27)*(N + 1) + 6*(size_t)node_slots;
 }
 
 template <int NS, bool STREAM>
@@ -860,6 +868,161 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
     for (int i = 0; i < N - 1; i++) forward(i, std::false_type());
     forward(N - 1, std::true_type());
     S[N*S_STRIDE + S_DT] = dt; S[N*S_STRIDE + S_DB] = 0.0; S[N*S_STRIDE + S_DF] = 0.0;
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Serial sweeps of the restoration problem's Newton system (cold path, one lane; msd_resto.hpp assembles the blocks).  The two
+ * dynamics rows of an interval are relaxed there: x+ = F y + r + D lam+ on (t, b), with D = n/z_n + p/z_p > 0 of the row (unscaled).  The
+ * value function of stage i+1 enters stage i through  P~ = P - P[:,tb] M P[tb,:],  M = (P2 + D^-1)^-1 = D^1/2 (I + D^1/2 P2 D^1/2)^-1 D^1/2,
+ * and the forward sweep takes lam+ = -(I + P2 D)^-1 (P a + p) from the relaxed rows themselves (a = F y + r), so that their linearisation
+ * holds to rounding.  b_N stays a parameter: in the last interval df is eliminated through  F_b y + r_b = -sqrt(D_b) v  with
+ * v = sqrt(D_b) lam_b+ of unit curvature in the slot of df -- the hard elimination of riccati_solve in the limit D_b -> 0.
+ * Leaves (dt, db, df, dp, ds) and the new multipliers (lt, lb) of every interval in its block.  Static loss rows only.
+ * ---------------------------------------------------------------------------------------- */
+template <int DYN>
+__device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S, const double *Dtv, const double *Dbv, double *tmp)
+{
+    static_assert(DYN == LOSS_STATIC, "restoration phase: static loss rows");
+    constexpr int S_STRIDE = stage_stride(DYN);
+    /* every array of the sweeps lives in `tmp` (work area), not on the stack: the stack of this cold function would size the scratch memory of
+     * every launch of the kernel (a launch whose scratch need exceeds the runtime's standing allocation pays for it: config 2 lost a third) */
+    double (*P)[3] = reinterpret_cast<double (*)[3]>(tmp + 198), *pv = tmp + 207;
+    double (*Pt)[3] = reinterpret_cast<double (*)[3]>(tmp + 210), *pt = tmp + 219, (*L)[3] = reinterpret_cast<double (*)[3]>(tmp + 222);
+    double (*K)[4] = reinterpret_cast<double (*)[4]>(tmp + 231), *h = tmp + 243, *g = tmp + 249, *gy = tmp + 255, *g2 = tmp + 261, *Pr = tmp + 267;
+    double (*F)[6] = reinterpret_cast<double (*)[6]>(tmp + 270), *r = tmp + 288;
+    for (int a = 0; a < 3; a++) { pv[a] = 0; for (int b = 0; b < 3; b++) P[a][b] = 0; }
+    P[0][0] = S[N*S_STRIDE + S_HTT]; pv[0] = S[N*S_STRIDE + S_HT];
+    bool ok = true;
+#pragma unroll 1
+    for (int i = N - 1; i >= 0; i--) {
+        double *s = S + i*S_STRIDE;
+        const bool last = i == N - 1;
+        const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+        const double Dt = Dtv[i], Db = Dbv[i];
+        double (*H)[6] = reinterpret_cast<double (*)[6]>(tmp), (*G)[6] = reinterpret_cast<double (*)[6]>(tmp + 36), (*T)[6] = reinterpret_cast<double (*)[6]>(tmp + 72),
+               (*GT)[6] = reinterpret_cast<double (*)[6]>(tmp + 108), (*G2)[6] = reinterpret_cast<double (*)[6]>(tmp + 144), (*PF)[6] = reinterpret_cast<double (*)[6]>(tmp + 180);
+        for (int a = 0; a < 6; a++) { h[a] = 0; for (int b = 0; b < 6; b++) H[a][b] = 0; }
+        H[0][0] = s[S_HTT]; H[1][1] = s[S_HBB]; H[1][2] = H[2][1] = s[S_HBQ]; H[1][3] = H[3][1] = s[S_HBF]; H[1][4] = H[4][1] = s[S_HBP];
+        H[2][2] = s[S_HQQ]; H[2][3] = H[3][2] = s[S_HQF]; H[3][3] = s[S_HFF]; H[3][4] = H[4][3] = s[S_HFP]; H[4][4] = s[S_HPP];
+        h[0] = s[S_HT]; h[1] = s[S_HB]; h[2] = s[S_HQ]; h[3] = s[S_HF]; h[4] = s[S_HP];
+        if (last) { H[3][5] = H[5][3] = s[S_GFS]; H[5][5] = 1.0/s[S_IS]; h[5] = s[S_GS]; }      /* the last interval keeps its s row */
+        else H[5][5] = 1.0;
+        /* value function of stage i+1 as it is, for the forward sweep */
+        s[S_PN + 0] = P[0][0]; s[S_PN + 1] = P[0][1]; s[S_PN + 2] = P[0][2]; s[S_PN + 3] = P[1][1]; s[S_PN + 4] = P[1][2]; s[S_PN + 5] = P[2][2];
+        s[S_PV + 0] = pv[0]; s[S_PV + 1] = pv[1]; s[S_PV + 2] = pv[2];
+        /* through the relaxed rows */
+        double M00, M01, M11;
+        if (last) {
+            const double den = 1 + P[0][0]*Dt;
+            if (!(den > 0)) ok = false;
+            M00 = Dt/den; M01 = 0; M11 = 0;
+        } else {
+            const double st = sqrt(Dt), sb = sqrt(Db);
+            const double ma = 1 + st*P[0][0]*st, mb = st*P[0][1]*sb, mc = 1 + sb*P[1][1]*sb, det = ma*mc - mb*mb;
+            if (!(det > 0) || !(ma > 0)) ok = false;
+            M00 = st*(mc/det)*st; M01 = -st*(mb/det)*sb; M11 = sb*(ma/det)*sb;
+        }
+        for (int a = 0; a < 3; a++) {
+            const double q0 = P[a][0]*M00 + P[a][1]*M01, q1 = P[a][0]*M01 + P[a][1]*M11;
+            for (int b = 0; b < 3; b++) Pt[a][b] = P[a][b] - (q0*P[0][b] + q1*P[1][b]);
+            pt[a] = pv[a] - (q0*pv[0] + q1*pv[1]);
+        }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 6; b++) F[a][b] = 0;
+        F[0][0] = 1; F[0][1] = Tb; F[0][3] = Tw; F[0][4] = pn ? Tw : 0.0; F[1][1] = Bb; F[1][3] = Bw; F[1][4] = pn ? Bw : 0.0; F[2][3] = 1;
+        r[0] = rt; r[1] = last ? 0.0 : rb; r[2] = 0;
+        /* G = H + F^T P~ F, g = h + F^T (P~ r + p~) */
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 6; b++) PF[a][b] = Pt[a][0]*F[0][b] + Pt[a][1]*F[1][b] + Pt[a][2]*F[2][b];
+            Pr[a] = pt[a] + Pt[a][0]*r[0] + Pt[a][1]*r[1] + Pt[a][2]*r[2];
+        }
+        for (int a = 0; a < 6; a++) {
+            for (int b = 0; b < 6; b++) G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b];
+            g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2];
+        }
+        if (!pn) { for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0; G[4][4] = 1; g[4] = 0; }
+        if (last) {
+            /* df = eb db - dp + e0 - kap v */
+            const double eb = -Bb/Bw, e0 = -rb/Bw, kap = sqrt(Db)/Bw;
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) T[a][b] = a == b ? 1.0 : 0.0;
+            T[3][3] = -kap; T[3][1] = eb; T[3][4] = pn ? -1.0 : 0.0;
+
+            for (int a = 0; a < 6; a++) {
+                for (int b = 0; b < 6; b++) { double v = 0; for (int m = 0; m < 6; m++) v += G[a][m]*T[m][b]; GT[a][b] = v; }
+                gy[a] = g[a] + G[a][3]*e0;
+            }
+            for (int a = 0; a < 6; a++) {
+                for (int b = 0; b < 6; b++) { double v = 0; for (int m = 0; m < 6; m++) v += T[m][a]*GT[m][b]; G2[a][b] = v; }
+                double v = 0; for (int m = 0; m < 6; m++) v += T[m][a]*gy[m]; g2[a] = v;
+            }
+            G2[3][3] += 1.0;
+            for (int a = 0; a < 6; a++) { for (int b = 0; b < 6; b++) G[a][b] = G2[a][b]; g[a] = g2[a]; }
+        }
+        /* eliminate the controls: (f, p), in the last interval (v, p, s) */
+        const int nu = last ? 3 : 2;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) L[a][b] = 0;
+        for (int j = 0; j < nu; j++) {
+            double d = G[3 + j][3 + j];
+            for (int k = 0; k < j; k++) d -= L[j][k]*L[j][k];
+            if (!(d > 0) || !isfinite(d)) { ok = false; d = 1.0; }
+            L[j][j] = sqrt(d);
+            for (int a = j + 1; a < nu; a++) {
+                double v = G[3 + a][3 + j];
+                for (int k = 0; k < j; k++) v -= L[a][k]*L[j][k];
+                L[a][j] = v/L[j][j];
+            }
+        }
+        for (int c = 0; c < 4; c++) {      /* K: columns t, b, q and the constant */
+            double y[3], x[3];
+            for (int a = 0; a < nu; a++) { double v = -(c < 3 ? G[3 + a][c] : g[3 + a]); for (int k = 0; k < a; k++) v -= L[a][k]*y[k]; y[a] = v/L[a][a]; }
+            for (int a = nu - 1; a >= 0; a--) { double v = y[a]; for (int k = a + 1; k < nu; k++) v -= L[k][a]*x[k]; x[a] = v/L[a][a]; }
+            for (int a = 0; a < 3; a++) K[a][c] = a < nu ? x[a] : 0.0;
+        }
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) { double v = G[a][b]; for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][b]; P[a][b] = v; }
+            double v = g[a]; for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][3]; pv[a] = v;
+        }
+        for (int a = 0; a < 3; a++) for (int b = a + 1; b < 3; b++) { const double m = 0.5*(P[a][b] + P[b][a]); P[a][b] = P[b][a] = m; }
+        if (!pn) { K[1][0] = K[1][1] = K[1][2] = K[1][3] = 0; }
+        s[S_K + 0] = K[0][0]; s[S_K + 1] = K[0][1]; s[S_K + 2] = K[0][2]; s[S_K + 3] = K[1][0]; s[S_K + 4] = K[1][1]; s[S_K + 5] = K[1][2];
+        s[S_KV + 0] = K[0][3]; s[S_KV + 1] = K[1][3];
+        if (last) { s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3]; }
+    }
+    if (!ok) return false;
+
+    double x0 = 0, x1 = 0, x2 = 0;      /* (dt, db, dq) of the stage; x_0 is a parameter */
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        double *s = S + i*S_STRIDE;
+        const bool last = i == N - 1;
+        const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+        const double Dt = Dtv[i], Db = Dbv[i];
+        const double u0 = s[S_K + 0]*x0 + s[S_K + 1]*x1 + s[S_K + 2]*x2 + s[S_KV + 0];
+        const double u1 = pn ? s[S_K + 3]*x0 + s[S_K + 4]*x1 + s[S_K + 5]*x2 + s[S_KV + 1] : 0.0;
+        double df, dsl;
+        const double dp = u1;
+        if (last) {
+            dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
+            df = -Bb/Bw*x1 - dp - rb/Bw - sqrt(Db)/Bw*u0;
+        } else {
+            df = u0;
+            dsl = -(s[S_GS] + s[S_GFS]*df)*s[S_IS];
+        }
+        const double dw = df + dp;
+        const double at = x0 + Tb*x1 + Tw*dw + rt, ab = last ? 0.0 : Bb*x1 + Bw*dw + rb;
+        const double Ptt = s[S_PN + 0], Ptb = s[S_PN + 1], Ptq = s[S_PN + 2], Pbb = s[S_PN + 3], Pbq = s[S_PN + 4];
+        const double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
+        double lt, lb, nt, nb;
+        if (last) { lt = -g0/(1 + Ptt*Dt); lb = u0/sqrt(Db); nt = at + Dt*lt; nb = 0; }
+        else {
+            const double a00 = 1 + Ptt*Dt, a01 = Ptb*Db, a10 = Ptb*Dt, a11 = 1 + Pbb*Db, det = a00*a11 - a01*a10;
+            lt = -(a11*g0 - a01*g1)/det; lb = -(a00*g1 - a10*g0)/det;
+            nt = at + Dt*lt; nb = ab + Db*lb;
+        }
+        s[S_DT] = x0; s[S_DB] = x1; s[S_DF] = df; s[S_DP] = dp; s[S_DS] = dsl; s[S_LT] = lt; s[S_LB] = lb;
+        x0 = nt; x1 = nb; x2 = df;
+    }
+    S[N*S_STRIDE + S_DT] = x0; S[N*S_STRIDE + S_DB] = 0.0; S[N*S_STRIDE + S_DF] = 0.0;
     return true;
 }
 
@@ -1313,7 +1476,7 @@ struct ParallelRiccati {
  * workgroups per CU, one per SIMD, each with the whole 512-entry register file of its SIMD,
  * so the complete iterate of two nodes stays in registers and barriers are wave-local.
  * ---------------------------------------------------------------------------------------- */
-enum { MODE_NEWTON = 0, MODE_LSQ = 1 };
+enum { MODE_NEWTON = 0, MODE_LSQ = 1, MODE_RESTO = 2 };      /* (MODE_RESTO: Newton system of the restoration problem, msd_resto.hpp) */
 
 template <int NT, int SPT, int DYN, bool STREAM, bool GEN, bool FULL>
 struct Solver {
@@ -1610,7 +1773,8 @@ struct Solver {
      */
     struct Err { double dual, primal, primal_u, cmax, cmin, sd, sc, theta, L, D, obj; };
 
-    __device__ __forceinline__ void kkt_pass(Err &E)
+    struct RsSums { double theta, np, lognp, prox; };      /* restoration: 1-norm of the relaxed rows, sum(n + p), sum log(n p), |D_R (x - x_R)|^2 */
+    __device__ __forceinline__ void kkt_pass(Err &E, const bool resto = false, const double eta = 0.0, const double rho = 0.0, RsSums *RS = nullptr)
     {
         Ev e[SPT];
 #pragma unroll
@@ -1618,6 +1782,7 @@ struct Solver {
         double gl[SPT][NV];
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;
         double th = 0, logs = 0, damp = 0, obj = 0;
+        double rs_th = 0, rs_np = 0, rs_log = 0, rs_prox = 0, rs_prim = 0;
         LogSum lsum;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
@@ -1632,6 +1797,7 @@ struct Solver {
                 row_grads(j, e[j], gb, gf, gp, gs, gb1, gd);
                 double of, op, os, oq, off, opp;
                 obj_grads(j, q, of, op, os, oq, off, opp);
+                if (resto) { of = op = os = oq = 0; }
                 gl[j][VF] = of; gl[j][VP] = op; gl[j][VS] = os; out_q = oq;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
@@ -1662,7 +1828,23 @@ struct Solver {
                     if (!rL(r) && rU(r)) damp += U.dU[r] - nd.sg[r];
                     dual = fmax(dual, fabs(gsl));
                 }
-            } else if (nd.i == P.N && !energyOpt()) gl[j][VT] = U.sf/P.objDen;
+                if (resto) {
+                    /* optimality error of the restoration problem: the relaxed rows row + n - p, stationarity in (n, p), their complementarity */
+#pragma unroll
+                    for (int jr = 0; jr < 2 + NR; jr++) {
+                        if (!rs_on(jr)) continue;
+                        const double row = jr == 0 ? nd.sct*resc[j][0] : jr == 1 ? nd.scb*resc[j][1] : resd[j][jr >= 2 ? jr - 2 : 0];
+                        const double y = jr == 0 ? nd.lam[0]/nd.sct : jr == 1 ? nd.lam[1]/nd.scb : nd.nu[jr >= 2 ? jr - 2 : 0];
+                        const double rn = wf(W_RN + jr, nd.i), rp = wf(W_RP + jr, nd.i), zn = wf(W_RZN + jr, nd.i), zp = wf(W_RZP + jr, nd.i);
+                        const double v = fabs(row + rn - rp);
+                        rs_prim = fmax(rs_prim, v); rs_th += v;
+                        dual = fmax(dual, fmax(fabs(rho + y - zn), fabs(rho - y - zp)));
+                        cmax = fmax(cmax, fmax(rn*zn, rp*zp)); cmin = fmin(cmin, fmin(rn*zn, rp*zp));
+                        sumz += zn + zp; nz += 2;
+                        rs_np += rn + rp; rs_log += log(rn) + log(rp);
+                    }
+                }
+            } else if (nd.i == P.N && !energyOpt() && !resto) gl[j][VT] = U.sf/P.objDen;
             if (nd.node()) {
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
@@ -1692,12 +1874,14 @@ struct Solver {
             for (int k = 0; k < NV; k++) {
                 if (!nd.on(k)) continue;
                 double g = gl[j][k];
+                if (resto) { const double xr = wf(W_XR + k, nd.i), dr = 1.0/fmax(1.0, fabs(xr)), qv = dr*(nd.x[k] - xr); g += eta*dr*qv; rs_prox += qv*qv; }
                 { const double s = nd.x[k] - lbv(k); g -= nd.zL[k]; const double cp = s*nd.zL[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zL[k]; nz += 1; }
                 if (hasU(k)) { const double s = ubv(j, k) - nd.x[k]; g += nd.zU[k]; const double cp = s*nd.zU[k]; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += nd.zU[k]; nz += 1; }
                 dual = fmax(dual, fabs(g));
             }
         }
         logs = lsum.value();
+        if (resto) prim = rs_prim;
         double vm[5] = {dual, prim, prim_u, cmax, -cmin};
         block_reduce<5>(vm, OpMax(), c);
         double vs[8] = {sumlam, sumz, nlam, nz, th, logs, damp, obj};
@@ -1706,6 +1890,11 @@ struct Solver {
         E.sd = uni(fmax(K_SMAX, (vs[0] + vs[1])/fmax(1.0, vs[2] + vs[3]))/K_SMAX);
         E.sc = uni(fmax(K_SMAX, vs[1]/fmax(1.0, vs[3]))/K_SMAX);
         E.theta = uni(vs[4]); E.L = uni(vs[5]); E.D = uni(vs[6]); E.obj = uni(vs[7]);
+        if (resto) {
+            double vr[4] = {rs_th, rs_np, rs_log, rs_prox};
+            block_reduce<4>(vr, OpSum(), c);
+            RS->theta = uni(vr[0]); RS->np = uni(vr[1]); RS->lognp = uni(vr[2]); RS->prox = uni(vr[3]);
+        }
     }
     __device__ static __forceinline__ double compl_err(const Err &E, double mu_) { return (E.cmax >= E.cmin) ? fmax(fabs(E.cmax - mu_), fabs(E.cmin - mu_)) : 0.0; }
     __device__ static __forceinline__ double total_err(const Err &E, double mu_) { return fmax(E.dual/E.sd, fmax(E.primal, compl_err(E, mu_)/E.sc)); }
@@ -1714,7 +1903,7 @@ struct Solver {
      * Condensed stage block of every node into LDS (W&B eq. (13) with slacks and bound multipliers eliminated).
      * MODE_LSQ: least-squares multiplier system (W = 0, Sigma = I, gradient = grad f - zL + zU).
      */
-    __device__ __forceinline__ void assemble(const int mode, double mu_, double dw)
+    __device__ __forceinline__ void assemble(const int mode, double mu_, double dw, const double eta = 0.0)
     {
         Ev e[SPT];
 #pragma unroll
@@ -1736,8 +1925,9 @@ struct Solver {
                 const double rt = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0;
                 double of, op, os, oq, off, opp;
                 obj_grads(j, q, of, op, os, oq, off, opp);
+                if (mode == MODE_RESTO) { of = op = os = oq = off = opp = 0; }      /* the restoration problem has no objective but the proximity term */
                 hf = of; hp = op; hs = os; hq = oq;
-                if (mode == MODE_NEWTON) {
+                if (mode != MODE_LSQ) {
                     Hff = off; Hpp = opp;
                     if (energyOpt() && nd.i > 0) { Hqq = off; Hqf = -off; }
                     /* - lam_t hess(tau) - lam_b hess(b+) */
@@ -1785,6 +1975,12 @@ struct Solver {
                     if (!rowOn(r)) continue;
                     double Sg, coef;
                     if (mode == MODE_NEWTON) { double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw; coef = Sg*(resd[j][r] + gd[r]*rt) + gphi; }
+                    else if (mode == MODE_RESTO) {
+                        /* relaxed row: Sigma -> 1/(D + 1/Sigma); resd carries rhat */
+                        double gphi; row_terms(j, r, mu_, Sg, gphi); Sg += dw;
+                        const double St = 1.0/(rs_D(nd.i, 2 + r) + 1.0/Sg);
+                        coef = St*resd[j][r] + gphi*St/Sg; Sg = St;
+                    }
                     else { Sg = 1.0; coef = -nd.zLs[r] + nd.zUs[r]; }
                     hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
                     Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
@@ -1793,7 +1989,7 @@ struct Solver {
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
                     if (DYN) { Hbs += Sg*gb[r]*gs[r]; Hps += Sg*gp[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
-            } else if (nd.i == P.N && !energyOpt()) ht = U.sf/P.objDen;
+            } else if (nd.i == P.N && !energyOpt() && mode != MODE_RESTO) ht = U.sf/P.objDen;
             /* bounds of the node's own variables + regularisation */
             if (nd.node()) {
                 double Sv[NV], gv[NV];
@@ -1802,13 +1998,19 @@ struct Solver {
                     Sv[k] = 0; gv[k] = 0;
                     if (!nd.on(k)) continue;
                     if (mode == MODE_NEWTON) { var_terms(j, k, mu_, Sv[k], gv[k]); Sv[k] += dw; }
+                    else if (mode == MODE_RESTO) {
+                        var_terms(j, k, mu_, Sv[k], gv[k]); Sv[k] += dw;
+                        const double xr = wf(W_XR + k, nd.i), dr = 1.0/fmax(1.0, fabs(xr)), w = eta*dr*dr;      /* eta/2 |D_R (x - x_R)|^2 */
+                        Sv[k] += w; gv[k] += w*(nd.x[k] - xr);
+                    }
                     else { Sv[k] = 1.0; gv[k] = -nd.zL[k] + nd.zU[k]; }
                 }
                 Htt += Sv[VT]; ht += gv[VT]; Hbb += Sv[VB]; hb += gv[VB]; Hff += Sv[VF]; hf += gv[VF]; Hpp += Sv[VP]; hp += gv[VP]; Hss += Sv[VS]; hs += gv[VS];
                 double *s = c.S + nd.i*S_STRIDE;
                 if (nd.ival()) {
                     s[S_TB] = e[j].tb; s[S_TW] = e[j].tw; s[S_BB] = e[j].Bb; s[S_BW] = e[j].Bw;
-                    s[S_RT] = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0; s[S_RB] = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
+                    s[S_RT] = (mode == MODE_NEWTON) ? -resc[j][0] : (mode == MODE_RESTO) ? -resc[j][0]/nd.sct : 0.0;
+                    s[S_RB] = (mode == MODE_NEWTON) ? -resc[j][1] : (mode == MODE_RESTO) ? -resc[j][1]/nd.scb : 0.0;
                 }
                 if (nd.ival()) {
                     /* everything that does not depend on the value function is folded in here, off the serial path: the couplings
@@ -2022,7 +2224,8 @@ struct Solver {
     }
 
     /* theta (1-norm of the scaled constraint rows), barrier objective and validity of the point x + alpha d */
-    __device__ __forceinline__ void merit(double alpha, double mu_, double &theta, double &phi, bool &ok)
+    __device__ __forceinline__ void merit(double alpha, double mu_, double &theta, double &phi, bool &ok, const bool resto = false, const double eta = 0.0,
+                                          const double rho = 0.0)
     {
         double xt[SPT][NV], st[SPT][NR];
         trial_point(alpha, xt, st);
@@ -2037,11 +2240,23 @@ struct Solver {
             if (nd.ival()) {
                 double cv[2], dv[NR]; Ev dummy;
                 eval_interval<false, DYN, GEN, FULL>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
-                th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
+                if (!resto) th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
+                else {
+                    /* restoration problem: relaxed rows with the trial (n, p); barrier and penalty terms of (n, p) */
+#pragma unroll
+                    for (int jr = 0; jr < 2 + NR; jr++) {
+                        if (!rs_on(jr)) continue;
+                        const double row = jr == 0 ? nd.sct*cv[0] : jr == 1 ? nd.scb*cv[1] : dv[jr >= 2 ? jr - 2 : 0] - st[j][jr >= 2 ? jr - 2 : 0];
+                        const double rn = wf(W_RN + jr, nd.i) + alpha*wf(W_RDN + jr, nd.i), rp = wf(W_RP + jr, nd.i) + alpha*wf(W_RDP + jr, nd.i);
+                        th += fabs(row + rn - rp);
+                        if (rn <= 0 || rp <= 0) bad = 1; else lsum.add(rn*rp);
+                        damp += rn + rp; obj += rho*(rn + rp);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     if (!rowOn(r)) continue;
-                    th += fabs(dv[r] - st[j][r]);
+                    if (!resto) th += fabs(dv[r] - st[j][r]);
                     if (rL(r)) { const double s = st[j][r] - U.dL[r]; if (s <= 0) bad = 1; else prod *= s; }
                     if (rU(r)) { const double s = U.dU[r] - st[j][r]; if (s <= 0) bad = 1; else prod *= s; }
                     if (rL(r) && !rU(r)) damp += st[j][r] - U.dL[r];
@@ -2055,8 +2270,9 @@ struct Solver {
                     { const double s = xt[j][k] - lbv(k); if (s <= 0) bad = 1; else prod *= s; }
                     if (hasU(k)) { const double s = ubv(j, k) - xt[j][k]; if (s <= 0) bad = 1; else prod *= s; }
                     else damp += xt[j][k] - lbv(k);
+                    if (resto) { const double xr = wf(W_XR + k, nd.i), qv = (xt[j][k] - xr)/fmax(1.0, fabs(xr)); obj += 0.5*eta*qv*qv; }
                 }
-                obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
+                if (!resto) obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
             }
             lsum.add(prod);
         }
@@ -2696,9 +2912,22 @@ struct Solver {
      * FL: the fused iteration of the FAST kernels (no least-squares multiplier estimate: profile start or primal-dual warm start only);
      * it returns STATUS_GENERAL when something rare asks for the general iteration, and the caller solves the scenario again with FL = false */
     static constexpr int STATUS_GENERAL = -100;
+#include "msd_resto.hpp"
+
+    /* the general iteration hands a scenario whose line search broke down to the restoration phase (STATUS_RESTO, the iterate parked in the
+     * work area) and is entered again with `resume` afterwards: kernels with static loss rows whose horizon fits the LDS */
+#ifndef MSD_RESTO
+#define MSD_RESTO 1      /* 0: kernels without the restoration phase (A/B builds) */
+#endif
+#ifndef MSD_RESTO_VARIANT
+#define MSD_RESTO_VARIANT 0
+#endif
+    static constexpr bool HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM;
+    static constexpr int STATUS_RESTO = -101;
+
     template <bool FL>
     __device__ __forceinline__ int run(const double *scen, const double *guess, const double *dual_in, int startKind, int iter_offset, int &iters_out,
-                                       double *z_out, double *lam_out, double *dual_out, double *stats, double *hist, int hist_cap)
+                                       double *z_out, double *lam_out, double *dual_out, double *stats, double *hist, int hist_cap, const bool resume = false)
     {
         const int N = P.N;
         const bool ext = guess != nullptr;
@@ -2751,6 +2980,8 @@ struct Solver {
             nd.lam[0] = nd.lam[1] = 0;
             nd.sct = nd.scb = 1;
         }
+        double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
+        if (!(HAS_RESTO && !FL && resume)) {
         if (!ext && startKind == MSD_START_PROFILE) profile_start(t0, tEnd, v0sq, vNsq);
         Uni u;     /* built in registers (uniform), published to the LDS copy every phase reads */
         u.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); u.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
@@ -2860,7 +3091,6 @@ struct Solver {
             }
         }
 
-        double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
 
         /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
         if constexpr (!FL)
@@ -2894,16 +3124,30 @@ struct Solver {
                 for (int r = 0; r < NR; r++) { nd.nu[r] = (tk && rowOn(r)) ? nd.dsg[r] : 0.0; nd.dsg[r] = 0; }
             }
         }
+        }      /* (start-up; skipped when the iteration is resumed after a restoration phase) */
 
         int nfilt = 0;
         double delta_last = 0, theta_max = 0, theta_min = 0;
         int status = MSD_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
-        int n_reg = 0, n_soc = 0, n_back = 0;
+        int n_reg = 0, n_soc = 0, n_back = 0, n_resto = 0, iter_first = 0, forced = 0;
         Err E;
         double alpha_pr = 0, alpha_du = 0, dnorm = 0, objv = 0;
         const double mu_floor = fmin(P.tol, 1e-4)/(K_EPS + 1.0);
+        if constexpr (HAS_RESTO && !FL) {
+            if (resume) {
+                /* the iterate from the work area (the restoration phase left the new point there), the scalars of the interrupted iteration */
+                fetch<H_ALL>();
+#pragma unroll
+                for (int j = 0; j < SPT; j++) { n[j].sct = wf(W_SC, n[j].i); n[j].scb = wf(W_SC + 1, n[j].i); }
+                mu = uni(wf(W_SCAL, SC_MU)); tau = fmax(K_TAU_MIN, 1 - mu);
+                iter_first = (int)uni(wf(W_SCAL, SC_ITER)); nfilt = (int)uni(wf(W_SCAL, SC_NFILT));
+                theta_max = uni(wf(W_SCAL, SC_THETA_MAX)); theta_min = uni(wf(W_SCAL, SC_THETA_MIN)); delta_last = uni(wf(W_SCAL, SC_DELTA_LAST));
+                n_reg = (int)uni(wf(W_SCAL, SC_N_REG)); n_soc = (int)uni(wf(W_SCAL, SC_N_SOC)); n_back = (int)uni(wf(W_SCAL, SC_N_BACK));
+                n_resto = (int)uni(wf(W_SCAL, SC_N_RESTO)); forced = (int)uni(wf(W_SCAL, SC_FORCED));
+            }
+        }
 
-        for (iter = 0;; iter++) {
+        for (iter = iter_first;; iter++) {
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
             double h0[SPT][HV], h1[SPT][HV];
             if constexpr (FL) {
@@ -2918,13 +3162,14 @@ struct Solver {
                 fused_pass(iter == 0, E, h0, h1);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
                 c.mark(PH_KKT); phase_fence(PH_KKT);
             } else {
-                if (iter > 0) evaluate_current();
+                if (iter > 0 || (HAS_RESTO && !FL && resume)) evaluate_current();
                 c.mark(PH_EVAL); phase_fence(PH_EVAL);
                 kkt_pass(E);
                 c.mark(PH_KKT); phase_fence(PH_KKT);
             }
             objv = E.obj/U.sf;
             if (iter == 0) { theta_max = 1e4*fmax(1.0, E.theta); theta_min = 1e-4*fmax(1.0, E.theta); }
+            if (HAS_RESTO && !FL && forced != 0) { status = forced; break; }      /* the restoration phase ended the solve: outputs at the point it left */
             if (hist && c.tid == 0 && iter < hist_cap) {
                 double *hh = hist + HIST_COLS*iter;
                 hh[0] = iter; hh[1] = objv; hh[2] = E.primal; hh[3] = E.dual; hh[4] = log10(mu); hh[5] = dnorm; hh[6] = alpha_du; hh[7] = alpha_pr;
@@ -2990,7 +3235,7 @@ struct Solver {
                     if (alpha < amin) break;
                 }
                 if (general) { status = STATUS_GENERAL; break; }
-                if (!accepted) { status = MSD_STATUS_LINESEARCH; break; }
+                if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; break; }      /* (the general iteration has the restoration phase) */
                 alpha_pr = alpha;
                 c.mark(PH_MERIT); phase_fence(PH_MERIT);
                 if (!ftype_armijo && nfilt < FILT_CAP) {      /* filter augmentation (W&B eq. (22)) */
@@ -3160,7 +3405,27 @@ struct Solver {
                 alpha *= 0.5; ls++; n_back++;
                 if (alpha < amin) break;
             }
-            if (!accepted) { status = MSD_STATUS_LINESEARCH; break; }
+            if (!accepted) {
+                /* the step became too small: feasibility restoration (IpBacktrackingLineSearch), unless the point is almost feasible
+                 * (resto_failure_feasibility_threshold = 100 tol).  The current point enters the filter; the iterate and the scalars
+                 * of this iteration go to the work area */
+                if (HAS_RESTO && P.resto && E.primal > 1e2*P.tol) {
+                    __syncthreads();
+                    if (nfilt < FILT_CAP) { if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; } nfilt++; }
+                    stash<H_ALL>();
+#pragma unroll
+                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
+                    if (c.tid == 0) {
+                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = theta; wf(W_SCAL, SC_PHI) = phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
+                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
+                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + 1;
+                        wf(W_SCAL, SC_FORCED) = 0;
+                    }
+                    __syncthreads();
+                    status = STATUS_RESTO; break;
+                }
+                status = MSD_STATUS_LINESEARCH; break;
+            }
             alpha_pr = alpha;
             c.mark(PH_MERIT); phase_fence(PH_MERIT);
 
@@ -3210,6 +3475,7 @@ struct Solver {
             }      /* (general iteration) */
         }
         if (FL && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path solves the scenario */
+        if (status == STATUS_RESTO) { iters_out = iter; return status; }
 
         /* ---- the multipliers for a later primal-dual warm start ---- */
         if (dual_out) {
@@ -3251,7 +3517,7 @@ struct Solver {
             stats[MSD_ST_STATUS] = status; stats[MSD_ST_ITERS] = iter + iter_offset; stats[MSD_ST_OBJ] = objv;
             stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/U.sf;
             stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/U.sf;
-            stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back;
+            stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back; stats[MSD_ST_N_RESTO] = n_resto;
             stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1]; stats[MSD_ST_N_FALLBACK] = c.misc[MISC_FALLBACKS];
             /* phase telemetry of the logged scenario: the last two rows of the history buffer */
             if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
@@ -3261,6 +3527,24 @@ struct Solver {
         return status;
     }
 };
+
+/* the restoration phase as a function of its own: its code and its registers stay out of the iteration's */
+template <int NT, int SPT, int DYN, bool GEN, bool FULL>
+__device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, Uni *U, const double *scen, double *hist, int hist_cap)
+{
+    Solver<NT, SPT, DYN, true, GEN, FULL> r(*P, c, work, *U);
+    int nit = 0;
+    const int rr = (MSD_RESTO_VARIANT == 3) ? 0 : r.restoration(scen, hist, hist_cap, nit);
+    /* hand-over to the general iteration: where it continues, and with which status if the solve ends here */
+    __syncthreads();
+    if (c.tid == 0) {
+        double *sc = work + (size_t)W_SCAL*NT*SPT;
+        sc[Solver<NT, SPT, DYN, true, GEN, FULL>::SC_ITER] += nit;
+        sc[Solver<NT, SPT, DYN, true, GEN, FULL>::SC_FORCED] = rr == 1 ? 0 : rr == -1 ? MSD_STATUS_INFEASIBLE : rr == -2 ? MSD_STATUS_MAXITER : MSD_STATUS_LINESEARCH;
+    }
+    __syncthreads();
+    return rr;
+}
 
 /*
  * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64), NT*SPT >= N + 1.
@@ -3279,7 +3563,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     if (STREAM) {
         /* long horizons (N > 560): stage blocks and exchange arrays behind the node fields in the workgroup's work area (device
          * memory, L2-resident); LDS keeps the filter, the reduction scratch and the uniform records */
-        c.S = wg_work + work_doubles(NS);
+        c.S = wg_work + (size_t)W_FIELDS_ITERATE*NS;
         c.xt = c.S + stage_stride(DYN)*(P.N + 1);
         c.filt = lds;
     } else {
@@ -3344,12 +3628,25 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                                               (hist && sidx == 0) ? hist : nullptr, hist_cap);
                 __syncthreads();
             }
-            if (st == SolverT::STATUS_GENERAL)
-                st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
-                                           lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                           (hist && sidx == 0) ? hist : nullptr, hist_cap);
+            if (st == SolverT::STATUS_GENERAL) {
+                /* one call site: a scenario whose line search broke down comes back with STATUS_RESTO, goes through the restoration phase and is
+                 * resumed -- with the status the phase ended the solve with, if it did */
+                bool resume = false;
+#pragma unroll 1
+                for (;;) {
+                    st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                               lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
+                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
+                    __syncthreads();
+                    if constexpr (SolverT::HAS_RESTO) {
+                        if (st != SolverT::STATUS_RESTO) break;
+                        if (MSD_RESTO_VARIANT != 2) resto_entry<NT, SPT, DYN, GEN, FULL>(Pl, c, wg_work, Ul, scen + (size_t)MSD_SC_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
+                        resume = true;
+                    } else break;
+                }
+            }
             __syncthreads();
-            if (st >= 0 || st == MSD_STATUS_MAXITER) break;
+            if (st >= 0 || st == MSD_STATUS_MAXITER || st == MSD_STATUS_INFEASIBLE) break;
             spent = iters;
             if (guess) guess = nullptr;      /* a warm start that breaks down: once more from the problem's own starting point */
             else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;

@@ -14,17 +14,17 @@ import numpy as np
 
 LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 INTEGRATOR_ADAPTIVE, INTEGRATOR_COLLOCATION = 1, 2     # MSD_INTEGRATOR_* (also the methods of msd_interval_integrate)
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, COUNT=14)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, N_RESTO=14, COUNT=15)
 SC_COUNT = 4
 OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, TOTAL_MASS=9, COUNT=10)
 HIST_COLS = 8
 
 STATUS_MAXITER, STATUS_LINESEARCH, STATUS_INFEASIBLE = -1, -2, -6
-# -2: the filter line search failed from both starting points: where IPOPT would enter its restoration phase, which the device
-# solver does not have ('Restoration_Failed' is IPOPT's status for a solve that ends there).  -6 is set by the host, from the
-# minimum-running-time certificate (casadiSolver._classify_failures), never by the kernel.
+# -2: the filter line search broke down and the feasibility restoration phase (csrc/msd_resto.hpp, IPOPT's MinC_1Nrm restoration) did not
+# find an acceptable point either -- IPOPT's 'Restoration_Failed'.  -6: the restoration phase converged to a stationary point of the
+# infeasibility (device), or the minimum-running-time certificate of a failed scenario says so (casadiSolver._classify_failures).
 STATUS_TEXT = {0: 'Solve_Succeeded', 1: 'Solved_To_Acceptable_Level', -1: 'Maximum_Iterations_Exceeded',
                -2: 'Restoration_Failed', -3: 'Error_In_Step_Computation', -4: 'Invalid_Number_Detected',
                -5: 'Search_Direction_Becomes_Too_Small', -6: 'Infeasible_Problem_Detected'}
@@ -39,7 +39,7 @@ class ProblemDesc(ctypes.Structure):
                 ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
                 ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
                 ('start_kind', ctypes.c_int), ('integrator', ctypes.c_int), ('coll_degree', ctypes.c_int), ('newton_iterations', ctypes.c_int),
-                ('integrate_losses', ctypes.c_int), ('reserved_i', ctypes.c_int*2),
+                ('integrate_losses', ctypes.c_int), ('no_restoration', ctypes.c_int), ('reserved_i', ctypes.c_int*1),
                 ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
                 ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
@@ -129,7 +129,7 @@ START = dict(reference=0, profile=1)   # MSD_START_*
 
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
               pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference',
-              integrator=None, integrateLosses=False):
+              integrator=None, integrateLosses=False, restoration=True):
     """
     Fill a ProblemDesc; the numpy arrays are kept alive on the returned object.  integrator: None ('RK'), ('CVODES', absTol, relTol) or
     ('IRK', order, maxIter, C, D) with the tables of mseetc.train.collocationTables.  integrateLosses: ocp.py:28,231-241.
@@ -140,6 +140,7 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
     d.num_intervals, d.with_pn_brake, d.has_power_rows, d.energy_optimal = int(N), int(withPn), int(hasPower), int(energyOptimal)
     d.num_steps, d.num_approx_steps, d.loss_kind, d.max_iterations = int(numSteps), int(numApproxSteps), int(lossKind), int(maxIterations)
     d.start_kind = START[start]
+    d.no_restoration = 0 if restoration else 1
     d.sr0, d.sr1, d.sr2 = sr
     d.g, d.rho = g, rho
     d.f_max, d.f_min, d.f_min_pn = fmax, fmin, fminPn

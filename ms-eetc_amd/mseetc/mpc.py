@@ -84,7 +84,8 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     `solverFactory(train, track, opts)` lets tests substitute the solver (default: the device solver).
     """
 
-    make = solverFactory or (lambda tr, tk, op: casadiSolver(tr, tk, op, device=device))
+    # (no restoration phase: a re-solve that fails is certified and relaxed below, and a launch lasts as long as its slowest scenario)
+    make = solverFactory or (lambda tr, tk, op: casadiSolver(tr, tk, op, device=device, restoration=False))
 
     T = np.array(np.atleast_1d(np.asarray(terminalTime, dtype=float)), copy=True)
     B = T.shape[0]

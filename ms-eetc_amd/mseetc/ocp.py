@@ -72,18 +72,23 @@ class casadiSolver():
 
     TOLERANCE = 1e-8   # IPOPT default `tol`; the reference passes only max_iter (ocp.py:290)
 
-    def __init__(self, train, track, optsDict={}, device=0, startingPoint='profile'):
+    def __init__(self, train, track, optsDict={}, device=0, startingPoint='profile', restoration=True):
         """
         Same arguments as the reference (ocp.py:79) plus two that have no counterpart there: `device` (GPU index) and
         `startingPoint`: 'reference' starts every solve from the reference's point (ocp.py:325-339), 'profile' (default)
         from a speed profile built on the device from the limits, the running time and the end speeds -- same optimum,
         about half the interior-point iterations; a scenario that breaks down from it is repeated from the reference's point.
+        `restoration` (default True, IPOPT's behaviour): a solve whose filter line search breaks down enters the feasibility restoration
+        phase on the device (static loss models, N <= 560); False: it ends there ('Restoration_Failed') after the restart from the other
+        starting point -- what a loop that handles failed scenarios itself wants (mseetc/mpc.py), since a hopeless scenario can spend
+        hundreds of iterations in restoration and a launch lasts as long as its slowest scenario.
         """
 
         if startingPoint not in _device.START:
             raise ValueError("Unknown starting point '{}'!".format(startingPoint))
 
         self.startingPoint = startingPoint
+        self.restoration = bool(restoration)
         self._optsDict = dict(optsDict)
 
         track.checkFields()
@@ -167,7 +172,7 @@ class casadiSolver():
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
             self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
             lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint, integrator=integrator,
-            integrateLosses=integrateLosses)
+            integrateLosses=integrateLosses, restoration=restoration)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU
@@ -349,7 +354,7 @@ class casadiSolver():
             opts = dict(self._optsDict)
             opts['energyOptimal'] = False
             opts.pop('integrateLosses', None)      # (the loss slacks do not exist in the time-optimal problem)
-            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile')
+            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile', restoration=self.restoration)
 
         sub = np.atleast_2d(np.asarray(scen, dtype=float))
         loose = sub.copy()
@@ -371,14 +376,17 @@ class casadiSolver():
     def _classify_failures(self, scen, st, overrides=None):
         """
         IPOPT ends a solve whose constraints cannot be met in its restoration phase with 'Infeasible_Problem_Detected'
-        (ocp.py:362-370 prints that status).  The device solver has no restoration phase; what it has is an exact certificate
+        (ocp.py:362-370 prints that status).  The device's restoration phase (csrc/msd_resto.hpp) reports that status itself when it
+        converges; on this problem class it usually breaks down first ('Restoration_Failed': its 1-norm objective leaves the distribution
+        of the missing time over the intervals open).  The host adds an exact certificate
         for the one infeasibility this problem class knows -- a running time below the minimum: the time-optimal twin of the
         problem is solved for the scenarios that broke down (with their own rolling stock), and those whose minimum running
         time exceeds their T are marked infeasible.  Everything else keeps its status.
         """
 
         ST = _device.ST
-        failed = np.flatnonzero((st[:, ST['STATUS']] < 0) & (st[:, ST['STATUS']] != _device.STATUS_MAXITER))
+        # (the iteration limit is a verdict of its own -- unless the solve ran into it inside or between restoration phases)
+        failed = np.flatnonzero((st[:, ST['STATUS']] < 0) & ((st[:, ST['STATUS']] != _device.STATUS_MAXITER) | (st[:, ST['N_RESTO']] > 0)))
 
         if failed.size == 0:
             return

@@ -621,6 +621,7 @@ typedef struct {
     double F[3][6], r[3];
     double K[3][3], k[3], Pn[3][3], pn[3]; /* feedback, and the (P,p) of stage i+1 used at i */
     double ef[6], e0;                       /* terminal elimination: df = ef . y~ + e0 (last interval only) */
+    double M[2][2], Dt, Db;                 /* restoration: (P2 + D^-1)^-1 on the relaxed rows (t, b), their D = n/zn + p/zp (unscaled rows) */
     double Ghat[6][6], ghat[6];             /* G, g before elimination (for multiplier recovery) */
 } StageKkt;
 
@@ -628,8 +629,24 @@ typedef struct {
     double dx[NV], dsig[NR], dlam[2], dnu[NR], dzL[NV], dzU[NV], dzLs[NR], dzUs[NR];
 } StageDir;
 
+/*
+ * Feasibility restoration (IPOPT's MinC_1NrmRestorationPhase, Waechter & Biegler 2006 section 3.3; reached by the reference through
+ * ocp.py:290,359 and surfaced at :362-370).  Every equality row of the barrier problem -- the two dynamics rows of an interval
+ * (scaled) and the rows d(x) - sigma = 0 -- is relaxed with a pair of non-negative variables: row + n - p = 0.
+ */
+enum { NC = 2 + NR };
+typedef struct { double n[NC], p[NC], zn[NC], zp[NC]; } StageRs;
+typedef struct { double dn[NC], dp[NC], dzn[NC], dzp[NC]; } StageRsDir;
+typedef struct Resto {
+    double rho, eta;            /* penalty parameter (resto_penalty_parameter = 1000), proximity weight sqrt(mu) */
+    StageRs *v, *trial;         /* per interval */
+    StageRsDir *d;
+    double (*xR)[NV], (*dr)[NV];/* reference point and the scaling D_R = 1/max(1, |x_R|) of the proximity term */
+} Resto;
+
 typedef struct {
     Prob P;
+    struct Resto *resto;     /* non-null while the restoration problem is being solved: compute_direction() then builds its Newton system */
     int N, rowOn[NR];
     double dL[NR], dU[NR]; int rhasL[NR], rhasU[NR];
     double rs[NR];          /* inequality row scaling (gradient based) */
@@ -649,7 +666,7 @@ typedef struct {
     /* inertia correction memory */
     double delta_last;
     /* stats */
-    int n_reg, n_soc, n_back;
+    int n_reg, n_soc, n_back, n_resto;
 } Ws;
 
 /* IPOPT default option values (Waechter & Biegler 2006, section 3 + IPOPT 3.14 defaults) */
@@ -993,9 +1010,20 @@ static void bar_terms(double x, double lb, double ub, int hasL, int hasU, double
  *   replaced by the accumulated values in a second-order correction).
  * returns 1 if the inertia is correct (all stage pivots positive), 0 otherwise.
  * ---------------------------------------------------------------------------------------- */
+static double rs_D(const StageRs *v, int j) { return v->n[j]/v->zn[j] + v->p[j]/v->zp[j]; }
+
+/*
+ * With W->resto set this is the Newton system of the restoration problem with (n, p, z_n, z_p) eliminated: every relaxed row reads
+ *   (row gradient) dx + rhat = D y+,   D = n/z_n + p/z_p,   rhat = row + n - p + (mu - rho n)/z_n - (mu - rho p)/z_p
+ * (res_c / res_d then carry rhat; the dynamics rows scaled).  An inequality row condenses like before with Sigma replaced by
+ * 1/(D + 1/Sigma); a dynamics row becomes x+ = F y + r + D lam+: the value function of stage i+1 is used through
+ * M = (P2 + D^-1)^-1 on the relaxed rows.  The objective is the proximity term eta/2 |D_R (x - x_R)|^2; b_N stays a parameter,
+ * the last interval's b row is a penalty on F_b y + r_b instead of an elimination.
+ */
 static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[2], const double (*res_d)[NR], StageDir *D)
 {
     int N = W->N; const Prob *P = &W->P;
+    const Resto *R = W->resto;
 
     memset(W->HN, 0, sizeof W->HN); memset(W->hN, 0, sizeof W->hN);
     for (int i = 0; i < N; i++) { memset(W->kk[i].H, 0, sizeof W->kk[i].H); memset(W->kk[i].h, 0, sizeof W->kk[i].h); memset(W->kk[i].E, 0, sizeof W->kk[i].E); }
@@ -1004,7 +1032,7 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
     for (int i = 0; i < N; i++) {
         StageEv *e = &W->ev[i]; StageIt *I = &W->it[i]; StageKkt *Kk = &W->kk[i];
         double Hl[NL][NL], hl[NL];
-        for (int a = 0; a < NL; a++) { hl[a] = e->objg[a]; for (int c = 0; c < NL; c++) Hl[a][c] = e->objh[a][c]; }
+        for (int a = 0; a < NL; a++) { hl[a] = R ? 0.0 : e->objg[a]; for (int c = 0; c < NL; c++) Hl[a][c] = R ? 0.0 : e->objh[a][c]; }
         /* -lam_t * hess(tau) - lam_b * hess(bplus) on (b, w) with w = f + p */
         {
             double hbb = -(I->lam[0]*e->th[0] + I->lam[1]*e->bh[0]);
@@ -1019,6 +1047,7 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gphi);
             Sg += dw;
             double coef = Sg*res_d[i][r] + gphi;
+            if (R) { const double St = 1.0/(rs_D(&R->v[i], 2 + r) + 1.0/Sg); coef = St*res_d[i][r] + gphi*St/Sg; Sg = St; }
             for (int a = 0; a < NL; a++) {
                 hl[a] += e->gr[r][a]*coef;
                 for (int c = 0; c < NL; c++) Hl[a][c] += I->nu[r]*e->hr[r][a][c] + Sg*e->gr[r][a]*e->gr[r][c];
@@ -1040,6 +1069,7 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
         Kk->F[1][1] = e->bg[0]; Kk->F[1][3] = e->bg[1]; Kk->F[1][4] = P->withPn ? e->bg[1] : 0;
         Kk->F[2][3] = 1;
         Kk->r[0] = -res_c[i][0]; Kk->r[1] = -res_c[i][1]; Kk->r[2] = 0;
+        if (R) { Kk->r[0] /= W->sct[i]; Kk->r[1] /= W->scb[i]; }
     }
     /* variable bounds + regularisation */
     for (int i = 0; i <= N; i++) {
@@ -1049,6 +1079,7 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             double Sg, gphi;
             bar_terms(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], I->zL[k], I->zU[k], mu, &Sg, &gphi);
             int a = var2loc[k];
+            if (R) { const double w = R->eta*R->dr[i][k]*R->dr[i][k]; Sg += w; gphi += w*(I->x[k] - R->xR[i][k]); }
             if (i < N) { W->kk[i].H[a][a] += Sg + dw; W->kk[i].h[a] += gphi; }
             else { W->HN[a][a] += Sg + dw; W->hN[a] += gphi; }
         }
@@ -1079,15 +1110,37 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             for (int m = 0; m < 3; m++) s += Kk->F[m][a]*Pr[m] + Kk->E[a][m]*Kk->r[m];
             g[a] = s;
         }
+        if (R) {
+            const double Dt = rs_D(&R->v[i], 0)/(W->sct[i]*W->sct[i]), Db = rs_D(&R->v[i], 1)/(W->scb[i]*W->scb[i]);
+            Kk->Dt = Dt; Kk->Db = Db; memset(Kk->M, 0, sizeof Kk->M);
+            if (i == N - 1) Kk->M[0][0] = Dt/(1 + Pm[0][0]*Dt);
+            else {
+                /* M = (P2 + D^-1)^-1 = D^1/2 (I + D^1/2 P2 D^1/2)^-1 D^1/2 */
+                const double st = sqrt(Dt), sb = sqrt(Db);
+                const double ma = 1 + st*Pm[0][0]*st, mb = st*Pm[0][1]*sb, mc = 1 + sb*Pm[1][1]*sb, det = ma*mc - mb*mb;
+                if (!(det > 0) || !(ma > 0)) return 0;      /* P2 + D^-1 not positive definite: wrong inertia */
+                Kk->M[0][0] = st*(mc/det)*st; Kk->M[0][1] = Kk->M[1][0] = -st*(mb/det)*sb; Kk->M[1][1] = sb*(ma/det)*sb;
+            }
+            if (!(1 + Pm[0][0]*Dt > 0)) return 0;
+            double Q[2][6];
+            for (int m = 0; m < 2; m++) for (int c = 0; c < 6; c++) Q[m][c] = PF[m][c] + Kk->E[c][m];
+            for (int a = 0; a < 6; a++) {
+                double qa[2] = {Kk->M[0][0]*Q[0][a] + Kk->M[1][0]*Q[1][a], Kk->M[0][1]*Q[0][a] + Kk->M[1][1]*Q[1][a]};
+                for (int c = 0; c < 6; c++) G[a][c] -= qa[0]*Q[0][c] + qa[1]*Q[1][c];
+                g[a] -= qa[0]*Pr[0] + qa[1]*Pr[1];
+            }
+        }
         if (!P->withPn) { for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0; G[4][4] = 1; g[4] = 0; }
         memcpy(Kk->Ghat, G, sizeof G); memcpy(Kk->ghat, g, sizeof g);
 
         if (i == N - 1) {
-            /* b_N fixed: the b-row of the dynamics is an equality in (x, u); eliminate df through it */
+            /* b_N fixed: the b-row of the dynamics is an equality in (x, u); eliminate df through it.  Restoration: the row is relaxed,
+             * F_b y + r_b = -D_b lam_b+ with the penalty D_b lam_b+^2 / 2; in terms of v = sqrt(D_b) lam_b+ (slot of df, unit curvature)
+             * the system stays well conditioned as D_b -> 0 */
             double Bw = Kk->F[1][3];
             double T[6][6]; memset(T, 0, sizeof T);
             for (int a = 0; a < 6; a++) T[a][a] = 1;
-            T[3][3] = 0;
+            T[3][3] = R ? -sqrt(Kk->Db)/Bw : 0;
             T[3][1] = -Kk->F[1][1]/Bw; T[3][4] = -Kk->F[1][4]/Bw;
             double y0f = -Kk->r[1]/Bw;
             memset(Kk->ef, 0, sizeof Kk->ef); Kk->ef[1] = T[3][1]; Kk->ef[4] = T[3][4]; Kk->e0 = y0f;
@@ -1095,7 +1148,8 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             double GT[6][6], G2[6][6], gy[6], g2[6];
             for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += G[a][m]*T[m][c]; GT[a][c] = s; } gy[a] = g[a] + G[a][3]*y0f; }
             for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*GT[m][c]; G2[a][c] = s; } double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*gy[m]; g2[a] = s; }
-            for (int a = 0; a < 6; a++) G2[3][a] = G2[a][3] = 0; G2[3][3] = 1; g2[3] = 0;
+            if (R) G2[3][3] += 1;
+            else { for (int a = 0; a < 6; a++) G2[3][a] = G2[a][3] = 0; G2[3][3] = 1; g2[3] = 0; }
             memcpy(G, G2, sizeof G); memcpy(g, g2, sizeof g);
         }
 
@@ -1123,21 +1177,37 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
         double du[3], y[6];
         for (int a = 0; a < 3; a++) { double s = Kk->k[a]; for (int c = 0; c < 3; c++) s += Kk->K[a][c]*dxs[c]; du[a] = s; }
         for (int a = 0; a < 3; a++) { y[a] = dxs[a]; y[3 + a] = du[a]; }
-        if (i == N - 1) { double s = Kk->e0; for (int a = 0; a < 6; a++) if (a != 3) s += Kk->ef[a]*y[a]; y[3] = s; }
+        const double v_last = y[3];
+        if (i == N - 1) { double s = Kk->e0; for (int a = 0; a < 6; a++) if (a != 3) s += Kk->ef[a]*y[a]; y[3] = s; if (R) y[3] -= sqrt(Kk->Db)/Kk->F[1][3]*v_last; }
         if (!P->withPn) y[4] = 0;
         double xn[3];
         for (int a = 0; a < 3; a++) { double s = Kk->r[a]; for (int c = 0; c < 6; c++) s += Kk->F[a][c]*y[c]; xn[a] = s; }
         if (i == N - 1) xn[1] = 0;
+        double lam_r[2] = {0, 0};
+        if (R) {
+            /* x+ = a + D lam+, lam+ = -(I + P2 D)^-1 (P a + p + E^T y) on the relaxed rows (the last interval: t only, b_N is a
+             * parameter): the multipliers from the relaxed rows themselves, so that the rows' linearisation holds to rounding */
+            double gg[2];
+            for (int m = 0; m < 2; m++) { double s = Kk->pn[m]; for (int c = 0; c < 3; c++) s += Kk->Pn[m][c]*xn[c]; for (int c = 0; c < 6; c++) s += Kk->E[c][m]*y[c]; gg[m] = s; }
+            if (i == N - 1) { lam_r[0] = -gg[0]/(1 + Kk->Dt*Kk->Pn[0][0]); lam_r[1] = v_last/sqrt(Kk->Db); xn[0] += Kk->Dt*lam_r[0]; }
+            else {
+                const double a00 = 1 + Kk->Pn[0][0]*Kk->Dt, a01 = Kk->Pn[0][1]*Kk->Db, a10 = Kk->Pn[1][0]*Kk->Dt, a11 = 1 + Kk->Pn[1][1]*Kk->Db;
+                const double det = a00*a11 - a01*a10;
+                lam_r[0] = -(a11*gg[0] - a01*gg[1])/det; lam_r[1] = -(a00*gg[1] - a10*gg[0])/det;
+                xn[0] += Kk->Dt*lam_r[0]; xn[1] += Kk->Db*lam_r[1];
+            }
+        }
         memset(d, 0, sizeof *d);
         d->dx[VT] = y[0]; d->dx[VB] = y[1]; d->dx[VF] = y[3]; d->dx[VP] = y[4]; d->dx[VS] = y[5];
         /* new dynamics multipliers: lam+ = -(P+ x+ + p+ + E^T y) */
         double lp[3];
         for (int a = 0; a < 3; a++) { double s = Kk->pn[a]; for (int c = 0; c < 3; c++) s += Kk->Pn[a][c]*xn[c]; for (int c = 0; c < 6; c++) s += Kk->E[c][a]*y[c]; lp[a] = -s; }
-        if (i == N - 1) {
+        if (i == N - 1 && !R) {
             /* multiplier of the eliminated row from stationarity wrt df: (G y + g)_f - lam_b * Bw = 0 */
             double s = Kk->ghat[3]; for (int c = 0; c < 6; c++) s += Kk->Ghat[3][c]*y[c];
             lp[1] = s/Kk->F[1][3];
         }
+        if (R) { lp[0] = lam_r[0]; lp[1] = lam_r[1]; }
         d->dlam[0] = lp[0] - W->it[i].lam[0]; d->dlam[1] = lp[1] - W->it[i].lam[1];
         dxs[0] = xn[0]; dxs[1] = xn[1]; dxs[2] = xn[2];
     }
@@ -1158,6 +1228,11 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             for (int a = 0; a < NL; a++) dsg += e->gr[r][a]*dl[a];
             d->dsig[r] = dsg;
             d->dnu[r] = (Sg + dw)*dsg + gphi - I->nu[r];
+            if (R) {
+                const double Sw = Sg + dw, St = 1.0/(rs_D(&R->v[i], 2 + r) + 1.0/Sw), nup = St*dsg + gphi*St/Sw;
+                d->dsig[r] = (nup - gphi)/Sw; d->dnu[r] = nup - I->nu[r];
+                dsg = d->dsig[r];
+            }
             if (W->rhasL[r]) { double s = I->sig[r] - W->dL[r]; d->dzLs[r] = mu/s - I->zLs[r] - I->zLs[r]/s*dsg; }
             if (W->rhasU[r]) { double s = W->dU[r] - I->sig[r]; d->dzUs[r] = mu/s - I->zUs[r] + I->zUs[r]/s*dsg; }
         }
@@ -1170,6 +1245,20 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
             if (B->hasU[k]) { double s = B->ub[k] - I->x[k]; d->dzU[k] = mu/s - I->zU[k] + I->zU[k]/s*d->dx[k]; }
         }
     }
+    if (R)
+        for (int i = 0; i < N; i++) {
+            const StageRs *v = &R->v[i]; StageRsDir *q = &R->d[i]; const StageIt *I = &W->it[i];
+            memset(q, 0, sizeof *q);
+            for (int j = 0; j < NC; j++) {
+                if (j >= 2 && !W->rowOn[j - 2]) continue;
+                const double sc = j == 0 ? W->sct[i] : j == 1 ? W->scb[i] : 1.0;
+                const double y = (j < 2 ? I->lam[j] : I->nu[j - 2])/sc, dy = (j < 2 ? D[i].dlam[j] : D[i].dnu[j - 2])/sc;
+                q->dn[j] = (mu - v->n[j]*(R->rho + y))/v->zn[j] - v->n[j]/v->zn[j]*dy;
+                q->dp[j] = (mu - v->p[j]*(R->rho - y))/v->zp[j] + v->p[j]/v->zp[j]*dy;
+                q->dzn[j] = R->rho + y + dy - v->zn[j];
+                q->dzp[j] = R->rho - y - dy - v->zp[j];
+            }
+        }
     return 1;
 }
 
@@ -1177,6 +1266,7 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
 static double direction_residual(Ws *W, double mu, double dw, const double (*res_c)[2], const double (*res_d)[NR], StageDir *D)
 {
     int N = W->N; const Prob *P = &W->P; double worst = 0;
+    const Resto *R = W->resto;
     double (*rx)[NV] = calloc(N + 1, sizeof *rx);
     for (int i = 0; i < N; i++) {
         StageEv *e = &W->ev[i]; StageIt *I = &W->it[i];
@@ -1186,9 +1276,9 @@ static double direction_residual(Ws *W, double mu, double dw, const double (*res
         double lt = I->lam[0] + D[i].dlam[0], lb = I->lam[1] + D[i].dlam[1];
         /* W d (with current multipliers) + grad f + J^T (new multipliers) */
         for (int a = 0; a < NL; a++) {
-            double s = e->objg[a];
+            double s = R ? 0.0 : e->objg[a];
             for (int c = 0; c < NL; c++) {
-                double w = e->objh[a][c];
+                double w = R ? 0.0 : e->objh[a][c];
                 for (int r = 0; r < NR; r++) if (W->rowOn[r]) w += I->nu[r]*e->hr[r][a][c];
                 s += w*dl[c];
             }
@@ -1208,12 +1298,17 @@ static double direction_residual(Ws *W, double mu, double dw, const double (*res
         /* linearised dynamics */
         double rt = dl[LT1] - dl[LT] - e->tg[0]*dl[LB] - e->tg[1]*dw_ + res_c[i][0];
         double rb = dl[LB1] - e->bg[0]*dl[LB] - e->bg[1]*dw_ + res_c[i][1];
+        if (R) {
+            rt = dl[LT1] - dl[LT] - e->tg[0]*dl[LB] - e->tg[1]*dw_ + res_c[i][0]/W->sct[i] - rs_D(&R->v[i], 0)/(W->sct[i]*W->sct[i])*lt;
+            rb = dl[LB1] - e->bg[0]*dl[LB] - e->bg[1]*dw_ + res_c[i][1]/W->scb[i] - rs_D(&R->v[i], 1)/(W->scb[i]*W->scb[i])*lb;
+        }
         worst = fmax(worst, fmax(fabs(rt), fabs(rb)));
         if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d dyn res %g %g\n", i, rt, rb);
         for (int r = 0; r < NR; r++) {
             if (!W->rowOn[r]) continue;
             double lin = res_d[i][r] - D[i].dsig[r];
             for (int a = 0; a < NL; a++) lin += e->gr[r][a]*dl[a];
+            if (R) lin -= rs_D(&R->v[i], 2 + r)*(I->nu[r] + D[i].dnu[r]);
             worst = fmax(worst, fabs(lin));
             if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d row %d lin res %g\n", i, r, lin);
             /* slack stationarity: dw*dsig - nu+ - zL+ + zU+ = 0 */
@@ -1231,11 +1326,12 @@ static double direction_residual(Ws *W, double mu, double dw, const double (*res
         for (int k = 0; k < NV; k++) {
             if (!B->on[k]) continue;
             double s = rx[i][k] + dw*D[i].dx[k];
+            if (R) s += R->eta*R->dr[i][k]*R->dr[i][k]*(I->x[k] + D[i].dx[k] - R->xR[i][k]);
             if (B->hasL[k]) s -= I->zL[k] + D[i].dzL[k];
             if (B->hasU[k]) s += I->zU[k] + D[i].dzU[k];
             if (B->hasL[k] && !B->hasU[k]) s += K_D*mu;
             if (!B->hasL[k] && B->hasU[k]) s -= K_D*mu;
-            if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d var %d stat res %g\n", i, k, s);
+            if (getenv("ORACLE_DBGCAT")) fprintf(stderr, "   i=%d var %d (x %.6e dx %.3e slackL %.3e slackU %.3e zL %.3e zU %.3e dzL %.3e dzU %.3e rx %.3e) stat res %g\n", i, k, I->x[k], D[i].dx[k], I->x[k] - B->lb[k], B->ub[k] - I->x[k], I->zL[k], I->zU[k], D[i].dzL[k], D[i].dzU[k], rx[i][k], s);
             worst = fmax(worst, fabs(s));
         }
     }
@@ -1336,6 +1432,385 @@ static double push_in(double x, double lb, double ub, int hasL, int hasU, double
 }
 
 static int debug_level(void) { const char *s = getenv("ORACLE_DEBUG"); return s ? atoi(s) : 0; }
+
+/* ------------------------------------------------------------------------------------------
+ * feasibility restoration phase
+ * ---------------------------------------------------------------------------------------- */
+static int g_resto = 1;
+void oracle_set_restoration(int on) { g_resto = on; }
+
+static const double RESTO_RHO = 1000.0;        /* resto_penalty_parameter */
+static const double RESTO_KAPPA = 0.9;         /* required_infeasibility_reduction */
+static const double RESTO_THETA_MAX_FACT = 1e8;/* resto.theta_max_fact */
+static const double BOUND_MULT_RESET = 1e3;    /* bound_mult_reset_threshold */
+static const int RESTO_MAX_ITER = 100;         /* iterations of one restoration phase (not IPOPT's default, which is unlimited: a phase that has not found an
+                                                * acceptable point by then is given up -- the phases that succeed take 1 to 30 -- and the solve ends with
+                                                * Restoration_Failed, after which it is repeated from the other starting point) */
+
+/* value of relaxed row j of interval i at an evaluated point (without n - p) */
+static double rs_row(const Ws *W, const StageIt *it, int i, const StageEv *e, int j)
+{
+    return j == 0 ? W->sct[i]*e->c[0] : j == 1 ? W->scb[i]*e->c[1] : e->d[j - 2] - it[i].sig[j - 2];
+}
+static int rs_on(const Ws *W, int j) { return j < 2 || W->rowOn[j - 2]; }
+
+/* theta_R = 1-norm of the relaxed rows, phi_R = rho sum(n + p) + eta/2 |D_R (x - x_R)|^2 + barrier terms of (x, sigma, n, p) */
+static void resto_merit(const Ws *W, const StageIt *it, const StageRs *rv, double mu, double *theta, double *phi, int *ok)
+{
+    const Resto *R = W->resto; const int N = W->N; double th = 0, bar = 0, f = 0; *ok = 1;
+    StageEv e;
+    for (int i = 0; i < N; i++) {
+        eval_interval(W, it, i, &e, 0);
+        for (int j = 0; j < NC; j++) {
+            if (!rs_on(W, j)) continue;
+            const double n = rv[i].n[j], p = rv[i].p[j];
+            th += fabs(rs_row(W, it, i, &e, j) + n - p);
+            if (n <= 0 || p <= 0) *ok = 0; else bar -= mu*(log(n) + log(p));
+            bar += K_D*mu*(n + p); f += R->rho*(n + p);
+        }
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double sg = it[i].sig[r];
+            if (W->rhasL[r]) { double s = sg - W->dL[r]; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (W->rhasU[r]) { double s = W->dU[r] - sg; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (W->rhasL[r] && !W->rhasU[r]) bar += K_D*mu*(sg - W->dL[r]);
+            if (!W->rhasL[r] && W->rhasU[r]) bar += K_D*mu*(W->dU[r] - sg);
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        const StageBd *B = &W->bd[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double x = it[i].x[k];
+            if (B->hasL[k]) { double s = x - B->lb[k]; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (B->hasU[k]) { double s = B->ub[k] - x; if (s <= 0) *ok = 0; else bar -= mu*log(s); }
+            if (B->hasL[k] && !B->hasU[k]) bar += K_D*mu*(x - B->lb[k]);
+            if (!B->hasL[k] && B->hasU[k]) bar += K_D*mu*(B->ub[k] - x);
+            const double q = R->dr[i][k]*(x - R->xR[i][k]);
+            f += 0.5*R->eta*q*q;
+        }
+    }
+    if (!isfinite(th) || !isfinite(bar) || !isfinite(f)) *ok = 0;
+    *theta = th; *phi = f + bar;
+}
+
+/* optimality error of the restoration problem (W->ev holds the derivatives at W->it) */
+static void resto_kkt_error(Ws *W, double mu, Err *Rr)
+{
+    const Resto *R = W->resto; int N = W->N; const Prob *P = &W->P;
+    double dual = 0, prim = 0, comp = 0, comp0 = 0, sumlam = 0, sumz = 0; int nlam = 0, nz = 0;
+    double (*gl)[NV] = calloc(N + 1, sizeof *gl);
+    for (int i = 0; i < N; i++) {
+        StageEv *e = &W->ev[i]; StageIt *I = &W->it[i]; const StageRs *v = &R->v[i];
+        double loc[NL];
+        for (int a = 0; a < NL; a++) loc[a] = 0;
+        for (int r = 0; r < NR; r++) if (W->rowOn[r]) for (int a = 0; a < NL; a++) loc[a] += I->nu[r]*e->gr[r][a];
+        loc[LT1] += I->lam[0]; loc[LT] -= I->lam[0];
+        loc[LB] -= I->lam[0]*e->tg[0]; loc[LF] -= I->lam[0]*e->tg[1]; loc[LP] -= P->withPn ? I->lam[0]*e->tg[1] : 0;
+        loc[LB1] += I->lam[1];
+        loc[LB] -= I->lam[1]*e->bg[0]; loc[LF] -= I->lam[1]*e->bg[1]; loc[LP] -= P->withPn ? I->lam[1]*e->bg[1] : 0;
+        gl[i][VT] += loc[LT]; gl[i][VB] += loc[LB]; gl[i][VF] += loc[LF]; gl[i][VP] += loc[LP]; gl[i][VS] += loc[LS];
+        if (i > 0) gl[i - 1][VF] += loc[LQ];
+        gl[i + 1][VT] += loc[LT1]; gl[i + 1][VB] += loc[LB1];
+        for (int j = 0; j < NC; j++) {
+            if (!rs_on(W, j)) continue;
+            const double sc = j == 0 ? W->sct[i] : j == 1 ? W->scb[i] : 1.0;
+            const double y = (j < 2 ? I->lam[j] : I->nu[j - 2])/sc;
+            prim = fmax(prim, fabs(rs_row(W, W->it, i, e, j) + v->n[j] - v->p[j]));
+            sumlam += fabs(y); nlam++;
+            dual = fmax(dual, fmax(fabs(R->rho + y - v->zn[j]), fabs(R->rho - y - v->zp[j])));
+            const double cn = v->n[j]*v->zn[j], cp = v->p[j]*v->zp[j];
+            comp = fmax(comp, fmax(fabs(cn - mu), fabs(cp - mu))); comp0 = fmax(comp0, fmax(fabs(cn), fabs(cp)));
+            sumz += v->zn[j] + v->zp[j]; nz += 2;
+        }
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double sg = I->sig[r], gs = -I->nu[r];
+            if (W->rhasL[r]) { gs -= I->zLs[r]; double c = (sg - W->dL[r])*I->zLs[r]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zLs[r]; nz++; }
+            if (W->rhasU[r]) { gs += I->zUs[r]; double c = (W->dU[r] - sg)*I->zUs[r]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zUs[r]; nz++; }
+            dual = fmax(dual, fabs(gs));
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double g = gl[i][k] + R->eta*R->dr[i][k]*R->dr[i][k]*(I->x[k] - R->xR[i][k]);
+            if (B->hasL[k]) { g -= I->zL[k]; double c = (I->x[k] - B->lb[k])*I->zL[k]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zL[k]; nz++; }
+            if (B->hasU[k]) { g += I->zU[k]; double c = (B->ub[k] - I->x[k])*I->zU[k]; comp = fmax(comp, fabs(c - mu)); comp0 = fmax(comp0, fabs(c)); sumz += I->zU[k]; nz++; }
+            dual = fmax(dual, fabs(g));
+        }
+    }
+    free(gl);
+    memset(Rr, 0, sizeof *Rr);
+    Rr->sd = fmax(K_SMAX, (sumlam + sumz)/fmax(1, nlam + nz))/K_SMAX;
+    Rr->sc = fmax(K_SMAX, sumz/fmax(1, nz))/K_SMAX;
+    Rr->dual = dual; Rr->primal = prim; Rr->compl_ = comp;
+    Rr->E = fmax(dual/Rr->sd, fmax(prim, comp/Rr->sc));
+    Rr->dual_u = dual; Rr->primal_u = prim; Rr->compl_u = comp0;
+}
+
+/*
+ * The restoration phase proper: the same filter interior-point iteration on
+ *   min rho sum(n + p) + sqrt(mu)/2 |D_R (x - x_R)|^2   s.t.  rows(x, sigma) + n - p = 0,  bounds on x and sigma,  n, p >= 0
+ * started at the current point x_R with mu = max(mu, |rows|_inf), (n, p) from the closed-form minimiser, z = mu/(n, p), zero row
+ * multipliers and the bound multipliers cut at rho (IpRestoIterateInitializer).  It ends as soon as an iterate reduces the
+ * infeasibility of the original problem to 90 % and is acceptable to the original filter and to (theta_ref, phi_ref)
+ * (IpRestoFilterConvCheck); if instead the restoration problem itself converges, the original problem is locally infeasible there.
+ * On success the original iterate takes (x, sigma), its bound multipliers a step towards mu/slack at the new point (reset to 1 when
+ * one exceeds 1000) and zero row multipliers (constr_mult_reset_threshold = 0).  No second-order correction inside.
+ * Returns 1 restored, 0 failed, -1 locally infeasible, -2 iteration limit; *nit = iterations taken.
+ */
+static int restoration(Ws *W, double mu_orig, double theta_ref, double phi_ref, int iter0, int *nit, double *hist, int hist_cap, int dbg)
+{
+    const Prob *P = &W->P; const int N = W->N;
+    Resto Rs; Resto *R = &Rs; memset(R, 0, sizeof *R);
+    R->rho = RESTO_RHO;
+    R->v = calloc(N + 1, sizeof(StageRs)); R->trial = calloc(N + 1, sizeof(StageRs)); R->d = calloc(N + 1, sizeof(StageRsDir));
+    R->xR = calloc(N + 1, sizeof *R->xR); R->dr = calloc(N + 1, sizeof *R->dr);
+    StageIt *save = malloc((N + 1)*sizeof(StageIt)); memcpy(save, W->it, (N + 1)*sizeof(StageIt));
+    double (*res_c)[2] = calloc(N + 1, sizeof *res_c);
+    double (*res_d)[NR] = calloc(N + 1, sizeof *res_d);
+    double ftheta[512], fphi[512]; int nf = 0;
+    int ret = 0, k = 0;
+
+    for (int i = 0; i <= N; i++) for (int kk = 0; kk < NV; kk++) { R->xR[i][kk] = W->it[i].x[kk]; R->dr[i][kk] = 1.0/fmax(1.0, fabs(W->it[i].x[kk])); }
+    double cmax = 0;
+    for (int i = 0; i < N; i++) {
+        eval_interval(W, W->it, i, &W->ev[i], 0);
+        for (int j = 0; j < NC; j++) if (rs_on(W, j)) cmax = fmax(cmax, fabs(rs_row(W, W->it, i, &W->ev[i], j)));
+    }
+    double mu = fmax(mu_orig, cmax), tau = fmax(K_TAU_MIN, 1 - mu);
+    R->eta = sqrt(mu);
+    for (int i = 0; i < N; i++) {
+        StageRs *v = &R->v[i];
+        for (int j = 0; j < NC; j++) {
+            if (!rs_on(W, j)) { v->n[j] = v->p[j] = v->zn[j] = v->zp[j] = 1; continue; }
+            const double c = rs_row(W, W->it, i, &W->ev[i], j), a = (mu - R->rho*c)/(2*R->rho);
+            v->n[j] = a + sqrt(a*a + mu*c/(2*R->rho)); v->p[j] = c + v->n[j];
+            v->zn[j] = mu/v->n[j]; v->zp[j] = mu/v->p[j];
+        }
+    }
+    for (int i = 0; i <= N; i++) {
+        StageIt *I = &W->it[i];
+        for (int kk = 0; kk < NV; kk++) { I->zL[kk] = fmin(R->rho, I->zL[kk]); I->zU[kk] = fmin(R->rho, I->zU[kk]); }
+        for (int r = 0; r < NR; r++) { I->zLs[r] = fmin(R->rho, I->zLs[r]); I->zUs[r] = fmin(R->rho, I->zUs[r]); I->nu[r] = 0; }
+        I->lam[0] = I->lam[1] = 0;
+    }
+    W->resto = R;
+
+    double thR, phR; int okR;
+    resto_merit(W, W->it, R->v, mu, &thR, &phR, &okR);
+    const double thmax = RESTO_THETA_MAX_FACT*fmax(1.0, thR), thmin = 1e-4*fmax(1.0, thR);
+    double delta_last = 0, alpha_pr = 0, alpha_du = 0, dnorm = 0;
+    int tiny_count = 0;
+    const double mu_floor = fmin(P->tol, 1e-4)/(K_EPS + 1.0);
+    Err Er;
+
+    for (k = 0; ; k++) {
+        for (int i = 0; i < N; i++) eval_interval(W, W->it, i, &W->ev[i], 2);
+        resto_kkt_error(W, 0.0, &Er);
+        double th_o, ph_o; int ok_o;
+        merit_terms(W, W->it, mu_orig, &th_o, &ph_o, &ok_o);
+        if (hist && k > 0 && iter0 + k < hist_cap) {
+            double *hh = hist + 8*(iter0 + k);
+            hh[0] = iter0 + k; hh[1] = objective_value(W, W->it)/W->sf; hh[2] = th_o; hh[3] = Er.dual; hh[4] = log10(mu); hh[5] = dnorm; hh[6] = alpha_du; hh[7] = alpha_pr;
+        }
+        if (dbg) fprintf(stderr, "[oracle] it %3dr obj %.8e theta %.2e | resto inf_pr %.2e inf_du %.2e compl %.2e lg(mu) %5.1f |d| %.2e a_du %.2e a_pr %.2e\n",
+                         iter0 + k, objective_value(W, W->it)/W->sf, th_o, Er.primal, Er.dual, Er.compl_, log10(mu), dnorm, alpha_du, alpha_pr);
+        /* back to the original problem? (not before one step has been taken) */
+        if (k >= 1 && ok_o && th_o <= RESTO_KAPPA*theta_ref && th_o <= W->theta_max && filter_ok(W, th_o, ph_o)
+            && (cmp_le(th_o, (1 - G_THETA)*theta_ref, theta_ref) || cmp_le(ph_o - phi_ref, -G_PHI*theta_ref, phi_ref))) { ret = 1; break; }
+        /* the restoration problem itself solved: a stationary point of the infeasibility */
+        if (Er.E <= P->tol && Er.dual_u <= 1.0 && Er.primal_u <= 1e-4 && Er.compl_u <= 1e-4) {
+            double pinf = 0;
+            for (int i = 0; i < N; i++) {
+                pinf = fmax(pinf, fmax(fabs(W->ev[i].c[0]), fabs(W->ev[i].c[1])));
+                for (int r = 0; r < NR; r++) if (W->rowOn[r]) pinf = fmax(pinf, fabs(W->ev[i].d[r] - W->it[i].sig[r])/W->rs[r]);
+            }
+            ret = (pinf <= 1e-4) ? 0 : -1;
+            break;
+        }
+        if (iter0 + k >= P->maxIter) { ret = -2; break; }
+        if (k >= RESTO_MAX_ITER) { ret = 0; break; }
+
+        /* barrier parameter of the restoration problem (monotone); the proximity weight follows it */
+        {
+            Err Rm; resto_kkt_error(W, mu, &Rm);
+            int changed = 0;
+            while (Rm.E <= K_EPS*mu && mu > mu_floor) {
+                double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, pow(mu, K_MU_SUP)));
+                if (nm >= mu) break;
+                mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = 1;
+                resto_kkt_error(W, mu, &Rm);
+            }
+            if (changed) { nf = 0; R->eta = sqrt(mu); }
+        }
+        resto_merit(W, W->it, R->v, mu, &thR, &phR, &okR);
+
+        for (int i = 0; i < N; i++) {
+            const StageRs *v = &R->v[i];
+            for (int j = 0; j < NC; j++) {
+                double rh = 0;
+                if (rs_on(W, j)) rh = rs_row(W, W->it, i, &W->ev[i], j) + v->n[j] - v->p[j] + (mu - R->rho*v->n[j])/v->zn[j] - (mu - R->rho*v->p[j])/v->zp[j];
+                if (j < 2) res_c[i][j] = rh; else res_d[i][j - 2] = rh;
+            }
+        }
+        double dw = 0; int ok = compute_direction(W, mu, 0.0, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
+        if (!ok) {
+            dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last);
+            for (;;) {
+                ok = compute_direction(W, mu, dw, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir);
+                if (ok) break;
+                dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
+                if (dw > DW_MAX) break;
+            }
+            if (!ok) { if (dbg) fprintf(stderr, "[oracle] resto: regularisation failed\n"); ret = 0; break; }
+            delta_last = dw;
+        }
+
+        if (dbg >= 2) fprintf(stderr, "[oracle]    resto dw %.2e newton residual %.3e\n", dw, direction_residual(W, mu, dw, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir));
+        /* directional derivative of phi_R, step norms, fraction to the boundary */
+        double gphid = 0, rel_step = 0; dnorm = 0;
+        double amax = alpha_primal_max(W, W->dir, tau); alpha_du = alpha_dual_max(W, W->dir, tau);
+        for (int i = 0; i <= N; i++) {
+            StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
+            for (int kk = 0; kk < NV; kk++) {
+                if (!B->on[kk]) continue;
+                double Sg, gp; bar_terms(I->x[kk], B->lb[kk], B->ub[kk], B->hasL[kk], B->hasU[kk], I->zL[kk], I->zU[kk], mu, &Sg, &gp);
+                gphid += (R->eta*R->dr[i][kk]*R->dr[i][kk]*(I->x[kk] - R->xR[i][kk]) + gp)*W->dir[i].dx[kk];
+                dnorm = fmax(dnorm, fabs(W->dir[i].dx[kk]));
+                rel_step = fmax(rel_step, fabs(W->dir[i].dx[kk])/(1 + fabs(I->x[kk])));
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                double Sg, gp; bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gp);
+                gphid += gp*W->dir[i].dsig[r];
+                dnorm = fmax(dnorm, fabs(W->dir[i].dsig[r]));
+                rel_step = fmax(rel_step, fabs(W->dir[i].dsig[r])/(1 + fabs(I->sig[r])));
+            }
+            const StageRs *v = &R->v[i]; const StageRsDir *q = &R->d[i];
+            for (int j = 0; j < NC; j++) {
+                if (!rs_on(W, j)) continue;
+                gphid += (R->rho - mu/v->n[j] + K_D*mu)*q->dn[j] + (R->rho - mu/v->p[j] + K_D*mu)*q->dp[j];
+                dnorm = fmax(dnorm, fmax(fabs(q->dn[j]), fabs(q->dp[j])));
+                rel_step = fmax(rel_step, fmax(fabs(q->dn[j])/(1 + v->n[j]), fabs(q->dp[j])/(1 + v->p[j])));
+                if (q->dn[j] < 0) amax = fmin(amax, -tau*v->n[j]/q->dn[j]);
+                if (q->dp[j] < 0) amax = fmin(amax, -tau*v->p[j]/q->dp[j]);
+                if (q->dzn[j] < 0) alpha_du = fmin(alpha_du, -tau*v->zn[j]/q->dzn[j]);
+                if (q->dzp[j] < 0) alpha_du = fmin(alpha_du, -tau*v->zp[j]/q->dzp[j]);
+            }
+        }
+
+        int tiny = rel_step < 10*DBL_EPSILON;
+        double alpha = amax; int accepted = 0, ftype_armijo = 0;
+        if (tiny) {
+            accepted = 1;
+            if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { if (dbg) fprintf(stderr, "[oracle] resto: tiny steps\n"); ret = 0; break; }
+        } else tiny_count = 0;
+        double amin;
+        if (gphid < 0) {
+            amin = G_THETA;
+            amin = fmin(amin, G_PHI*thR/(-gphid));
+            if (thR <= thmin) amin = fmin(amin, K_DELTA*pow(thR, S_THETA)/pow(-gphid, S_PHI));
+        } else amin = G_THETA;
+        amin *= ALPHA_MIN_FRAC;
+        for (;;) {
+            make_trial(W, W->dir, alpha);
+            for (int i = 0; i < N; i++) for (int j = 0; j < NC; j++) { R->trial[i].n[j] = R->v[i].n[j] + alpha*R->d[i].dn[j]; R->trial[i].p[j] = R->v[i].p[j] + alpha*R->d[i].dp[j]; }
+            if (accepted) break;
+            double th_t, ph_t; int okt;
+            resto_merit(W, W->trial, R->trial, mu, &th_t, &ph_t, &okt);
+            int ftype = (gphid < 0) && (alpha*pow(-gphid, S_PHI) > K_DELTA*pow(thR, S_THETA));
+            int acc = 0;
+            if (okt && th_t <= thmax) {
+                if (ftype && thR <= thmin) acc = cmp_le(ph_t - phR, ETA_PHI*alpha*gphid, phR);
+                else acc = cmp_le(th_t, (1 - G_THETA)*thR, thR) || cmp_le(ph_t - phR, -G_PHI*thR, phR);
+                if (acc) for (int m = 0; m < nf; m++) if (th_t >= ftheta[m] && ph_t >= fphi[m]) { acc = 0; break; }
+            }
+            if (acc) { accepted = 1; ftype_armijo = ftype && cmp_le(ph_t - phR, ETA_PHI*alpha*gphid, phR); break; }
+            if (dbg >= 3) fprintf(stderr, "[oracle]      resto trial alpha %.3e theta %.6e (%.6e) phi %.10e (%.10e) ok %d ftype %d\n", alpha, th_t, thR, ph_t, phR, okt, ftype);
+            alpha *= 0.5; W->n_back++;
+            if (alpha < amin) break;
+        }
+        if (!accepted) { if (dbg) fprintf(stderr, "[oracle] resto: line search failed (alpha %.3e < %.3e, gphid %.3e thetaR %.3e)\n", alpha, amin, gphid, thR); ret = 0; break; }
+        alpha_pr = alpha;
+        if (!tiny && !ftype_armijo && nf < 512) { ftheta[nf] = (1 - G_THETA)*thR; fphi[nf] = phR - G_PHI*thR; nf++; }
+
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i]; StageBd *B = &W->bd[i]; const StageDir *d = &W->dir[i];
+            for (int kk = 0; kk < NV; kk++) {
+                if (!B->on[kk]) continue;
+                I->x[kk] = W->trial[i].x[kk];
+                if (B->hasL[kk]) { I->zL[kk] += alpha_du*d->dzL[kk]; double s = I->x[kk] - B->lb[kk]; I->zL[kk] = fmax(fmin(I->zL[kk], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                if (B->hasU[kk]) { I->zU[kk] += alpha_du*d->dzU[kk]; double s = B->ub[kk] - I->x[kk]; I->zU[kk] = fmax(fmin(I->zU[kk], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+            }
+            if (i == N) break;
+            for (int r = 0; r < NR; r++) {
+                if (!W->rowOn[r]) continue;
+                I->sig[r] = W->trial[i].sig[r];
+                I->nu[r] += alpha_pr*d->dnu[r];
+                if (W->rhasL[r]) { I->zLs[r] += alpha_du*d->dzLs[r]; double s = I->sig[r] - W->dL[r]; I->zLs[r] = fmax(fmin(I->zLs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+                if (W->rhasU[r]) { I->zUs[r] += alpha_du*d->dzUs[r]; double s = W->dU[r] - I->sig[r]; I->zUs[r] = fmax(fmin(I->zUs[r], K_SIGMA*mu/s), mu/(K_SIGMA*s)); }
+            }
+            I->lam[0] += alpha_pr*d->dlam[0]; I->lam[1] += alpha_pr*d->dlam[1];
+            StageRs *v = &R->v[i]; const StageRsDir *q = &R->d[i];
+            for (int j = 0; j < NC; j++) {
+                if (!rs_on(W, j)) continue;
+                v->n[j] = R->trial[i].n[j]; v->p[j] = R->trial[i].p[j];
+                v->zn[j] += alpha_du*q->dzn[j]; v->zn[j] = fmax(fmin(v->zn[j], K_SIGMA*mu/v->n[j]), mu/(K_SIGMA*v->n[j]));
+                v->zp[j] += alpha_du*q->dzp[j]; v->zp[j] = fmax(fmin(v->zp[j], K_SIGMA*mu/v->p[j]), mu/(K_SIGMA*v->p[j]));
+            }
+        }
+    }
+    W->resto = NULL;
+
+    if (ret == 1) {
+        /* bound multipliers of the original problem: z + alpha dz with dz = (mu - z slack_new)/slack_old (MinC_1NrmRestorationPhase::
+         * ComputeBoundMultiplierStep), alpha from the fraction-to-the-boundary rule; all of them 1 when one ends above 1000 */
+        const double tau_o = fmax(K_TAU_MIN, 1 - mu_orig);
+        double a = 1.0, zmax = 0;
+#define RS_DZ(z, sn, so) ((mu_orig - (z)*(sn))/(so))
+        for (int pass = 0; pass < 2; pass++)
+            for (int i = 0; i <= N; i++) {
+                StageIt *I = &W->it[i]; const StageIt *O = &save[i]; const StageBd *B = &W->bd[i];
+                for (int kk = 0; kk < NV; kk++) {
+                    if (!B->on[kk]) continue;
+                    if (B->hasL[kk]) { double dz = RS_DZ(O->zL[kk], I->x[kk] - B->lb[kk], O->x[kk] - B->lb[kk]); if (!pass) { if (dz < 0) a = fmin(a, -tau_o*O->zL[kk]/dz); } else { I->zL[kk] = O->zL[kk] + a*dz; zmax = fmax(zmax, I->zL[kk]); } }
+                    if (B->hasU[kk]) { double dz = RS_DZ(O->zU[kk], B->ub[kk] - I->x[kk], B->ub[kk] - O->x[kk]); if (!pass) { if (dz < 0) a = fmin(a, -tau_o*O->zU[kk]/dz); } else { I->zU[kk] = O->zU[kk] + a*dz; zmax = fmax(zmax, I->zU[kk]); } }
+                }
+                if (i == N) break;
+                for (int r = 0; r < NR; r++) {
+                    if (!W->rowOn[r]) continue;
+                    if (W->rhasL[r]) { double dz = RS_DZ(O->zLs[r], I->sig[r] - W->dL[r], O->sig[r] - W->dL[r]); if (!pass) { if (dz < 0) a = fmin(a, -tau_o*O->zLs[r]/dz); } else { I->zLs[r] = O->zLs[r] + a*dz; zmax = fmax(zmax, I->zLs[r]); } }
+                    if (W->rhasU[r]) { double dz = RS_DZ(O->zUs[r], W->dU[r] - I->sig[r], W->dU[r] - O->sig[r]); if (!pass) { if (dz < 0) a = fmin(a, -tau_o*O->zUs[r]/dz); } else { I->zUs[r] = O->zUs[r] + a*dz; zmax = fmax(zmax, I->zUs[r]); } }
+                }
+            }
+#undef RS_DZ
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i]; const StageBd *B = &W->bd[i];
+            if (zmax > BOUND_MULT_RESET) {
+                for (int kk = 0; kk < NV; kk++) if (B->on[kk]) { if (B->hasL[kk]) I->zL[kk] = 1; if (B->hasU[kk]) I->zU[kk] = 1; }
+                for (int r = 0; r < NR; r++) if (i < N && W->rowOn[r]) { if (W->rhasL[r]) I->zLs[r] = 1; if (W->rhasU[r]) I->zUs[r] = 1; }
+            }
+            I->lam[0] = I->lam[1] = 0;
+            for (int r = 0; r < NR; r++) I->nu[r] = 0;
+        }
+    } else {
+        /* the original iterate keeps its bound multipliers (row multipliers zero); (x, sigma) are left where the restoration phase ended */
+        for (int i = 0; i <= N; i++) {
+            StageIt *I = &W->it[i]; const StageIt *O = &save[i];
+            memcpy(I->zL, O->zL, sizeof I->zL); memcpy(I->zU, O->zU, sizeof I->zU); memcpy(I->zLs, O->zLs, sizeof I->zLs); memcpy(I->zUs, O->zUs, sizeof I->zUs);
+            I->lam[0] = I->lam[1] = 0;
+            for (int r = 0; r < NR; r++) I->nu[r] = 0;
+        }
+    }
+    if (dbg) fprintf(stderr, "[oracle] restoration phase: %d iterations, outcome %d\n", k, ret);
+    free(R->v); free(R->trial); free(R->d); free(R->xR); free(R->dr); free(save); free(res_c); free(res_d);
+    *nit = k;
+    return ret;
+}
 
 int oracle_solve(const int *ip, const double *dp, const double *ds, const double *grad, const double *curv,
                  const double *bmax, double *z_out, double *lam_out, double *stats, double *hist, int hist_cap)
@@ -1715,7 +2190,21 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
             alpha *= 0.5; ls++; W->n_back++;
             if (alpha < amin) break;
         }
-        if (!accepted) { status = OR_STATUS_LINESEARCH; break; }
+        if (!accepted) {
+            /* the step became too small: feasibility restoration (IpBacktrackingLineSearch: goto_resto).  Not from an almost feasible
+             * point (resto_failure_feasibility_threshold = 100 tol); restated for the static loss rows, like the kernels (msd_resto.hpp) */
+            if (!g_resto || P->lossKind == 2 || P->intLosses || R.primal <= 1e2*P->tol) { status = OR_STATUS_LINESEARCH; break; }
+            if (W->nfilt < 512) { W->filt_theta[W->nfilt] = (1 - G_THETA)*theta; W->filt_phi[W->nfilt] = phi - G_PHI*theta; W->nfilt++; }
+            int nit = 0;
+            const int rr = restoration(W, mu, theta, phi, iter, &nit, hist, hist_cap, dbg);
+            W->n_resto++;
+            if (rr == 1) { iter += nit - 1; acc_count = 0; tiny_count = 0; alpha_pr = alpha_du = dnorm = 0; continue; }
+            iter += nit;
+            for (int i = 0; i < N; i++) eval_interval(W, W->it, i, &W->ev[i], 2);
+            kkt_error(W, 0.0, &R);
+            status = rr == -1 ? OR_STATUS_INFEASIBLE : rr == -2 ? OR_STATUS_MAXITER : OR_STATUS_LINESEARCH;
+            break;
+        }
         alpha_pr = alpha;
 
         /* filter augmentation (W&B eq. (22)) */
@@ -1789,7 +2278,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
     if (stats) {
         stats[OR_ST_STATUS] = status; stats[OR_ST_ITERS] = iter; stats[OR_ST_OBJ] = objective_value(W, W->it)/W->sf;
         stats[OR_ST_KKT] = R.E; stats[OR_ST_MU] = mu; stats[OR_ST_DUAL_INF] = R.dual_u; stats[OR_ST_CONSTR_VIOL] = R.primal_u; stats[OR_ST_COMPL] = R.compl_u;
-        stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back;
+        stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back; stats[OR_ST_N_RESTO] = W->n_resto;
     }
     free(res_c); free(res_d); free(soc_c); free(soc_d);
     ws_free(W);
@@ -1875,7 +2364,7 @@ int oracle_solve_start(const int *ip, const double *dp, const double *ds, const 
 {
     int st = (start == 1) ? solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
                           : oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
-    if (st < 0 && st != OR_STATUS_MAXITER) {
+    if (st < 0 && st != OR_STATUS_MAXITER && st != OR_STATUS_INFEASIBLE) {
         const double spent = stats[OR_ST_ITERS];
         st = (start == 1) ? oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
                           : solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);

@@ -92,16 +92,18 @@ enum {
     OR_ST_N_REG,          /* iterations that needed inertia correction                       */
     OR_ST_N_SOC,          /* second-order corrections taken                                  */
     OR_ST_N_BACKTRACK,    /* total backtracking steps                                        */
+    OR_ST_N_RESTO,        /* restoration phases entered                                      */
     OR_ST_COUNT
 };
 
 #define OR_STATUS_SOLVED 0
 #define OR_STATUS_ACCEPTABLE 1
 #define OR_STATUS_MAXITER (-1)
-#define OR_STATUS_LINESEARCH (-2)    /* step became too small: IPOPT would enter restoration  */
+#define OR_STATUS_LINESEARCH (-2)    /* the restoration phase failed (or was entered at an almost feasible point): IPOPT's Restoration_Failed */
 #define OR_STATUS_REGULARIZATION (-3)
 #define OR_STATUS_NUMERIC (-4)
 #define OR_STATUS_TINY_STEP (-5)
+#define OR_STATUS_INFEASIBLE (-6)    /* the restoration phase converged to a stationary point of the infeasibility: IPOPT's Infeasible_Problem_Detected */
 
 /*
  * Solve one OCP.  ds/grad/curv have N entries (grad already divided by 1000, ocp.py:195),
@@ -149,6 +151,9 @@ void oracle_stage_eval(const int *ip, const double *dp, double b, double w, doub
 
 /* parameter block of the dynamic loss model (efficiency.py), see ms_oracle.c; the pointer must stay valid */
 void oracle_set_loss_table(const double *block);
+
+/* feasibility restoration phase on (default) / off: off, a solve whose line search breaks down ends with OR_STATUS_LINESEARCH like before */
+void oracle_set_restoration(int on);
 void oracle_loss_rows(const double *block, double f, double v, double *out12);
 
 /* NLP functions at z (reference layout): objective and the constraint rows in the reference's order. */

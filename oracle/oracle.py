@@ -21,7 +21,7 @@ HERE = Path(__file__).resolve().parent
 IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, INTEGRATOR=8, COLL_DEGREE=9, NEWTON_ITERS=10, INTEGRATE_LOSSES=11, COUNT=12)
 DP = dict(SR0=0, SR1=1, SR2=2, G=3, RHO=4, FMAX=5, FMIN=6, FMIN_PN=7, PW_UPPER=8, PW_LOWER=9, ACC_MIN=10, ACC_MAX=11,
           LOSS_CT=12, LOSS_CR=13, VMIN_SQ=14, OBJ_DEN=15, TOL=16, T0=17, TEND=18, V0SQ=19, VNSQ=20, INT_ATOL=21, INT_RTOL=22, COUNT=23)
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, COUNT=11)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, N_RESTO=11, COUNT=12)
 
 _lib = None
 

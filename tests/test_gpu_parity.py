@@ -19,12 +19,12 @@ OBJ_RTOL = 1e-8
 Z_RTOL = 1e-6
 
 
-def _solver(train, track, N, energyOptimal=True, numSteps=1, numApproxSteps=1, start='reference', maxIterations=500):
+def _solver(train, track, N, energyOptimal=True, numSteps=1, numApproxSteps=1, start='reference', maxIterations=500, restoration=True):
     # the oracle comparisons pin the whole iteration, so both sides start from the same point; 'reference' unless a test says otherwise
     from mseetc.ocp import casadiSolver
     opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal,
                 integrationOptions=dict(numSteps=numSteps, numApproxSteps=numApproxSteps))
-    return casadiSolver(train, track, opts, startingPoint=start)
+    return casadiSolver(train, track, opts, startingPoint=start, restoration=restoration)
 
 
 def _compare(solver, prob, T, **kw):
@@ -469,23 +469,29 @@ def test_profile_start_same_optimum_fewer_iterations(case):
 
 def test_profile_start_falls_back_to_the_reference_point():
     # a scenario that breaks down from the profile start (here: infeasible running times, the line search gives up) is repeated
-    # from the reference's point inside the launch; the iterations of both attempts are reported, exactly like the oracle does
+    # from the reference's point inside the launch; the iterations of both attempts are reported, exactly like the oracle does.
+    # (restoration=False: with the restoration phase a hopeless scenario spends hundreds of iterations there before either attempt gives
+    # up -- tests/test_restoration.py -- and where exactly that happens is not reproducible to a few iterations)
     from oracle import oracle
     train, track = cases.train_default(), cases.track_00()
-    fast = _solver(train, track, 100, start='profile')
-    cold = _solver(train, track, 100, start='reference')
+    fast = _solver(train, track, 100, start='profile', restoration=False)
+    cold = _solver(train, track, 100, start='reference', restoration=False)
     T = [1541.0, 900.0, 1000.0]
     res, ref = fast.solveBatch(T, classifyFailures=False), cold.solveBatch(T, classifyFailures=False)
     assert list(res['status'] >= 0) == [True, False, False] == list(ref['status'] >= 0)
     prob = cases.oracle_problem(train, track, 100)
-    for k in (1, 2):
-        for got, start in ((res, 'profile'), (ref, 'reference')):      # both directions: the second attempt starts from the other point
-            chk = oracle.solve(prob, prob.scenario(T[k]), start=start)
-            assert got['status'][k] == int(chk['stats']['STATUS'])
-            # both attempts are counted; where exactly a hopeless line search gives up depends on alpha_min, whose powers the device
-            # evaluates in single precision: a few iterations either way
-            assert abs(int(got['iterations'][k]) - int(chk['stats']['ITERS'])) <= 6
-        assert abs(int(res['iterations'][k]) - int(ref['iterations'][k])) <= 6        # the same two attempts in the other order
+    oracle.lib().oracle_set_restoration(0)
+    try:
+        for k in (1, 2):
+            for got, start in ((res, 'profile'), (ref, 'reference')):      # both directions: the second attempt starts from the other point
+                chk = oracle.solve(prob, prob.scenario(T[k]), start=start)
+                assert got['status'][k] == int(chk['stats']['STATUS'])
+                # both attempts are counted; where exactly a hopeless line search gives up depends on alpha_min, whose powers the device
+                # evaluates in single precision: a few iterations either way
+                assert abs(int(got['iterations'][k]) - int(chk['stats']['ITERS'])) <= 6
+            assert abs(int(res['iterations'][k]) - int(ref['iterations'][k])) <= 6        # the same two attempts in the other order
+    finally:
+        oracle.lib().oracle_set_restoration(1)
     # the iteration limit is not a breakdown: no second attempt, and a cap between the two starting points' needs separates them
     few = _solver(train, track, 100, start='profile', maxIterations=12).solveBatch([1541.0])
     assert few['status'][0] == -1 and few['iterations'][0] == 12
@@ -821,8 +827,8 @@ def test_single_process_multi_device_dispatch():
 def test_infeasible_running_time_is_reported_like_ipopt(capsys):
     """
     ocp.py:362-370: a failed solve prints IPOPT's status and returns (None, stats).  A running time below the minimum is
-    'Infeasible_Problem_Detected' in IPOPT (end of its restoration phase); here the status comes from the minimum-time
-    certificate (casadiSolver._classify_failures).  Feasible neighbours in the same batch are untouched; a scenario that is
+    'Infeasible_Problem_Detected' in IPOPT (end of its restoration phase); here the restoration phase of the device ends such a solve
+    with a failure status of its own and the minimum-time certificate (casadiSolver._classify_failures) names the reason.  Feasible neighbours in the same batch are untouched; a scenario that is
     feasible but fails for another reason would keep its own status.
     """
     from mseetc import _device
@@ -839,8 +845,10 @@ def test_infeasible_running_time_is_reported_like_ipopt(capsys):
         tmin = float(twin.solveBatch([5000.0])['z'][0][-2])
         edge = s.solveBatch([tmin*1.002, tmin*0.998])
         assert edge['status'][0] == 0 and edge['status'][1] == _device.STATUS_INFEASIBLE
+        # the device's own verdict: a failure -- 'Restoration_Failed' where the restoration phase breaks down itself, 'Infeasible_Problem_
+        # Detected' where it converges, or the iteration limit (tests/test_restoration.py); the certificate above settles it
         raw = s.solveBatch([900.0], classifyFailures=False)
-        assert raw['status'][0] < 0 and raw['status'][0] != _device.STATUS_INFEASIBLE
+        assert raw['status'][0] in (_device.STATUS_MAXITER, _device.STATUS_LINESEARCH, _device.STATUS_INFEASIBLE)
         s.close(); twin.close()
 
 

@@ -1,0 +1,179 @@
+"""
+Feasibility restoration phase (what IPOPT does behind ocp.py:290,359 when its filter line search breaks down, surfaced at
+ocp.py:362-370): oracle/ms_oracle.c: restoration() restates IPOPT's MinC_1Nrm restoration phase, csrc/msd_resto.hpp is the device code.
+
+No reference-held vector exists for it (CasADi/IPOPT cannot run here): the pins are (1) the Newton system of the restoration problem
+checked equation by equation inside the oracle (ORACLE_DEBUG >= 2: direction_residual), (2) the optimum a restored solve reaches being the
+optimum the other starting point reaches without restoration, (3) the kernel following the oracle iterate for iterate through the
+restoration phases (emulation here, GPU below).
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import cases
+
+
+def _loose_case():
+    # 8 to 13 times the minimum running time from the reference's starting point: the power rows are violated by 60 % there and the
+    # filter line search breaks down on the way (test_gpu_parity.py::test_loose_schedules_converge_from_both_starts)
+    return cases.train_default(), cases.track_00(), 100, [12000.0, 20000.0]
+
+
+def test_oracle_restoration_reaches_the_optimum_of_the_other_start():
+    from oracle import oracle
+    train, track, N, Ts = _loose_case()
+    prob = cases.oracle_problem(train, track, N)
+    for T in Ts:
+        ref = oracle.solve(prob, prob.scenario(T), start='profile')
+        assert ref['stats']['STATUS'] == 0 and ref['stats']['N_RESTO'] == 0
+        res = oracle.solve(prob, prob.scenario(T), start='reference')
+        # converged from the reference's point through the restoration phase -- not by the restart from the other starting point,
+        # which would have added the failed attempt's iterations and left N_RESTO = 0 in the record of the second attempt
+        assert res['stats']['STATUS'] == 0 and res['stats']['N_RESTO'] >= 1
+        assert abs(res['stats']['OBJ'] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-6
+    # without the phase the same solve ends where the line search breaks down (and the restart has to rescue it)
+    oracle.lib().oracle_set_restoration(0)
+    try:
+        res = oracle.solve(prob, prob.scenario(Ts[0]), start='reference')
+        assert res['stats']['STATUS'] == 0 and res['stats']['N_RESTO'] == 0
+    finally:
+        oracle.lib().oracle_set_restoration(1)
+
+
+def test_oracle_restoration_on_an_infeasible_running_time():
+    """
+    A running time below the minimum: the restoration phases reduce the infeasibility to what the train cannot make up and the solve
+    ends with a failure status -- Restoration_Failed (-2: the restoration problem's own line search breaks down; its 1-norm objective
+    leaves the distribution of the missing time over the intervals undetermined, the Newton systems are nearly singular along it),
+    Infeasible_Problem_Detected (-6) or the iteration limit.  Never a success, and the infeasibility that is left is the missing time.
+    """
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00(12000)
+    prob = cases.oracle_problem(train, track, 30, maxIterations=200)
+    res = oracle.solve(prob, prob.scenario(300.0), start='reference')
+    assert res['stats']['STATUS'] in (-1, -2, -6) and res['stats']['N_RESTO'] >= 1
+    fast = cases.oracle_problem(train, track, 30, energyOptimal=False)
+    tmin = oracle.solve(fast, fast.scenario(2000.0), start='profile')
+    assert tmin['stats']['STATUS'] == 0 and tmin['z'][-2] > 300.0
+
+
+def test_emulated_restoration_phase_follows_the_oracle():
+    """
+    The kernel (host emulation: tests/hip_emu) through two restoration phases of an infeasible problem, history row by history row
+    against the oracle: entry (iteration and point), the restoration iterations (original objective and infeasibility at the restoration
+    iterates, dual infeasibility and barrier parameter of the restoration problem) and the return to the general iteration.
+    """
+    from test_kernel_emulation import load_emulation
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    emu = load_emulation()
+    N, crop, T, cap = 30, 12000, 300.0, 64
+    train, track = cases.train_default(), cases.track_00(crop)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=60, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='reference')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((cap, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), cap) == 0
+    prob = cases.oracle_problem(train, track, N, maxIterations=60)
+    ref = oracle.solve(prob, prob.scenario(T), start='reference', history=True)
+    assert int(st[0, ST['STATUS']]) == int(ref['stats']['STATUS']) == -1
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 60
+    assert int(st[0, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
+    h = ref['hist']
+    for i in range(60):
+        assert np.allclose(hist[i, 1:5], h[i, 1:5], rtol=1e-4, atol=1e-9), (i, hist[i], h[i])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+RK11 = dict(numSteps=1, numApproxSteps=1)      # the transcription cases.oracle_problem packs by default
+
+
+@gpu
+def test_gpu_loose_schedules_from_the_reference_start_through_restoration():
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train, track, N, Ts = _loose_case()
+    opts = dict(numIntervals=N, maxIterations=500, integrationOptions=RK11)
+    ref = casadiSolver(train, track, opts, startingPoint='profile')
+    best = ref.solveBatch(Ts)
+    ref.close()
+    assert np.all(best['status'] == 0) and np.all(best['stats'][:, ST['N_RESTO']] == 0)
+    s = casadiSolver(train, track, opts, startingPoint='reference')
+    res = s.solveBatch(Ts)
+    s.close()
+    assert np.all(res['status'] == 0), res['status']
+    assert np.all(res['stats'][:, ST['N_RESTO']] >= 1)          # through the restoration phase, not the restart
+    assert np.max(np.abs(res['cost'] - best['cost'])/np.abs(best['cost'])) < 1e-7
+    prob = cases.oracle_problem(train, track, N)
+    for k, T in enumerate(Ts):
+        chk = oracle.solve(prob, prob.scenario(T), start='reference')
+        assert chk['stats']['STATUS'] == 0 and chk['stats']['N_RESTO'] >= 1
+        assert abs(res['cost'][k] - chk['stats']['OBJ']) <= 1e-7*abs(chk['stats']['OBJ'])
+    # restoration=False: ABI 4's behaviour -- the line search breaks down, the scenario is solved again from the other starting point
+    s = casadiSolver(train, track, opts, startingPoint='reference', restoration=False)
+    old = s.solveBatch(Ts)
+    s.close()
+    assert np.all(old['status'] == 0) and np.all(old['stats'][:, ST['N_RESTO']] == 0)
+    assert np.max(np.abs(old['cost'] - best['cost'])/np.abs(best['cost'])) < 1e-7
+    # the package's default transcription (joint RK4 for the time, numApproxSteps = 0): 12 000 s breaks down from BOTH starting points
+    # without the restoration phase, and converges from both to the same optimum with it
+    costs = []
+    for start in ('profile', 'reference'):
+        s = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500), startingPoint=start)
+        r = s.solveBatch([12000.0])
+        s.close()
+        assert r['status'][0] == 0 and r['stats'][0, ST['N_RESTO']] >= 1
+        costs.append(r['cost'][0])
+    assert abs(costs[0] - costs[1]) <= 1e-6*abs(costs[1])
+
+
+@gpu
+def test_gpu_restoration_phase_follows_the_oracle():
+    "The GPU kernel through the restoration phases of an infeasible problem, against the oracle (same case as the emulation test, 120 iterations)."
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    N, crop, T = 30, 12000, 300.0
+    train, track = cases.train_default(), cases.track_00(crop)
+    s = casadiSolver(train, track, dict(numIntervals=N, maxIterations=60, integrationOptions=RK11), startingPoint='reference')
+    res = s.solveBatch([T, T*1.0001], classifyFailures=False)
+    s.close()
+    prob = cases.oracle_problem(train, track, N, maxIterations=60)
+    for k, Tk in enumerate([T, T*1.0001]):
+        ref = oracle.solve(prob, prob.scenario(Tk), start='reference')
+        assert res['status'][k] == int(ref['stats']['STATUS']) == -1
+        assert res['iterations'][k] == int(ref['stats']['ITERS'])
+        assert int(res['stats'][k, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-4*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
+
+
+@gpu
+@pytest.mark.parametrize('N,variant', [(63, 'both'), (127, 'rg'), (255, 'both'), (300, 'rg'), (450, 'both')])
+def test_gpu_restoration_on_every_geometry(N, variant):
+    """
+    One and several waves per scenario, one and two nodes per lane, general and structure-specialised kernels: a loose schedule from the
+    reference's point (restoration phase) reaches the optimum of the profile start.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    train = cases.train_default() if variant == 'both' else cases.train_fig10()
+    track = cases.track_00()
+    T = [9000.0, 14000.0]
+    ref = casadiSolver(train, track, dict(numIntervals=N, maxIterations=800, integrationOptions=RK11), startingPoint='profile')
+    best = ref.solveBatch(T)
+    ref.close()
+    s = casadiSolver(train, track, dict(numIntervals=N, maxIterations=800, integrationOptions=RK11), startingPoint='reference')
+    res = s.solveBatch(T)
+    s.close()
+    assert np.all(best['status'] == 0) and np.all(res['status'] == 0), (best['status'], res['status'])
+    assert np.max(np.abs(res['cost'] - best['cost'])/np.abs(best['cost'])) < 1e-6
