@@ -554,6 +554,24 @@ def alt_workloads(args, device):
                       "including transfers; resolves_per_s counts successful re-solves only; a re-solve whose measured state no longer allows the arrival time "
                       "is repeated with the arrival time moved to its certified minimum (arrival_time_relaxed)")
     alt["c4"] = c4
+
+    # the restoration phase (cold path): schedules 8 to 13 times the minimum running time from the reference's starting point, where its
+    # filter line search breaks down on the way -- one launch, not timed against anything
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    train, track, N = wl.config('c1')
+    Tl = np.linspace(11000.0, 20000.0, 64)
+    out = {}
+    for resto in (True, False):
+        s = casadiSolver(train, track, wl.options(N), device=device, startingPoint='reference', restoration=resto)
+        r = s.solveBatch(Tl)
+        s.close()
+        out["restoration" if resto else "restart_only"] = {"converged": int(np.sum(r['status'] >= 0)), "scenarios": len(Tl), "restoration_phases": int(np.sum(r['stats'][:, ST['N_RESTO']])),
+                                                           "ip_iterations_mean": float(np.mean(r['iterations'])), "kernel_ms": float(r['kernel_ms']),
+                                                           "cost_sum": float(np.sum(r['cost'][r['status'] >= 0]))}
+    out["workload"] = ("config 1 problem, 64 running times 11000 ... 20000 s (8 to 13 times the minimum) from the reference's starting point: with the feasibility "
+                       "restoration phase (IPOPT's behaviour, default) and with the restart from the other starting point only")
+    alt["loose_schedules_reference_start"] = out
     return alt
 
 

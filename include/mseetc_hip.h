@@ -48,8 +48,9 @@ extern "C" {
  * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
  * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the
  * iterations.  A scenario whose line search breaks down enters the feasibility restoration phase like in IPOPT (msd_resto.hpp; kernels
- * with static loss rows, N <= 560, unless no_restoration is set); one that still ends with a breakdown (any failure but the iteration
- * limit and MSD_STATUS_INFEASIBLE) is solved again from the other starting point inside the same launch.
+ * with static loss rows and Runge-Kutta shooting, N <= 511, unless no_restoration is set); one that still ends with a breakdown (any
+ * failure but MSD_STATUS_INFEASIBLE and the iteration limit -- that one too when a restoration phase came before it) is solved again
+ * from the other starting point inside the same launch.
  */
 #define MSD_START_REFERENCE 0
 #define MSD_START_PROFILE 1

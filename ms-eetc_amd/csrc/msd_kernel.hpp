@@ -2915,14 +2915,15 @@ struct Solver {
 #include "msd_resto.hpp"
 
     /* the general iteration hands a scenario whose line search broke down to the restoration phase (STATUS_RESTO, the iterate parked in the
-     * work area) and is entered again with `resume` afterwards: kernels with static loss rows whose horizon fits the LDS */
+     * work area) and is entered again with `resume` afterwards: the kernels with static loss rows and explicit Runge-Kutta shooting of up to four
+     * waves (N <= 511: every BASELINE configuration); the others keep the restart from the other starting point */
 #ifndef MSD_RESTO
 #define MSD_RESTO 1      /* 0: kernels without the restoration phase (A/B builds) */
 #endif
 #ifndef MSD_RESTO_VARIANT
 #define MSD_RESTO_VARIANT 0
 #endif
-    static constexpr bool HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM;
+    static constexpr bool HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM && !GEN && NT <= 256;
     static constexpr int STATUS_RESTO = -101;
 
     template <bool FL>
@@ -3646,7 +3647,10 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                 }
             }
             __syncthreads();
-            if (st >= 0 || st == MSD_STATUS_MAXITER || st == MSD_STATUS_INFEASIBLE) break;
+            /* no second attempt after a success, a verdict of infeasibility or the iteration limit -- unless the solve ran into that limit after a
+             * restoration phase (it can leave the iterate where the original iteration only crawls; the other starting point is the way out) */
+            if (st >= 0 || st == MSD_STATUS_INFEASIBLE) break;
+            if (st == MSD_STATUS_MAXITER && !(SolverT::HAS_RESTO && stats[(size_t)MSD_ST_COUNT*sidx + MSD_ST_N_RESTO] > 0)) break;
             spent = iters;
             if (guess) guess = nullptr;      /* a warm start that breaks down: once more from the problem's own starting point */
             else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;

@@ -2364,7 +2364,8 @@ int oracle_solve_start(const int *ip, const double *dp, const double *ds, const 
 {
     int st = (start == 1) ? solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
                           : oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
-    if (st < 0 && st != OR_STATUS_MAXITER && st != OR_STATUS_INFEASIBLE) {
+    /* (the iteration limit after a restoration phase counts as a breakdown: the phase can leave the iterate where the original iteration only crawls) */
+    if (st < 0 && st != OR_STATUS_INFEASIBLE && (st != OR_STATUS_MAXITER || stats[OR_ST_N_RESTO] > 0)) {
         const double spent = stats[OR_ST_ITERS];
         st = (start == 1) ? oracle_solve(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap)
                           : solve_from_profile(ip, dp, ds, grad, curv, bmax, z_out, lam_out, stats, hist, hist_cap);
