@@ -294,6 +294,8 @@ template <class T> __device__ __forceinline__ void interval_map(const DevProb &P
  * dynamic loss model (reference: mseetc/efficiency.py:7-141 with utils.py:197-220 and train.py:214-217).
  * Parameter block: forceMax, powerMax, vTurn, vMin, vMax, auxiliaries, cgT, cgB, R, V, totalMass, nx, ny, xb[nx+1], yb[ny+1],
  * coef[nx][ny][4][4] -- bicubic patches (about the cell centres) of the not-a-knot spline of the measured motor+converter losses.
+ * With vTurn = 0 the table is the total loss power itself over (signed force [N], speed) and the gear / auxiliaries / transformer terms are
+ * skipped: any loss function L(F, v) the reference accepts (train.py:190-219), tabulated by the host (mseetc/efficiency.py: TabulatedLosses).
  * ---------------------------------------------------------------------------------------- */
 struct DynLoss {
     double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
@@ -334,11 +336,14 @@ __device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, doub
     const Jet F = Jet{f, 1, 0, 0, 0, 0}*D.M, vv = Jet{v, 0, 1, 0, 0, 0};
     const bool inside = (v >= D.vMin && v <= D.vMax);
     const Jet vc = inside ? vv : Jet{v < D.vMin ? D.vMin : D.vMax, 0, 0, 0, 0, 0};                       /* efficiency.py:40 */
-    const Jet absF = traction ? F : F*(-1.0);
-    const Jet load = (vc.v <= D.vTurn) ? absF*(100/D.Fmax) : (absF*vc)*(100/D.Pmax);                      /* efficiency.py:7-12 */
+    /* vTurn = 0 marks a direct table: total losses [W] over (signed force [N], speed) -- a user-supplied loss function L(F, v)
+     * (train.py:190-219 accepts any) tabulated by the host, traction and braking side as separate splines that meet in a cell edge at F = 0 */
+    const bool direct = !(D.vTurn > 0);
+    const Jet absF = (traction || direct) ? F : F*(-1.0);
+    const Jet load = direct ? absF : (vc.v <= D.vTurn) ? absF*(100/D.Fmax) : (absF*vc)*(100/D.Pmax);     /* efficiency.py:7-12 */
     double t[6];
     table_eval(D, load.v, vc.v, t);
-    if (!(t[0] > 0)) return Jet{0, 0, 0, 0, 0, 0};                                                        /* efficiency.py:137 */
+    if (!direct && !(t[0] > 0)) return Jet{0, 0, 0, 0, 0, 0};                                             /* efficiency.py:137 */
     Jet motor;
     motor.v = t[0];
     motor.g0 = t[1]*load.g0 + t[2]*vc.g0;
@@ -346,6 +351,7 @@ __device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, doub
     motor.h00 = t[1]*load.h00 + t[2]*vc.h00 + t[3]*load.g0*load.g0 + 2*t[4]*load.g0*vc.g0 + t[5]*vc.g0*vc.g0;
     motor.h01 = t[1]*load.h01 + t[2]*vc.h01 + t[3]*load.g0*load.g1 + t[4]*(load.g0*vc.g1 + load.g1*vc.g0) + t[5]*vc.g0*vc.g1;
     motor.h11 = t[1]*load.h11 + t[2]*vc.h11 + t[3]*load.g1*load.g1 + 2*t[4]*load.g1*vc.g1 + t[5]*vc.g1*vc.g1;
+    if (direct) return motor*(1/D.M);                                                                     /* train.py:216 */
     const Jet pW = traction ? F*vv : (F*vv)*(-1.0);                                                        /* efficiency.py:108-109 */
     const Jet gear = pW*(traction ? D.cgT : D.cgB);                                                        /* efficiency.py:112-116 */
     const Jet Pm = traction ? (pW + gear) + (motor + D.aux) : (pW - gear) - (motor + D.aux);

@@ -154,6 +154,94 @@ class DynamicLosses():
         return np.concatenate([head, self.table.flat()])
 
 
+class _JoinedTable():
+    "Two BicubicTable objects over the same y grid that meet at x = 0 (a cell edge): one block of bicubic patches for the device."
+
+    def __init__(self, neg, pos):
+
+        assert neg.xb[-1] == 0.0 and pos.xb[0] == 0.0 and np.array_equal(neg.yb, pos.yb)
+        self.neg, self.pos = neg, pos
+        self.xb = np.concatenate([neg.xb, pos.xb[1:]])
+        self.yb = pos.yb
+        self.coef = np.concatenate([neg.coef, pos.coef], axis=0)
+
+    def eval(self, x, y):
+        return (self.pos if np.real(x) >= 0 else self.neg).eval(x, y)
+
+    def flat(self):
+        return np.concatenate([[len(self.xb) - 1, len(self.yb) - 1], self.xb, self.yb, self.coef.reshape(-1)])
+
+
+class TabulatedLosses():
+    """
+    Any loss function `L(F [N], v [m/s]) -> [W]` for the device.  The reference hands `train.powerLosses` to CasADi, which traces whatever
+    the lambda computes (train.py:190-219, utils.py:197-220); the device has no symbolic layer, so a callable that is neither zero nor a
+    constant-efficiency model is sampled on a (force, speed) grid over the train's operating range and shipped as bicubic patches of the
+    interpolating (not-a-knot) spline -- the traction side F >= 0 and the braking side F <= 0 as separate splines, because the reference
+    splits the function at F = 0 and extends each side linearly (utils.py:197-220), which the device model does on the table.  A function
+    that is a polynomial of degree <= 3 in F and in v on each side is represented exactly; otherwise `maxDeviation` holds the largest
+    difference found between function and table at the cell centres, relative to the largest loss on the grid (a warning is raised above
+    `tolerance`); refine with `numForce` / `numVelocity`.
+
+    Calling the object evaluates the user's function itself (post-processing reports the losses of the function, like the reference);
+    `tabulated(F, v)` evaluates what the device sees.  Outside the speed range the table is continued constantly in v; the force range covers
+    the train's limits with a margin of 5 %.
+    """
+
+    KIND = 2      # utils.LOSS_DYNAMIC: shipped as a parameter block + table like the dynamic model
+
+    def __init__(self, fun, forceMin, forceMax, velocityMax, numForce=24, numVelocity=32, velocityMin=0.25, tolerance=1e-4):
+
+        import warnings
+
+        self.fun = fun
+        fpos = np.linspace(0.0, 1.05*float(forceMax), int(numForce) + 1)
+        lo = min(float(forceMin), -0.05*float(forceMax))      # a train without regenerative brake still gets a braking side (it stays inactive)
+        fneg = np.linspace(1.05*lo, 0.0, int(numForce) + 1)
+        vs = np.linspace(float(velocityMin), 1.1*float(velocityMax), int(numVelocity) + 1)
+
+        sample = lambda fs: np.array([[float(fun(float(f), float(v))) for v in vs] for f in fs])
+        vpos, vneg = sample(fpos), sample(fneg)
+
+        if not (np.all(np.isfinite(vpos)) and np.all(np.isfinite(vneg))):
+            raise ValueError("The power-losses function returns non-finite values on the operating range of the train!")
+
+        self.table = _JoinedTable(BicubicTable(fneg, vs, vneg), BicubicTable(fpos, vs, vpos))
+        self.forceMax = float(forceMax)
+        self.vMin, self.vMax = float(vs[0]), float(vs[-1])
+
+        # how well does the table follow the function between the samples?
+        scale = max(np.max(np.abs(vpos)), np.max(np.abs(vneg)), 1e-300)
+        dev = 0.0
+        for fs in (fpos, fneg):
+            for f in 0.5*(fs[:-1] + fs[1:]):
+                for v in 0.5*(vs[:-1] + vs[1:]):
+                    dev = max(dev, abs(self.tabulated(f, v) - float(fun(float(f), float(v))))/scale)
+        self.maxDeviation = dev
+
+        if dev > tolerance:
+            warnings.warn("The tabulated power-losses function deviates from the function by {:.1e} of its largest value: "
+                          "increase numForce / numVelocity (train.lossesTableSize).".format(dev))
+
+    def __call__(self, f, v):
+        return self.fun(f, v)
+
+    def tabulated(self, f, v):
+        "The device's view of the function (before the split at F = 0)."
+
+        vr = np.real(v)
+        vc = v if self.vMin <= vr <= self.vMax else (self.vMin if vr < self.vMin else self.vMax)
+
+        return self.table.eval(f, vc)[0]
+
+    def parameters(self, totalMass):
+        "Parameter block in the layout of the dynamic model with vTurn = 0: the table is the loss power itself over (signed force, speed)."
+
+        head = [self.forceMax, 0.0, 0.0, self.vMin, self.vMax, 0.0, 0.0, 0.0, 1.0, 1.0, float(totalMass)]
+
+        return np.concatenate([head, self.table.flat()])
+
+
 def motorLossesFunction(train, detailedOutput=False):
     "Spline of the measured motor + converter losses; updates the train limits to match the data (efficiency.py:54-98)."
 

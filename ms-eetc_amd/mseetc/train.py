@@ -16,7 +16,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .utils import Options, StaticLosses, checkTTOBenchVersion, convertUnit, splitLosses
+from .utils import Options, StaticLosses, checkTTOBenchVersion, closedFormLosses, convertUnit, splitLosses
 
 _DATA_DIR = Path(__file__).resolve().parent.parent / 'data'
 
@@ -165,7 +165,25 @@ class Train():
         "The train's power-loss function L(F [N], v [m/s]) -> [W]: explicit attribute or the two efficiencies."
 
         if hasattr(self, 'powerLosses'):
-            return self.powerLosses
+
+            fun = self.powerLosses
+
+            if closedFormLosses(fun) is not None:
+                return fun
+
+            # any other function of (F, v): tabulated over the operating range of this train (efficiency.TabulatedLosses), once per
+            # function and set of limits; `lossesTableSize = (numForce, numVelocity)` refines the grid
+            from .efficiency import TabulatedLosses
+
+            size = tuple(getattr(self, 'lossesTableSize', (24, 32)))
+            key = (self.forceMin, self.forceMax, self.velocityMax, size)
+            cached = getattr(self, '_lossesTable', None)
+
+            if cached is None or cached[0] is not fun or cached[1] != key:
+                cached = (fun, key, TabulatedLosses(fun, self.forceMin, self.forceMax, self.velocityMax, numForce=size[0], numVelocity=size[1]))
+                self._lossesTable = cached
+
+            return cached[2]
 
         if hasattr(self, 'etaTraction') and hasattr(self, 'etaRgBrake'):
             return StaticLosses(self.etaTraction, self.etaRgBrake)

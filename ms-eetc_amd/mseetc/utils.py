@@ -167,20 +167,19 @@ class StaticLosses():
         return (1 - self.etaTraction)/self.etaTraction, (1 - self.etaRgBrake)
 
 
-def classifyLosses(fun):
+def closedFormLosses(fun):
     """
-    Work out which device loss model a user-supplied callable `fun(F, v)`
-    corresponds to.  The reference accepts arbitrary CasADi-traceable lambdas
-    (`train.powerLosses = lambda f,v: ...`, e.g. figure5.py:92-93); the device
-    path has closed-form models only, so the callable is probed on a grid and
-    matched.  Returns (kind, ct, cr).
+    (kind, ct, cr) when the callable `fun(F, v)` is one of the loss models the device has in closed form or carries its own parameter
+    block (zero, constant efficiencies, efficiency.DynamicLosses / TabulatedLosses), None for any other function.  The reference accepts
+    arbitrary CasADi-traceable lambdas (`train.powerLosses = lambda f,v: ...`, e.g. figure5.py:92-93); a plain callable is probed
+    on a grid and matched.
     """
 
     if isinstance(fun, StaticLosses):
         ct, cr = fun.slopes()
         return LOSS_STATIC, ct, cr
 
-    if getattr(fun, 'KIND', None) == LOSS_DYNAMIC:      # efficiency.DynamicLosses
+    if getattr(fun, 'KIND', None) == LOSS_DYNAMIC:      # efficiency.DynamicLosses, efficiency.TabulatedLosses
         return LOSS_DYNAMIC, 0.0, 0.0
 
     fs = np.array([-3e5, -1.1e5, -2.5e4, -1.0, 1.0, 3.3e4, 1.2e5, 2.9e5])
@@ -200,8 +199,23 @@ def classifyLosses(fun):
     if ct >= 0 and cr >= 0 and np.allclose(vals, model, rtol=1e-12, atol=1e-9):
         return LOSS_STATIC, float(ct), float(cr)
 
-    raise NotImplementedError("The power-losses callable is neither zero, nor a constant-efficiency model: "
-                              "only closed-form loss models can run on the device.")
+    return None
+
+
+def classifyLosses(fun):
+    """
+    Which device loss model the callable `fun(F, v)` is: (kind, ct, cr).  `Train.lossesCallable()` has already wrapped a function
+    without closed form into its table (efficiency.TabulatedLosses); a bare function of that sort cannot be classified without the
+    train's operating range.
+    """
+
+    found = closedFormLosses(fun)
+
+    if found is None:
+        raise NotImplementedError("The power-losses callable is neither zero, nor a constant-efficiency model: pass it through "
+                                  "Train.lossesCallable() (train.powerLosses = fun), which tabulates it over the train's operating range.")
+
+    return found
 
 
 def splitLosses(fun):

@@ -63,6 +63,7 @@ static jet j_mul(jet a, jet b)
  * dynamic loss model (reference: mseetc/efficiency.py:7-141, utils.py:197-220, train.py:214-217).
  * Parameter block (doubles): forceMax, powerMax, vTurn, vMin, vMax, auxiliaries, cgT = (1-etaG)/etaG, cgB = 1-etaG, R, V,
  * totalMass, nx, ny, xb[nx+1], yb[ny+1], coef[nx][ny][4][4] (bicubic patches about the cell centres, ascending powers).
+ * vTurn = 0 marks a direct table of the total losses over (signed force [N], speed), see spec_losses.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
@@ -105,8 +106,11 @@ static jet spec_losses(const DynLoss *D, int traction, double f, double v)
 {
     jet F = j_scale(j_var(f, 0), D->M), vv = j_var(v, 1);
     jet vc = (v >= D->vMin && v <= D->vMax) ? vv : j_const(v < D->vMin ? D->vMin : D->vMax);   /* efficiency.py:40 */
-    jet absF = traction ? F : j_scale(F, -1);
-    jet load = (vc.v <= D->vTurn) ? j_scale(absF, 100/D->Fmax) : j_scale(j_mul(absF, vc), 100/D->Pmax);   /* efficiency.py:7-12 */
+    /* vTurn = 0: direct table of the total losses [W] over (signed force [N], speed): a user-supplied L(F, v) (train.py:190-219) tabulated
+     * by the caller; no load conversion, no gear / auxiliaries / transformer terms, no zeroing */
+    const int direct = !(D->vTurn > 0);
+    jet absF = (traction || direct) ? F : j_scale(F, -1);
+    jet load = direct ? absF : (vc.v <= D->vTurn) ? j_scale(absF, 100/D->Fmax) : j_scale(j_mul(absF, vc), 100/D->Pmax);   /* efficiency.py:7-12 */
     double t[6];
     table_eval(D, load.v, vc.v, t);
     jet motor;
@@ -116,6 +120,7 @@ static jet spec_losses(const DynLoss *D, int traction, double f, double v)
     motor.h00 = t[1]*load.h00 + t[2]*vc.h00 + t[3]*load.g0*load.g0 + 2*t[4]*load.g0*vc.g0 + t[5]*vc.g0*vc.g0;
     motor.h01 = t[1]*load.h01 + t[2]*vc.h01 + t[3]*load.g0*load.g1 + t[4]*(load.g0*vc.g1 + load.g1*vc.g0) + t[5]*vc.g0*vc.g1;
     motor.h11 = t[1]*load.h11 + t[2]*vc.h11 + t[3]*load.g1*load.g1 + 2*t[4]*load.g1*vc.g1 + t[5]*vc.g1*vc.g1;
+    if (direct) return j_scale(motor, 1/D->M);                                   /* train.py:216 */
     if (!(motor.v > 0)) return j_const(0);                                       /* efficiency.py:137 */
     jet pW = traction ? j_mul(F, vv) : j_scale(j_mul(F, vv), -1);               /* efficiency.py:108-109 */
     jet gear = j_scale(pW, traction ? D->cgT : D->cgB);                          /* efficiency.py:112-116 */
@@ -1439,6 +1444,18 @@ static int debug_level(void) { const char *s = getenv("ORACLE_DEBUG"); return s 
 static int g_resto = 1;
 void oracle_set_restoration(int on) { g_resto = on; }
 
+/* Telemetry for IPOPT's watchdog (IpBacktrackingLineSearch: watchdog_shortened_iter_trigger = 10): the longest run of successive
+ * iterations whose accepted step was shortened by the backtracking line search, over all solves since the last reset.  The watchdog
+ * procedure itself is not restated; a run of fewer than 10 means IPOPT would not have started it either. */
+static int g_max_shortened = 0;
+int oracle_max_shortened_run(int reset) { int v; 
+#pragma omp critical(msd_shortened)
+    { v = g_max_shortened; if (reset) g_max_shortened = 0; }
+    return v; }
+static void note_shortened_run(int run) {
+#pragma omp critical(msd_shortened)
+    { if (run > g_max_shortened) g_max_shortened = run; } }
+
 static const double RESTO_RHO = 1000.0;        /* resto_penalty_parameter */
 static const double RESTO_KAPPA = 0.9;         /* required_infeasibility_reduction */
 static const double RESTO_THETA_MAX_FACT = 1e8;/* resto.theta_max_fact */
@@ -2046,6 +2063,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
     W->nfilt = 0; W->delta_last = 0;
 
     int status = OR_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
+    int short_run = 0, short_max = 0;      /* successive shortened steps (watchdog telemetry) */
     Err R; memset(&R, 0, sizeof R);
     double alpha_pr = 0, alpha_du = 0, dnorm = 0;
 
@@ -2206,6 +2224,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
             break;
         }
         alpha_pr = alpha;
+        if (!tiny) { short_run = (ls > 0) ? short_run + 1 : 0; if (short_run > short_max) short_max = short_run; }
 
         /* filter augmentation (W&B eq. (22)) */
         if (!tiny && !ftype_armijo) {
@@ -2280,6 +2299,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         stats[OR_ST_KKT] = R.E; stats[OR_ST_MU] = mu; stats[OR_ST_DUAL_INF] = R.dual_u; stats[OR_ST_CONSTR_VIOL] = R.primal_u; stats[OR_ST_COMPL] = R.compl_u;
         stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back; stats[OR_ST_N_RESTO] = W->n_resto;
     }
+    note_shortened_run(short_max);
     free(res_c); free(res_d); free(soc_c); free(soc_d);
     ws_free(W);
     return status;

@@ -154,6 +154,10 @@ void oracle_set_loss_table(const double *block);
 
 /* feasibility restoration phase on (default) / off: off, a solve whose line search breaks down ends with OR_STATUS_LINESEARCH like before */
 void oracle_set_restoration(int on);
+
+/* longest run of successive iterations with a shortened (backtracked) step over the solves since the last reset: the quantity IPOPT's
+ * watchdog compares with watchdog_shortened_iter_trigger = 10 (the watchdog itself is not restated) */
+int oracle_max_shortened_run(int reset);
 void oracle_loss_rows(const double *block, double f, double v, double *out12);
 
 /* NLP functions at z (reference layout): objective and the constraint rows in the reference's order. */

@@ -330,6 +330,16 @@ def solve_batch(prob, scen, nthreads=0, start='reference'):
     return z, st, nfail
 
 
+def max_shortened_run(reset=True):
+    "Longest run of successive shortened steps of the solves since the last reset (what IPOPT's watchdog trigger of 10 looks at)."
+
+    L = lib()
+    L.oracle_max_shortened_run.restype = ctypes.c_int
+    L.oracle_max_shortened_run.argtypes = [ctypes.c_int]
+
+    return int(L.oracle_max_shortened_run(1 if reset else 0))
+
+
 def stage_eval(prob_or_ipdp, b, w, ds, grad=0.0, curv=0.0):
     "tau, bplus and their first/second derivatives wrt (b, w) for one interval."
 

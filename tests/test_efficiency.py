@@ -123,3 +123,110 @@ def test_oracle_solves_the_figure5_configuration_with_dynamic_losses():
         smooth = 1e-3*np.sum(np.diff(f)**2)/prob.dp[oracle.DP['OBJ_DEN']]
         assert abs(energy - (res['stats']['OBJ'] - smooth)) <= 1e-6*energy      # the active slack row is tight
     assert costs[0] > costs[1] > costs[2]
+
+
+# ---- any loss function L(F, v): tabulated for the device (reference: train.py:190-219 + utils.py:197-220 accept arbitrary callables) ----------
+
+def _copper_iron(f, v):
+    "A drive with copper losses ~ F^2, iron / friction losses ~ v and v^2 and a converter share of the power; cheaper in braking."
+    return (2.2e-6*f*f + 900*v + 14*v*v + 0.06*f*v + 4e-12*f*f*f*v)*(f >= 0) + (1.5e-6*f*f + 900*v + 14*v*v - 0.11*f*v)*(f < 0)
+
+
+def _smooth_nonpolynomial(f, v):
+    return 3e4*np.sqrt(1 + (f/1.2e5)**2)*(1 + 0.4*np.tanh(v/20)) - 3e4 + 0.05*abs(f)*v*(1 - 0.3*(f < 0))      # continuous, kink at F = 0
+
+
+def test_tabulated_losses_represent_piecewise_cubics_exactly():
+    from mseetc.efficiency import TabulatedLosses
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    tab = TabulatedLosses(_copper_iron, train.forceMin, train.forceMax, train.velocityMax)
+    assert tab.maxDeviation < 1e-12 and tab.KIND == LOSS_DYNAMIC
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        f, v = rng.uniform(train.forceMin, train.forceMax), rng.uniform(0.3, train.velocityMax)
+        assert abs(tab.tabulated(f, v) - _copper_iron(f, v)) <= 1e-11*max(1.0, abs(_copper_iron(f, v)))
+    # calling the object is calling the function; the parameter block carries vTurn = 0 (direct table) and the total mass
+    assert tab(1.0e5, 20.0) == _copper_iron(1.0e5, 20.0)
+    block = tab.parameters(4.2e5)
+    nx, ny = int(block[11]), int(block[12])
+    assert block[2] == 0.0 and block[10] == 4.2e5 and len(block) == 13 + nx + 1 + ny + 1 + 16*nx*ny
+    assert 0.0 in block[13:13 + nx + 1]      # F = 0 is a cell edge: the two sides are separate splines
+
+
+def test_tabulated_losses_follow_a_smooth_function_and_warn_when_the_grid_is_too_coarse():
+    import warnings
+    from mseetc.efficiency import TabulatedLosses
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    tab = TabulatedLosses(_smooth_nonpolynomial, train.forceMin, train.forceMax, train.velocityMax)
+    assert tab.maxDeviation < 1e-5
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        coarse = TabulatedLosses(_smooth_nonpolynomial, train.forceMin, train.forceMax, train.velocityMax, numForce=4, numVelocity=4, tolerance=1e-7)
+    assert coarse.maxDeviation > tab.maxDeviation and any('deviates' in str(x.message) for x in w)
+
+
+def test_train_wraps_an_arbitrary_loss_function_once():
+    from mseetc.efficiency import TabulatedLosses
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    eta = 0.8
+    train.powerLosses = lambda f, v: f*v*(f > 0)*(1 - eta)/eta - (1 - eta)*f*v*(f < 0)       # closed form: stays what it is
+    kind, ct, cr = classifyLosses(train.lossesCallable())
+    assert kind == 1 and abs(ct - (1 - eta)/eta) < 1e-14 and abs(cr - (1 - eta)) < 1e-14
+    train.powerLosses = _copper_iron
+    first = train.lossesCallable()
+    assert isinstance(first, TabulatedLosses) and train.lossesCallable() is first and classifyLosses(first)[0] == LOSS_DYNAMIC
+    train.forceMax *= 1.1                      # other operating range: tabulated again
+    assert train.lossesCallable() is not first
+    train.lossesTableSize = (8, 8)
+    assert int(train.lossesCallable().parameters(1.0)[12]) < int(first.parameters(1.0)[12])
+    with pytest.raises(NotImplementedError):
+        classifyLosses(_copper_iron)           # a bare function has no operating range to tabulate it on
+    # the specific split functions of the reference surface (train.py:214-217) evaluate the function itself
+    ftr, frg = train.powerLossesFuns()
+    M = train.mass*train.rho
+    assert abs(ftr(0.2, 15.0) - _copper_iron(0.2*M, 15.0)/M) <= 1e-15*abs(ftr(0.2, 15.0))
+
+
+def test_oracle_loss_rows_of_a_tabulated_function_are_the_split_of_utils_197_220():
+    "Direct-table mode of the loss rows against the reference's split restated in mseetc.utils.splitLosses (slope at +-1e-10, intercept L(0, v))."
+    from mseetc.efficiency import TabulatedLosses
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    M = train.mass*train.rho
+    tab = TabulatedLosses(_copper_iron, train.forceMin, train.forceMax, train.velocityMax)
+    block = tab.parameters(M)
+    spec = lambda f, v: _copper_iron(f*M, v)/M
+    # exact partial derivatives of the specific function on the two sides
+    dtr = lambda f, v: (4.4e-6*f*M + 0.06*v + 12e-12*(f*M)**2*v)
+    dbr = lambda f, v: (3.0e-6*f*M - 0.11*v)
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        f, v = rng.uniform(train.forceMin/M, train.forceMax/M), rng.uniform(1.0, 38.0)
+        r = oracle.loss_rows(block, f, v)
+        k = 0 if f >= 0 else 1
+        assert abs(r[k, 0] - spec(f, v)/v) <= 1e-10*abs(spec(f, v)/v)
+        assert abs(r[k, 1] - (dtr if k == 0 else dbr)(f, v)/v) <= 1e-8*abs(r[k, 1])
+        o = 1 - k       # the other row continues its side linearly through F = 0
+        slope = (dtr if o == 0 else dbr)(0.0, v)
+        assert abs(r[o, 0] - (slope*f + spec(0.0, v))/v) <= 1e-8*max(abs(slope*f), spec(0.0, v))/v       # (the two terms may cancel)
+        assert abs(r[o, 1] - slope/v) <= 1e-8*abs(slope/v)
+        # v derivative of the true row by a central difference
+        e = 1e-6
+        gv = (oracle.loss_rows(block, f, v*(1 + e))[k, 0] - oracle.loss_rows(block, f, v*(1 - e))[k, 0])/(2*e*v)
+        assert abs(r[k, 2] - gv) <= 1e-6*max(abs(gv), 1e-6)
+
+
+def test_oracle_constant_efficiencies_through_the_table_are_the_static_model():
+    "The same NLP twice: constant efficiencies as the closed-form rows (loss kind 1) and as a tabulated function (bilinear: exact in the table)."
+    from mseetc.efficiency import TabulatedLosses
+    train = cases.train_default()
+    track = cases.track_00(12000)
+    N = 40
+    static = cases.oracle_problem(train, track, N)
+    rs = oracle.solve(static, static.scenario(640.0), start='profile')
+    et, er = train.etaTraction, train.etaRgBrake
+    tab = TabulatedLosses(lambda f, v: f*v*(f > 0)*(1 - et)/et - (1 - er)*f*v*(f < 0), train.forceMin, train.forceMax, train.velocityMax)
+    prob = _dyn_problem(train, tab, track, N)
+    rt = oracle.solve(prob, prob.scenario(640.0), start='profile')
+    assert rs['stats']['STATUS'] == 0 and rt['stats']['STATUS'] == 0
+    assert abs(rt['stats']['OBJ'] - rs['stats']['OBJ']) <= 1e-8*abs(rs['stats']['OBJ'])
+    assert np.max(np.abs(rt['z'] - rs['z'])/np.maximum(1.0, np.abs(rs['z']))) <= 1e-5

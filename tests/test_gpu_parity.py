@@ -742,6 +742,77 @@ def test_dynamic_loss_model_vs_oracle():
             assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 5
 
 
+def test_arbitrary_loss_function_vs_oracle():
+    """
+    train.py:190-219 + utils.py:197-220: `train.powerLosses` may be any function of (F, v).  The device gets it as a table over the train's
+    operating range (efficiency.TabulatedLosses, exact for the piecewise cubic used here); kernels against the oracle on the same table for
+    the LDS-resident, the collocation and the streamed kernel, and post-processing with the function itself.
+    """
+    from oracle import oracle
+    from mseetc.train import Train
+    from mseetc.track import computeDiscretizationPoints
+    from mseetc.ocp import casadiSolver
+    from test_efficiency import _copper_iron
+    train = Train(config={'id': 'NL_Intercity_VIRM6'})
+    train.forceMinPn = 0
+    train.powerLosses = _copper_iron
+    track = cases.track_00(8500)
+    fun = train.lossesCallable()
+    assert fun.maxDeviation < 1e-12
+    oracle.set_loss_table(fun.parameters(train.mass*train.rho))
+    for N, T, kw in ((100, (300.0, 330.0, 380.0), {}), (60, (320.0,), dict(integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))),
+                     (600, (330.0,), {})):
+        opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        opts.update(kw)
+        solver = casadiSolver(train, track, opts, startingPoint='reference')
+        pts = computeDiscretizationPoints(track, N)
+        oopts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1 if not kw else 0)
+        if kw:
+            from mseetc.train import collocationTables
+            oopts.update(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10)
+            oracle.set_collocation(*collocationTables(2, 'radau'))
+        prob = oracle.pack_problem(train, pts, oopts, 2, 0.0, 0.0, track.length)
+        res = solver.solveBatch(list(T), terminalVelocity=80/3.6, initialVelocity=1)
+        assert np.all(res['status'] == 0), res['status']
+        for k, t in enumerate(T):
+            ref = oracle.solve(prob, prob.scenario(t, terminalVelocity=80/3.6, initialVelocity=1))
+            assert ref['stats']['STATUS'] == 0
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+            assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+            assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 5
+        if N == 100:
+            # the solver's surface: a solution frame whose losses are those of the function at the solution (utils.py:261-289)
+            df, stats = solver.solve(300.0, terminalVelocity=80/3.6, initialVelocity=1)
+            v = df['Velocity [m/s]'].values
+            vm = 0.5*(v[:-1] + v[1:])
+            fel = df['Force (el) [N]'].values[:-1]
+            expect = 1e-6/3.6*np.diff(df['Position [m]'].values)*np.array([_copper_iron(f, w) for f, w in zip(fel, vm)])/vm
+            assert np.allclose(df['Losses [kWh]'].values[:-1], expect, rtol=1e-9, atol=1e-12)
+            # the slacks sit on the loss rows wherever energy is priced: the frame's energy is the objective up to its smoothing term
+            assert abs(np.nansum(df['Energy [kWh]'].values) - stats['Cost']) <= 2e-3*stats['Cost']
+        solver.close()
+
+
+def test_constant_efficiencies_through_the_table_are_the_static_kernel():
+    "The same NLP through two kernels: closed-form loss rows (static kernel, structure compiled in) and the tabulated function (table kernel)."
+    from mseetc.efficiency import TabulatedLosses
+    train = cases.train_default()
+    track = cases.track_00()
+    T = cases.c1_times(8)
+    a = _solver(train, track, 100, start='profile')
+    ra = a.solveBatch(T)
+    a.close()
+    et, er = train.etaTraction, train.etaRgBrake
+    t2 = cases.train_default()
+    t2.powerLosses = TabulatedLosses(lambda f, v: f*v*(f > 0)*(1 - et)/et - (1 - er)*f*v*(f < 0), t2.forceMin, t2.forceMax, t2.velocityMax)
+    b = _solver(t2, track, 100, start='profile')
+    rb = b.solveBatch(T)
+    b.close()
+    assert np.all(ra['status'] == 0) and np.all(rb['status'] == 0)
+    assert np.max(np.abs(rb['cost'] - ra['cost'])/np.abs(ra['cost'])) <= 1e-7
+    assert np.max(np.abs(rb['z'] - ra['z'])/np.maximum(1.0, np.abs(ra['z']))) <= 1e-4
+
+
 def test_dynamic_losses_with_per_scenario_rolling_stock():
     # config 3's perturbations composed with the loss model of efficiency.py, which the reference composes freely
     # (train.py:44-62 + efficiency.py:101-141): one launch with overrides against one oracle problem per scenario

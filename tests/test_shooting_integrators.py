@@ -91,6 +91,49 @@ def test_oracle_adaptive_integrator_vs_dop853():
         assert abs(out[0] - sol.y[0, -1]) <= 1e-5*abs(sol.y[0, -1]) and abs(out[1] - sol.y[1, -1]) <= 1e-5*abs(sol.y[1, -1])
 
 
+def test_adaptive_pair_against_a_bdf_code_at_the_reference_tolerances():
+    """
+    Pins the difference the substitution behind 'CVODES' makes (reference: train.py:312-322 integrates an interval with SUNDIALS CVODES --
+    variable-order BDF -- at absTol 1e-8 / relTol 1e-6; here an adaptive Dormand-Prince pair at the same tolerances plays that role).  A BDF code
+    of the same family (scipy's variable-order BDF, Newton iteration, same tolerances) and the oracle's pair integrate 40 random intervals; both are
+    compared with a DOP853 solution at 1e-13.  Measured: pair 5.2e-8, BDF code 1.4e-6 relative from the exact map, 1.4e-6 between the two -- the
+    size of the difference a user switching from the reference sees per interval is the BDF code's own error; the asserts leave a margin.
+    """
+    prob = _problem(integration=ADAPT)
+    dp = prob.dp
+    rng = np.random.default_rng(31)
+    worst_pair, worst_bdf, worst_between = 0.0, 0.0, 0.0
+    for _ in range(40):
+        b0, w, ds, grad = rng.uniform(100, 1500), rng.uniform(-0.3, 0.4), rng.uniform(10, 400), rng.uniform(-0.012, 0.012)
+        out = oracle.stage_eval(prob, b0, w, ds, grad, 0.0)[:2]
+        G = dp[DP['G']]*grad/dp[DP['RHO']]
+        rhs = lambda s, y: [1/np.sqrt(y[1]), 2*(w - (dp[DP['SR0']] + dp[DP['SR1']]*np.sqrt(y[1]) + dp[DP['SR2']]*y[1]) - G)]
+        exact = solve_ivp(rhs, [0, ds], [0.0, b0], rtol=1e-13, atol=1e-13, method='DOP853').y[:, -1]
+        bdf = solve_ivp(rhs, [0, ds], [0.0, b0], rtol=ADAPT['relTol'], atol=ADAPT['absTol'], method='BDF').y[:, -1]
+        worst_pair = max(worst_pair, float(np.max(np.abs(out - exact)/np.abs(exact))))
+        worst_bdf = max(worst_bdf, float(np.max(np.abs(bdf - exact)/np.abs(exact))))
+        worst_between = max(worst_between, float(np.max(np.abs(out - bdf)/np.abs(exact))))
+    assert worst_pair <= 1e-6, worst_pair
+    assert worst_bdf <= 1e-4, worst_bdf
+    assert worst_between <= max(2*worst_bdf, 2e-6), (worst_between, worst_bdf)
+    assert worst_pair <= worst_bdf, (worst_pair, worst_bdf)      # the stand-in is the more accurate of the two at these tolerances
+
+
+def test_adaptive_transcription_optimum_is_insensitive_to_the_integrator_tolerance():
+    """
+    NLP-level side of the same pin: the optimum of the 'CVODES' transcription at the reference's default tolerances differs from the optimum at
+    tolerances a thousand times tighter by 1.5e-8 relative in energy (bound here: 1e-6, two orders below north_star's 1e-4), so an integrator
+    of the same accuracy class (the reference's BDF code, 30 times less accurate per interval above) stays below that bound too.
+    """
+    objs = []
+    for tol in (dict(absTol=1e-8, relTol=1e-6), dict(absTol=1e-11, relTol=1e-9)):
+        prob = _problem(integration=dict(ADAPT, **tol))
+        r = oracle.solve(prob, prob.scenario(520.0, 0.0, 8.0, 8.0), start='profile')
+        assert r['stats']['STATUS'] == 0
+        objs.append(r['stats']['OBJ'])
+    assert abs(objs[0] - objs[1]) <= 1e-6*abs(objs[1]), objs
+
+
 def test_oracle_nlp_with_accurate_integrators_agree():
     """
     Three transcriptions whose integrators are all accurate on this grid (RK4 with 32 steps, 5-point Radau with 4 steps, the adaptive

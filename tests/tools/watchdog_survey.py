@@ -1,0 +1,75 @@
+"""
+Would IPOPT's watchdog have started on these problems?  (CPU only; checker-side tool.)
+
+IPOPT starts its watchdog procedure after `watchdog_shortened_iter_trigger` = 10 successive iterations whose step the backtracking line
+search shortened (IpBacktrackingLineSearch.cpp).  The procedure is restated neither in the oracle nor on the device;
+this survey runs the oracle -- the iterate-for-iterate restatement of the rest of the algorithm -- over the benchmark workloads and random
+problems from both starting points and reports the longest run of successive shortened steps in each group.  A maximum below 10 means the
+watchdog never starts there, i.e. leaving it out changes no iterate.
+
+usage: watchdog_survey.py [scenarios per workload = 256] [random problems = 40]
+"""
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'ms-eetc_amd')); sys.path.insert(0, str(ROOT / 'tests'))
+import cases                                   # noqa: E402
+from oracle import oracle                      # noqa: E402
+from mseetc import workloads                   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+NRANDOM = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+
+worst = 0
+
+
+def group(label, prob, scen):
+    global worst
+    for start in ('profile', 'reference'):
+        oracle.max_shortened_run(reset=True)
+        z, st, nfail = oracle.solve_batch(prob, scen, start=start)
+        run = oracle.max_shortened_run(reset=True)
+        worst = max(worst, run)
+        it = st[:, oracle.ST['ITERS']]
+        print('{:<34s} {:<9s} solves {:5d}  failed {:3d}  iterations {:5.1f} (max {:3.0f})  backtracking steps / solve {:5.2f}  longest shortened run {:2d}'.format(
+            label, start, len(scen), int(nfail), it.mean(), it.max(), st[:, oracle.ST['N_BACKTRACK']].mean(), run), flush=True)
+
+
+def scenarios(times, v0=1.0, vN=1.0):
+    return np.array([[0.0, T, v0*v0, vN*vN] for T in times])
+
+
+train, track, N = workloads.config('c1')
+group('config 1 (N = 100, track 00)', cases.oracle_problem(train, track, N), scenarios(workloads.c1_times(B)))
+train, track, N = workloads.config('c2')
+group('config 2 (N = 200, CH_StGallen_Wil)', cases.oracle_problem(train, track, N), scenarios(workloads.c2_times(max(B//4, 16))))
+group('figure 10 train, N = 100', cases.oracle_problem(cases.train_fig10(), workloads.track_00(), 100), scenarios(workloads.c1_times(B, seed=7)))
+group('config 1, loose schedules', cases.oracle_problem(*workloads.config('c1')), scenarios(np.linspace(3000, 20000, 64)))
+
+if NRANDOM:
+    from test_gpu_parity import _random_problem      # noqa: E402  (the generator only: no GPU call)
+    runs = []
+    for seed in range(NRANDOM):
+        with tempfile.TemporaryDirectory() as tmp:
+            train, track, N, rng = _random_problem(seed, Path(tmp))
+            v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
+            # running times from the minimum-time solve of the oracle
+            pt = cases.oracle_problem(train, track, N, energyOptimal=False)
+            rt = oracle.solve(pt, pt.scenario(3*track.length/train.velocityMax, 0.0, vN, v0), start='profile')
+            if rt['stats']['STATUS'] != 0:
+                continue
+            tmin = float(rt['z'][-2])
+            pe = cases.oracle_problem(train, track, N)
+            for start in ('profile', 'reference'):
+                oracle.max_shortened_run(reset=True)
+                oracle.solve_batch(pe, scenarios(tmin*np.array([1.05, 1.1, 1.2, 1.45, 2.0]), v0, vN), start=start)
+                runs.append(oracle.max_shortened_run(reset=True))
+    worst = max([worst] + runs)
+    print('{} random problems x 5 running times x 2 starts: longest shortened run {} (histogram of the per-batch maxima: {})'.format(
+        NRANDOM, max(runs), np.bincount(runs).tolist()))
+
+print('longest run of successive shortened steps over everything:', worst, '(IPOPT starts its watchdog at 10)')
