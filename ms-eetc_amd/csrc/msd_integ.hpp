@@ -308,7 +308,7 @@ __device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds
     T yt = jconst(T(), 0.0), yb = b0;
     T kt[7], kb[7];
     auto rhs = [&](const T &bj, T &ot, T &ob) { ot = xrecip(xsqrt(bj))*ds; ob = ode_b(P, bj, w, G, ds); };
-    double sig = 0, h = 0.05;
+    double sig = 0, h = 1.0;      /* the whole interval first (1.9 instead of 3.4 sets of stages per interval on the benchmark grid: a rejected first step lands on the right size) */
     rhs(yb, kt[0], kb[0]);
     for (int step = 0; step < 100000 && sig < 1.0; step++) {
         if (sig + h > 1.0) h = 1.0 - sig;

@@ -55,7 +55,7 @@ __device__ int iv_dopri(const IvTrain &T, double ds, double w, double G, double 
                  e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
     double y[2] = {t, b}, k[7][2], yt[2], yn[2], d0, d1;
     auto f = [&](const double (&x)[2], double (&out)[2]) { iv_rhs(T, ds, w, G, x[1], out[0], out[1], d0, d1); };
-    double tau = 0, h = 0.05;
+    double tau = 0, h = 1.0;      /* the whole interval first, like the interval map of the NLP (msd_integ.hpp: dopri_tb) -- the two take the same steps */
     f(y, k[0]);
     for (int step = 0; step < 400000 && tau < 1.0; step++) {
         if (tau + h > 1.0) h = 1.0 - tau;

@@ -373,7 +373,7 @@ static void dopri_tb(const Prob *P, jet b0, jet w, double G, double ds, jet *tau
                  e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
     jet y[2] = {j_const(0), b0}, k[7][2], yn[2];
 #define RHS(bj, out) do { (out)[0] = j_scale(j_recip(j_sqrt(bj)), ds); (out)[1] = ode_b(P, (bj), w, G, ds); } while (0)
-    double sig = 0, h = 0.05;
+    double sig = 0, h = 1.0;      /* the whole interval first: most intervals of a shooting grid need one or two steps (a rejected first step costs one set of stages and lands on the right size) */
     RHS(y[1], k[0]);
     for (int step = 0; step < 100000 && sig < 1.0; step++) {
         if (sig + h > 1.0) h = 1.0 - sig;
