@@ -522,6 +522,8 @@ def alt_workloads(args, device):
     import numpy as np
     from mseetc import workloads as wl
 
+    from mseetc._device import ST as _ST
+    ST_STATUS = _ST['STATUS']
     alt = {}
     k, w = 10, 2
 
@@ -538,6 +540,23 @@ def alt_workloads(args, device):
     # the other transcriptions of the reference's options on the config-1 batch (their own kernel instantiations)
     for name in ('integrate_losses', 'irk_radau2', 'cvodes_tolerances'):
         one(name, 'c1', PER_GPU_BATCH['c1'], transcription=name)
+
+    # the host-buffer entry point (msd_solve_batch: scenarios from and results into host memory): the PCIe-inclusive rate of the same workload,
+    # wall clock over ten calls -- upload of the scenario records, launch, download of z* and the statistics.  Never the headline value.
+    hb = {}
+    for B in (PER_GPU_BATCH['c1'], 8192):
+        solver, scen, ov, text = build_workload('c1', B, 0, 0, 'profile', device, 'rk')
+        for _ in range(w):
+            solver.problem.solve_batch(scen)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            r = solver.problem.solve_batch(scen)
+        dt = time.perf_counter() - t0
+        hb["batch_%d" % B] = {"solves_per_s": B*k/dt, "ms_per_call": 1e3*dt/k, "kernel_ms": float(r['kernel_ms']), "converged": int(np.sum(r['stats'][:, ST_STATUS] >= 0)),
+                              "bytes_to_device": int(scen.nbytes), "bytes_to_host": int(r['z'].nbytes + r['stats'].nbytes)}
+        solver.close()
+    hb["workload"] = "config 1 through msd_solve_batch with pageable host buffers (numpy arrays): wall time per call including both transfers and the result arrays' allocation"
+    alt["host_buffers"] = hb
 
     # config 4: shrinking-horizon MPC, 512 scenarios per GPU (4096 over 8), 50 re-solves each: wall time of the whole loop
     train, track, N = wl.config('c4')
