@@ -107,8 +107,8 @@ static int check_desc(const msd_problem_desc *d)
         if (!d->coll_tables) return fail(MSD_E_INVALID, "collocation integrator without its tables");
     }
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE && (!(d->int_abstol > 0) || !(d->int_reltol > 0))) return fail(MSD_E_INVALID, "tolerances of the adaptive integrator must be positive");
-    if (d->integrate_losses && d->energy_optimal && (d->loss_kind != 1 || d->integrator != 0))
-        return fail(MSD_E_UNSUPPORTED, "integrateLosses runs with constant efficiencies (loss_kind 1) and the 'RK' transcription");
+    if (d->integrate_losses && d->energy_optimal && d->loss_kind != 1)
+        return fail(MSD_E_UNSUPPORTED, "integrateLosses runs with constant efficiencies (loss_kind 1)");
     return MSD_OK;
 }
 
@@ -165,16 +165,16 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     /* both brakes, power rows (finite by construction: ocp.py:186-187), energy objective, finite acceleration bounds (ocp.py:113-114) */
     const bool full = d->with_pn_brake != 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                       && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
-    msd::Geometry geo = (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
+    msd::Geometry geo = (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
                         : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full);
     size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
-        geo = (gen && dyn) ? msd::Geometry{0, 0, nullptr} : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
+        geo = (gen && (dyn || intloss)) ? msd::Geometry{0, 0, nullptr} : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
               : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
         lds = sizeof(double)*(size_t)msd::lds_doubles_stream();
         if (!geo.fn)
-            return fail(MSD_E_UNSUPPORTED, (gen && dyn) ? "numIntervals = " + std::to_string(N) + " with a collocation or adaptive shooting integrator and the dynamic loss model exceeds the 255 intervals of their kernels"
+            return fail(MSD_E_UNSUPPORTED, (gen && (dyn || intloss)) ? "numIntervals = " + std::to_string(N) + " with a collocation or adaptive shooting integrator and the dynamic loss model or integrateLosses exceeds the 255 intervals of their kernels"
                                            : (gen || intloss || dyn) ? "numIntervals = " + std::to_string(N) + " exceeds the 1023 intervals of the streamed kernels for the dynamic loss model, the collocation / adaptive shooting integrators and integrateLosses"
                                            : "numIntervals = " + std::to_string(N) + " exceeds the 5119 intervals of the streamed kernel");
     }

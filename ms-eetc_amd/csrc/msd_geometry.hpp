@@ -26,6 +26,7 @@ Geometry pick_geometry_general_long(int N);      /* 257 ... 640 nodes of the sam
 Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
 Geometry pick_geometry_general_dynamic(int N);      /* collocation / adaptive shooting integrators with the dynamic loss model (msd_kernels_compose.hip) */
+Geometry pick_geometry_general_intloss(int N);      /* collocation / adaptive shooting integrators with integrateLosses (msd_kernels_compose.hip) */
 /* the other transcriptions beyond the LDS-resident horizons, up to 1023 intervals (msd_kernels_stream3.hip): dynamic loss model, collocation /
  * adaptive shooting integrators, integrateLosses on the streamed kernel */
 Geometry pick_stream_geometry_dynamic(int N);

@@ -156,10 +156,11 @@ class casadiSolver():
 
         # loss slacks from the loss power integrated over the running time of the interval (ocp.py:231-241)
         integrateLosses = bool(opts.integrateLosses) and bool(opts.energyOptimal)
-        if integrateLosses and (lossKind == LOSS_DYNAMIC or integrator is not None):
+        if integrateLosses and lossKind == LOSS_DYNAMIC:
             # (the loss rows of ocp.py:231-241 integrate the loss power along the time-domain model: with constant efficiencies that is a multiple
-            # of the distance covered, which is what the device integrates; the dynamic loss table or another shooting integrator next to it is not built)
-            raise NotImplementedError("integrateLosses=True runs with constant efficiencies and the 'RK' transcription.")
+            # of the distance covered, which is what the device integrates -- next to any shooting integrator, the loss integrals have their own
+            # (train.py:367-413); with a loss table the loss power itself has to be integrated: not built)
+            raise NotImplementedError("integrateLosses=True runs with constant efficiencies.")
         if integrateLosses and lossKind == LOSS_NONE:
             integrateLosses = False      # perfect efficiency: both loss integrals vanish and the rows reduce to s >= 0
 

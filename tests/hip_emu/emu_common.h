@@ -45,5 +45,6 @@ bool emu_run_full(int NT, int SPT, const EmuArgs &a);
 bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general(int NT, int SPT, const EmuArgs &a);
 bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);
+bool emu_run_general_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_stream(const EmuArgs &a);
 #define EMU_CALL(...) run_blocks<__VA_ARGS__>(a.P, a.nscen, a.scen, a.ovr, a.z, a.lam, a.stats, a.hist, a.cap)

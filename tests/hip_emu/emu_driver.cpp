@@ -45,7 +45,8 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     const int nodes = P.N + 1;
     const EmuArgs a = {P, nscen, scen, ovr, z, lam, stats, hist, cap};
     if (d->integrate_losses) {      /* loss slacks from the integrated loss power (msd_lossint.hpp) */
-        if (dyn || d->integrator != 0) return -3;
+        if (dyn) return -3;
+        if (d->integrator != 0) return (nodes <= 64 && emu_run_general_intloss(64, 1, a)) ? 0 : -3;      /* both options (msd_kernels_compose.hip) */
         return emu_run_intloss(64, nodes <= 64 ? 1 : 2, a) && nodes <= 128 ? 0 : -3;
     }
     if (d->integrator != 0) {       /* the kernels with the collocation / adaptive shooting integrators: two geometries are enough here */

@@ -156,17 +156,20 @@ def test_oracle_nlp_with_accurate_integrators_agree():
 
 # ---- the emulated kernel ----------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('method,io,integration', [('IRK', dict(order=2, numSteps=1, numApproxSteps=0), IRK2),
-                                                   ('IRK', dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=2), IRK3L),
-                                                   ('CVODES', dict(), ADAPT)])
-def test_emulated_kernel_with_other_integrators_matches_oracle(method, io, integration):
+@pytest.mark.parametrize('method,io,integration,extra', [('IRK', dict(order=2, numSteps=1, numApproxSteps=0), IRK2, {}),
+                                                         ('IRK', dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=2), IRK3L, {}),
+                                                         ('CVODES', dict(), ADAPT, {}),
+                                                         ('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2, dict(integrateLosses=True)),      # both options at once
+                                                         ('CVODES', dict(), ADAPT, dict(integrateLosses=True))])
+def test_emulated_kernel_with_other_integrators_matches_oracle(method, io, integration, extra):
     from test_kernel_emulation import load_emulation
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
     lib = load_emulation()
     N, T = 30, 520.0
     train, track = cases.train_default(), cases.track_00(12000)
-    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationMethod=method, integrationOptions=io), startingPoint='profile')
+    integration = dict(integration, **extra)
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationMethod=method, integrationOptions=io, **extra), startingPoint='profile')
     scen = solver._scenarios(T, 0, 1, 1)
     nz = (4 + int(solver.withPnBrake))*N + 2
     z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
@@ -175,8 +178,16 @@ def test_emulated_kernel_with_other_integrators_matches_oracle(method, io, integ
     prob = _problem(N, 12000, io.get('numSteps', 1), io.get('numApproxSteps', 0), integration)
     ref = oracle.solve(prob, prob.scenario(T), start='profile')
     assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
-    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
-    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
+    if not extra:
+        assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+        assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
+    else:
+        # with the integrated loss rows the kernel's Newton step is the oracle's up to the folding of the running time into (b, f, p): the two logs
+        # agree to ten digits through the last barrier problem; after the final full step the dual infeasibility is 1e-8 in the kernel against
+        # 2e-11 in the oracle (same with 'RK' shooting on this case), so the test against 1e-8 can fall one barrier update later
+        assert 0 <= int(st[0, ST['ITERS']]) - int(ref['stats']['ITERS']) <= 2
+        assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4      # (another final barrier parameter: 9e-10 against 2.5e-9)
+        assert abs(st[0, 2] - ref['stats']['OBJ']) <= 3e-9*abs(ref['stats']['OBJ'])
 
 
 # ---- the HIP kernels ----------------------------------------------------------------------------------------------------------------
@@ -285,6 +296,32 @@ def test_gpu_other_transcriptions_on_the_streamed_kernel(what):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('method,io,integration,N,crop,T', [('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2, 100, None, (1541.0, 1650.0)),
+                                                            ('IRK', dict(order=3, collMethod='legendre', numSteps=2, numApproxSteps=0), IRK3L, 40, 12000, (640.0,)),
+                                                            ('CVODES', dict(), ADAPT, 100, None, (1541.0, 1700.0)),
+                                                            ('CVODES', dict(), ADAPT, 200, None, (1580.0,))])
+def test_gpu_integrated_losses_with_other_shooting_integrators_vs_oracle(method, io, integration, N, crop, T):
+    """
+    ocp.py:92 with ocp.py:231-241: the loss rows integrate the loss power with an integrator of their own (train.py:367-413), whatever integrates the
+    shooting intervals -- kernels with both options (msd_kernels_compose.hip) against the oracle from both starting points.
+    """
+    from mseetc.ocp import casadiSolver
+    train, track = cases.train_default(), cases.track_00(crop)
+    prob = cases.oracle_problem(train, track, N, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), integration=dict(integration, integrateLosses=True))
+    for start in ('profile', 'reference'):
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrateLosses=True, integrationMethod=method, integrationOptions=io), startingPoint=start)
+        res = solver.solveBatch(list(T))
+        solver.close()
+        assert np.all(res['status'] == 0), (method, start, res['status'])
+        for k, t in enumerate(T):
+            ref = oracle.solve(prob, prob.scenario(float(t)), start=start)
+            assert ref['stats']['STATUS'] == 0
+            assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ']), (method, start, k)
+            assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4, (method, start, k)
+            assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
+
+
+@pytest.mark.gpu
 def test_gpu_stage_function_of_other_integrators_vs_oracle_and_standalone_kernels():
     """
     msd_stage_eval of an 'IRK' / 'CVODES' problem: values against the stand-alone interval integrators (msd_interval_integrate,
@@ -324,8 +361,12 @@ def test_gpu_other_integrators_surface_and_limits():
     assert abs(stats['Cost'] - rk.solve(1541)[1]['Cost']) < 1e-3*stats['Cost']      # both integrate b accurately on this grid
     with pytest.raises(DeviceError):
         casadiSolver(train, track, dict(numIntervals=1100, integrationMethod='CVODES')).solve(1541)      # beyond the streamed kernels of the other integrators
+    with pytest.raises(DeviceError):
+        casadiSolver(train, track, dict(numIntervals=300, integrateLosses=True, integrationMethod='IRK')).solve(1541)      # that combination: up to 255 intervals
     with pytest.raises(NotImplementedError):
-        casadiSolver(train, track, dict(numIntervals=50, integrateLosses=True, integrationMethod='IRK'))
+        from mseetc.efficiency import totalLossesFunction
+        dyn = cases.train_default(); dyn.forceMinPn = 0; dyn.powerLosses = totalLossesFunction(dyn)
+        casadiSolver(dyn, track, dict(numIntervals=50, integrateLosses=True))      # the loss table under the integral: not built
     with pytest.raises(DeviceError):
         casadiSolver(train, track, dict(numIntervals=1100, integrateLosses=True)).solve(1541)
     # integrateLosses through the reference's surface: same optimum as the mid-point rows to about 1e-4 (X = ds up to the RK4 error)
