@@ -737,8 +737,8 @@ def test_dynamic_loss_model_vs_oracle():
             assert ref['stats']['STATUS'] == 0
             assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
             assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
-            # same path up to the rounding of the device's divisions (rcp + Newton, 1-2 ulp): with the spline rows one of these five
-            # solves takes 4 iterations more than the oracle's 41 on the GPU (the host emulation of the same code: 41)
+            # same path up to rounding (order of the wave reductions; until the end of round 3 also 1-2 ulp divisions): with the spline rows one
+            # of these five solves took 4 iterations more than the oracle's 41 on the fast-math build (the host emulation of the same code: 41)
             assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 5
 
 
