@@ -790,6 +790,21 @@ def test_arbitrary_loss_function_vs_oracle():
             assert np.allclose(df['Losses [kWh]'].values[:-1], expect, rtol=1e-9, atol=1e-12)
             # the slacks sit on the loss rows wherever energy is priced: the frame's energy is the objective up to its smoothing term
             assert abs(np.nansum(df['Energy [kWh]'].values) - stats['Cost']) <= 2e-3*stats['Cost']
+            # integrateLosses=True in post-processing (utils.py:261-289) integrates the table on the device: against a quadrature of the function
+            # itself along the re-integrated speed of each interval
+            from scipy.integrate import solve_ivp
+            from mseetc.utils import postProcessDataFrame
+            raw = solver.unpack(solver.solveBatch(300.0, terminalVelocity=80/3.6, initialVelocity=1)['z'][0])
+            dfb = postProcessDataFrame(raw, solver.points, train, CVODES=False, integrateLosses=True)
+            M, model, t = train.mass*train.rho, train.exportModel(), raw.index.values
+            ref = []
+            for i in range(N):
+                G = model.resistance(df['Gradient [permil]'].values[i]/1e3, df['Curvature [1/m]'].values[i])
+                ftot = (raw['Force (el) [N]'].values[i] + raw['Force (pnb) [N]'].values[i])/M
+                rhs = lambda tt, y: [ftot - (model.sr0 + model.sr1*y[0] + model.sr2*y[0]**2) - G, _copper_iron(raw['Force (el) [N]'].values[i], y[0])]
+                sol = solve_ivp(rhs, [0, t[i + 1] - t[i]], [raw['Velocity [m/s]'].values[i], 0.0], method='DOP853', rtol=1e-12, atol=1e-12)
+                ref.append(sol.y[1, -1]*(1e-6/3.6))
+            assert np.allclose(dfb['Losses [kWh]'].values[:-1], np.array(ref), rtol=1e-5, atol=1e-9)
         solver.close()
 
 
