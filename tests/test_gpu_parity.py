@@ -865,6 +865,42 @@ def test_dynamic_losses_with_per_scenario_rolling_stock():
     assert abs(res['cost'][1] - res['cost'][0]) > 1e-3*res['cost'][0]      # the perturbation is visible in the energy
 
 
+def test_arbitrary_loss_function_with_per_scenario_rolling_stock():
+    "The same composition for a tabulated loss function (absolute force on the table axis: a scenario's own mass converts its specific force)."
+    from oracle import oracle
+    from mseetc.train import Train
+    from mseetc.track import computeDiscretizationPoints
+    from test_efficiency import _copper_iron
+    def make(mass=None, r0=None):
+        cfg = {'id': 'NL_Intercity_VIRM6'}
+        if mass is not None:
+            cfg['mass'] = {'unit': 'kg', 'value': mass}
+        if r0 is not None:
+            cfg['rolling resistance r0'] = {'unit': 'N', 'value': r0}
+        tr = Train(config=cfg)
+        tr.forceMinPn = 0
+        tr.powerLosses = _copper_iron
+        return tr
+    base = make()
+    track, N = cases.track_00(8500), 100
+    solver = _solver(base, track, N)
+    pts = computeDiscretizationPoints(track, N)
+    fm, fr = np.array([1.0, 1.08, 0.93]), np.array([1.0, 0.9, 1.1])
+    T = np.array([300.0, 320.0, 350.0])
+    res = solver.solveBatch(T, terminalVelocity=80/3.6, initialVelocity=1, mass=base.mass*fm, r0=base.r0*fr)
+    assert np.all(res['status'] == 0)
+    for k in range(3):
+        tr = make(base.mass*fm[k], base.r0*fr[k])
+        oracle.set_loss_table(tr.lossesCallable().parameters(tr.mass*tr.rho))
+        prob = oracle.pack_problem(tr, pts, dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1),
+                                   2, 0.0, 0.0, track.length)
+        ref = oracle.solve(prob, prob.scenario(float(T[k]), terminalVelocity=80/3.6, initialVelocity=1))
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= OBJ_RTOL*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-4
+    solver.close()
+
+
 def test_multi_handle_launches_overlap():
     """
     msd_solve_batch_multi launches on every handle before it copies any result back (a copy into pageable host memory holds the
