@@ -1,3 +1,7 @@
+"""Diagnostic (GPU): kernel time and parity against the oracle at N = 520 / 540 / 556 with whatever geometry the loaded library picks there (MSD_LIB selects
+a variant library).  Used for the 256 x 3 experiment of DESIGN.md section 8: in msd_geometry.hpp: pick_geometry_t, in front of the 320 x 2 line,
+    if (nodes <= 768 && sizeof(double)*(size_t)lds_doubles(N, 768, DYN != LOSS_STATIC) <= 160*1024) return {256, 3, solve_kernel<256, 3, 1, DYN>};
+compile msd_kernels_static.hip with it and link it with the other objects of ms-eetc_amd/lib/obj into a variant library."""
 import sys
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/ms-eetc_amd'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np, cases
