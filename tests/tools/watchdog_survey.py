@@ -50,6 +50,45 @@ group('config 2 (N = 200, CH_StGallen_Wil)', cases.oracle_problem(train, track, 
 group('figure 10 train, N = 100', cases.oracle_problem(cases.train_fig10(), workloads.track_00(), 100), scenarios(workloads.c1_times(B, seed=7)))
 group('config 1, loose schedules', cases.oracle_problem(*workloads.config('c1')), scenarios(np.linspace(3000, 20000, 64)))
 
+# config 3: perturbed rolling stock, one oracle problem per scenario
+from mseetc.track import computeDiscretizationPoints      # noqa: E402
+train, track, N = workloads.config('c3')
+T3, pert = workloads.c3_scenarios(max(B//2, 32), train)
+pts = computeDiscretizationPoints(track, N)
+opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1)
+for start in ('profile', 'reference'):
+    oracle.max_shortened_run(reset=True)
+    its = []
+    for k in range(len(T3)):
+        tr = workloads.train_default()
+        tr.mass, tr.r0, tr.r1, tr.r2 = pert['mass'][k], pert['r0'][k], pert['r1'][k], pert['r2'][k]
+        prob = oracle.pack_problem(tr, pts, opts, 1, (1 - tr.etaTraction)/tr.etaTraction, 1 - tr.etaRgBrake, track.length)
+        r = oracle.solve(prob, prob.scenario(float(T3[k])), start=start)
+        its.append(r['stats']['ITERS'])
+    run = oracle.max_shortened_run(reset=True)
+    worst = max(worst, run)
+    print('{:<34s} {:<9s} solves {:5d}  iterations {:5.1f} (max {:3.0f})  longest shortened run {:2d}'.format('config 3 (perturbed rolling stock)', start, len(T3), np.mean(its), np.max(its), run), flush=True)
+
+# config 4 in miniature: shrinking-horizon re-solves of 16 scenarios from the state the previous solution reaches 16 intervals on (cold starts)
+train, track, N = workloads.config('c4')
+runs4 = []
+for T in workloads.c1_times(16, seed=20260615):
+    cur = workloads.track_00()
+    t_now, v_now, pos, prev = 0.0, 1.0, 0.0, None
+    for k in range(0, 40, 8):
+        Nk = N - 2*k
+        prob = cases.oracle_problem(train, cur, Nk)
+        oracle.max_shortened_run(reset=True)
+        r = oracle.solve_dual(prob, prob.scenario(float(T), t_now, 1.0, v_now), start='profile')
+        runs4.append(oracle.max_shortened_run(reset=True))
+        if r['stats']['STATUS'] != 0:
+            break
+        z = r['z']; stp = 5; j = 16
+        t_now, v_now = float(z[stp*j + 3]), float(np.sqrt(z[stp*j + 4]))
+        cur = workloads.track_00(); pos += float(prob.positions[j]); cur.updateLimits(positionStart=pos)
+worst = max([worst] + runs4)
+print('config 4 in miniature (16 scenarios x 5 cold re-solves on the shrinking horizon): longest shortened run {}'.format(max(runs4)), flush=True)
+
 if NRANDOM:
     from test_gpu_parity import _random_problem      # noqa: E402  (the generator only: no GPU call)
     runs = []
