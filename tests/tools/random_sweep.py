@@ -2,6 +2,7 @@
 One-off robustness sweep on a GPU box: the random problems of tests/test_gpu_parity.py::test_randomized_problems_vs_oracle for many more
 seeds than the test suite carries; prints every seed whose GPU solves fail or disagree with the oracle.  usage: random_sweep.py FIRST LAST
 """
+import os
 import sys
 import tempfile
 from pathlib import Path
@@ -27,7 +28,7 @@ for seed in range(first, last):
             print('seed', seed, 'N', N, 'time-optimal twin failed', rt['status'][0]); bad += 1
             continue
         tmin = float(rt['z'][0][-2])
-        T = tmin*np.array([1.05, 1.1, 1.2, 1.45, 2.0])
+        T = tmin*np.array([float(x) for x in os.environ.get('SWEEP_FACTORS', '1.05,1.1,1.2,1.45,2.0').split(',')])      # (SWEEP_FACTORS: other multiples of the minimum running time)
         for start in ('profile', 'reference'):
             s = _solver(train, track, N, start=start)
             res = s.solveBatch(T, initialVelocity=v0, terminalVelocity=vN)
