@@ -248,19 +248,29 @@ def measure_single_process(solver, scen, overrides, steps, warmup, ndev):
     return elapsed, max(ms)/steps, st.reshape(-1, ST['COUNT'])
 
 
-def measure_mpc(train, track, N, T, steps, warmup, device, warm=True, barrier=None):
+def measure_mpc(train, track, N, T, steps, warmup, device, warm=True, barrier=None, host_loop=False):
     """
-    Config 4: `steps` shrinking-horizon loops (50 re-solves of every scenario each, stride 2 intervals, 1 % measurement noise).
+    Config 4: `steps` shrinking-horizon loops (50 re-solves of every scenario each, stride 2 intervals, 1 % measurement noise) -- with the
+    loop's bookkeeping on the device (mseetc.mpc.DeviceLoop: the 50 problem records are built and uploaded once, outside the timed region,
+    since the grid sequence does not depend on the solutions; a timed step = one msd_mpc_run over the batch, including the download of the
+    log), or `host_loop`: the host-side loop of mseetc.mpc.shrinkingHorizon (one launch per re-solve, bookkeeping in numpy).
     Returns (elapsed s, dict of loop statistics of the last loop).
     """
 
     import numpy as np
     from mseetc import workloads as wl
-    from mseetc.mpc import shrinkingHorizon
+    from mseetc.mpc import shrinkingHorizon, DeviceLoop
 
-    run = lambda: shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm, device=device)
-    for _ in range(max(1, warmup) if warmup else 0):
-        shrinkingHorizon(train, track, wl.options(N), T[:64], numResolves=2, noise=0.01, seed=1, warmStart=warm, device=device)
+    if host_loop:
+        loop = None
+        run = lambda: shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm, device=device)
+        for _ in range(max(1, warmup) if warmup else 0):
+            shrinkingHorizon(train, track, wl.options(N), T[:64], numResolves=2, noise=0.01, seed=1, warmStart=warm, device=device)
+    else:
+        loop = DeviceLoop(train, track, wl.options(N), 50, noise=0.01, warmStart=warm, device=device)
+        run = lambda: loop.run(T, seed=1, keepZ=False)
+        for _ in range(max(1, warmup) if warmup else 0):
+            run()
     if barrier:
         barrier()
     t0 = time.perf_counter()
@@ -273,10 +283,13 @@ def measure_mpc(train, track, N, T, steps, warmup, device, warm=True, barrier=No
     if barrier:
         barrier()
     elapsed = time.perf_counter() - t0
+    if loop is not None:
+        loop.close()
     stage_iters = float(sum(l['numIntervals']*l['iterations'].sum() for l in log))
     info = {"resolves_per_loop": len(log), "scenarios": len(T), "successful": good, "failed": failed, "arrival_time_relaxed": relaxed,
             "ip_iterations_mean": float(np.mean([l['iterations'].mean() for l in log])),
-            "kernel_ms_per_loop": float(sum(l['kernel_ms'] for l in log)), "stage_iterations_per_loop": stage_iters}
+            "kernel_ms_per_loop": float(sum(l['kernel_ms'] for l in log)), "stage_iterations_per_loop": stage_iters,
+            "loop": "host" if host_loop else "device"}
     return elapsed, info
 
 
@@ -437,14 +450,15 @@ def main():
                 "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "config 4: {} scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals from N={}, 1 % measurement noise on t and v, "
-                                       "seed 20260615+rank), warm-started from the previous solution and multipliers on the device; value counts successful re-solves only; "
-                                       "wall time of the host loop including grids, transfers and re-configuration".format(B, N),
+                                       "seed 20260615+rank), warm-started from the previous solution and multipliers on the device, loop bookkeeping on the device (msd_mpc_run; the 50 problem "
+                                       "records are uploaded once, outside the timed region: the grid sequence does not depend on the solutions); value counts successful re-solves only; "
+                                       "wall time per loop including the download of the log".format(B, N),
                            "batch_per_gpu": B, "num_intervals": N, "resolves_failed": failed_all, "resolves_successful": good_all,
                            "arrival_time_relaxed": info['arrival_time_relaxed'], "ip_iterations_mean": info['ip_iterations_mean'],
                            "parallelism": "scenarios sharded, no collective"},
                 "roofline": roofline_block(entry, 'c4', B*info['resolves_per_loop'], N, nz, info['stage_iterations_per_loop'], launch_ms, geo),
             }
-            line["roofline"]["launch_ms_note"] = "sum of the kernel times of the loop's launches (one per re-solve, shrinking horizons)"
+            line["roofline"]["launch_ms_note"] = "device time of one whole loop (events around its 50 re-solves: solver launches and bookkeeping kernels, shrinking horizons)"
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -541,6 +555,25 @@ def alt_workloads(args, device):
     for name in ('integrate_losses', 'irk_radau2', 'cvodes_tolerances'):
         one(name, 'c1', PER_GPU_BATCH['c1'], transcription=name)
 
+    # the dynamic loss model (efficiency.py) on the configuration of simulations/figure5.py (fun2): 8.5 km crop, v0 = 1 m/s, vN = 100 km/h, forceMinPn = 0, limits
+    # after the side effects of totalLossesFunction; 1024 running times of 1.05 ... 1.35 times the reference's minimum of 272.4726 s (figure5.py:96)
+    from mseetc.train import Train
+    from mseetc.efficiency import totalLossesFunction
+    from mseetc.ocp import casadiSolver as _cs
+    for Nd in (100, 300):
+        tr = Train(config={'id': 'NL_Intercity_VIRM6'})
+        tr.forceMinPn = 0
+        tr.powerLosses = totalLossesFunction(tr, auxiliaries=27000, etaGear=0.96)
+        sv = _cs(tr, wl.track_00(8500), wl.options(Nd), device=device)
+        Td = 272.4726*(1.05 + 0.30*np.random.default_rng(20260616).random(PER_GPU_BATCH['c1']))
+        sc = sv._scenarios(Td, 0, 100/3.6, 1)
+        e, ms, st = measure(sv, sc, None, k, w)
+        alt["dynamic_losses_N%d" % Nd] = dict(summarize(sc.shape[0], Nd, k, e, ms, st), frac_model_S=BYTES_PER_STAGE_ITER*Nd*float(np.sum(st[:, _ST['ITERS']]))/(ms*1e-3)/1e9/HBM_PEAK_GBS,
+                                               kernel="msd::solve_kernel<{},{}> with the loss table (DYN = 1)".format(*sv.problem.geometry()),
+                                               workload="simulations/figure5.py configuration with the dynamic loss model of efficiency.py (motor/converter table, gear, auxiliaries, "
+                                                        "transformer), N = {}, 1024 running times 272.4726 s x (1.05 ... 1.35), v0 = 1 m/s, vN = 100 km/h".format(Nd))
+        sv.close()
+
     # the host-buffer entry point (msd_solve_batch: scenarios from and results into host memory): the PCIe-inclusive rate of the same workload,
     # wall clock over ten calls -- upload of the scenario records, launch, download of z* and the statistics.  Never the headline value.
     hb = {}
@@ -562,16 +595,18 @@ def alt_workloads(args, device):
     train, track, N = wl.config('c4')
     T = wl.c1_times(PER_GPU_BATCH['c4'], seed=20260615)
     c4 = {}
-    for warm in (False, True):
+    for name, warm, host in (("cold", False, False), ("warm", True, False), ("warm_host_loop", True, True)):
         loops = 3
-        wall, info = measure_mpc(train, track, N, T, loops, 1, device, warm=warm)
-        c4["warm" if warm else "cold"] = {"resolves_per_s": info['successful']/wall, "wall_s": wall/loops, "loops": loops, "resolves": info['resolves_per_loop'],
+        wall, info = measure_mpc(train, track, N, T, loops, 1, device, warm=warm, host_loop=host)
+        c4[name] = {"resolves_per_s": info['successful']/wall, "wall_s": wall/loops, "loops": loops, "resolves": info['resolves_per_loop'],
                                           "scenarios": len(T), "ip_iterations_mean": info['ip_iterations_mean'], "successful": info['successful']//loops,
                                           "failed": info['failed']//loops, "arrival_time_relaxed": info['arrival_time_relaxed']//loops,
-                                          "kernel_ms_per_loop": info['kernel_ms_per_loop']}
-    c4["workload"] = ("config 4: 512 scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals, 1 % measurement noise), wall time of the host loop "
-                      "including transfers; resolves_per_s counts successful re-solves only; a re-solve whose measured state no longer allows the arrival time "
-                      "is repeated with the arrival time moved to its certified minimum (arrival_time_relaxed)")
+                                          "kernel_ms_per_loop": info['kernel_ms_per_loop'], "loop": info['loop']}
+    c4["workload"] = ("config 4: 512 scenarios per GPU x 50 shrinking-horizon re-solves (stride 2 intervals, 1 % measurement noise); cold / warm: the loop with its "
+                      "bookkeeping on the device (msd_mpc_run: one call per loop, wall time including the download of the log; kernel_ms_per_loop = device time "
+                      "of the whole loop between two events); warm_host_loop: the host-side loop (one launch per re-solve, transfers and numpy in between; "
+                      "kernel_ms_per_loop = sum of the launches' kernel times); resolves_per_s counts successful re-solves only; a re-solve whose measured "
+                      "state no longer allows the arrival time is repeated with the arrival time moved to its certified minimum (arrival_time_relaxed)")
     alt["c4"] = c4
 
     # the restoration phase (cold path): schedules 8 to 13 times the minimum running time from the reference's starting point, where its

@@ -186,6 +186,17 @@ int msd_solve_batch_device_ex(msd_handle h, int nscen, const double *d_scen, con
 /* launch geometry the handle's problem runs with: threads per workgroup (= per scenario) and shooting nodes per thread */
 int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per_thread);
 
+/*
+ * Split solves (round 4).  The kernels of the benchmark family solve a batch in two launches on the handle's stream: a first pass that holds the
+ * fused interior-point iteration alone, and a follow-up kernel (general iteration, restoration phase, second attempt) for the scenarios
+ * the first pass hands over through a list in device memory -- in the reference all of that is inside the one call of IPOPT (ocp.py:359).
+ * Telemetry, never reset: counts[0] scenarios handed over since the handle was created, counts[1 + why] by reason (0 no fused start for the
+ * scenario, 1 wrong inertia or scan breakdown, 2 tiny step, 3 rejected first trial point with a second-order correction due, 4 line search
+ * broke down, 5 breakdown that asks for the second attempt).  Waits for the handle's stream.  n <= 7 entries are written (zeros for a
+ * handle whose kernels are not split).
+ */
+int msd_problem_follow_counts(msd_handle h, int *counts, int n);
+
 /* msd_solve_batch with per-scenario rolling-stock overrides: overrides[nscen][MSD_OV_COUNT] (host), NULL = none */
 int msd_solve_batch_ex(msd_handle h, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out, double *stats,
                        float *kernel_ms);

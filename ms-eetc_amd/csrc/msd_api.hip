@@ -19,70 +19,21 @@
 #include <utility>
 #include <vector>
 
-#include "msd_kernel.hpp"
-#include "msd_geometry.hpp"
+#include "msd_handle.hpp"
 
 namespace {
-
 thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-#define HIP_TRY(expr)                                                                                     \
-    do {                                                                                                  \
-        hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) return fail(MSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
-    } while (0)
-
-}  // namespace
-
-struct msd_problem {
-    msd::DevProb P;
-    int device = 0;
-    int NT = 0;
-    size_t lds_bytes = 0;
-    int max_grid = 0;
-    msd::KernelFn kernel = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
-    double *h_stage = nullptr; size_t cap_stage = 0;  /* pinned staging buffer for the profile upload */
-    double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
-    double *d_eval = nullptr; size_t cap_eval = 0;    /* msd_stage_eval: inputs and outputs of n intervals (17 n doubles), grown on demand */
-    int *d_queue = nullptr;                           /* scenario counters of the launches (a ring: launches in flight on the stream each own one) */
-    int queue_slot = 0;
-    size_t cap_work = 0;
-    int SPT = 0;
-    int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
-    /* grow-only scratch of the host-buffer entry point */
-    double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
-    /* second result buffers: a solve that warm-starts from the previous solve of the handle reads one pair while it writes the other */
-    double *d_z2 = nullptr, *d_stats2 = nullptr;
-    int prev_nscen = 0, prev_nz = 0, prev_stp = 0;      /* what d_z / d_stats hold (prev_nscen = 0: nothing) */
-    /* multipliers of the solves (msd_problem_keep_duals): written to d_dual, read from it by a shifted warm start that writes d_dual2 */
-    bool keep_duals = false;
-    double *d_dual = nullptr, *d_dual2 = nullptr;
-    double *d_coll = nullptr;                           /* tables of the collocation integrator */
-    size_t cap_dual = 0;
-    int prev_dual_nodes = 0;                            /* nodes per scenario of what d_dual holds (0: nothing) */
-    int cap_scen = 0, cap_guess = 0;
-    double *h_hist = nullptr;
-    int hist_cap = 0;
-};
-
-extern "C" {
-
-const char *msd_last_error(void) { return g_err.c_str(); }
-
-int msd_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
 }
 
+namespace msd_host {
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}
+using msd_host::fail;
+
+namespace msd_host {
+
 /* argument checks shared by create and reconfigure */
-static int check_desc(const msd_problem_desc *d)
+int check_desc(const msd_problem_desc *d)
 {
     if (d->abi_version != MSD_ABI_VERSION) return fail(MSD_E_INVALID, "ABI version mismatch");
     if (d->num_intervals < 1) return fail(MSD_E_INVALID, "Number of intervals must be a strictly positive integer!");
@@ -111,6 +62,7 @@ static int check_desc(const msd_problem_desc *d)
         return fail(MSD_E_UNSUPPORTED, "integrateLosses runs with constant efficiencies (loss_kind 1)");
     return MSD_OK;
 }
+
 
 static int cu_count(int device, int *out)
 {
@@ -152,12 +104,11 @@ static int kernel_limits(int device, const void *fn, int threads, size_t lds, in
     return MSD_OK;
 }
 
-/*
- * Load a problem into a handle: kernel geometry for its horizon, scalars, and the profile arrays in the handle's device
- * buffer (grown when the horizon or the loss table outgrows it).  Streams, events and the scenario buffers are kept.
- */
-static int configure(msd_problem *h, const msd_problem_desc *d)
+
+/* kernel geometry of a problem's horizon and structure, resident workgroups, problem record without the profile pointers */
+int make_plan(int device, const msd_problem_desc *d, Plan *out)
 {
+    Plan &pl = *out;
     const int N = d->num_intervals;
     const bool dyn = d->loss_kind == 2;
     const bool gen = d->integrator != 0, intloss = d->integrate_losses != 0 && d->energy_optimal != 0;
@@ -165,8 +116,11 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     /* both brakes, power rows (finite by construction: ocp.py:186-187), energy objective, finite acceleration bounds (ocp.py:113-114) */
     const bool full = d->with_pn_brake != 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                       && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
+    /* the same without the pneumatic brake (forceMinPn = 0: the reference's scripts); static loss rows + explicit Runge-Kutta shooting only */
+    const bool full_rg = d->with_pn_brake == 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
+                         && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
     msd::Geometry geo = (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
-                        : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full);
+                        : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
     size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
@@ -178,6 +132,120 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
                                            : (gen || intloss || dyn) ? "numIntervals = " + std::to_string(N) + " exceeds the 1023 intervals of the streamed kernels for the dynamic loss model, the collocation / adaptive shooting integrators and integrateLosses"
                                            : "numIntervals = " + std::to_string(N) + " exceeds the 5119 intervals of the streamed kernel");
     }
+    pl.NT = geo.NT; pl.SPT = geo.SPT; pl.lds_bytes = lds; pl.stream = geo.stream;
+    msd::DevProb &P = pl.P;
+    P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
+    P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
+    P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
+    P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
+    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
+    P.ds = P.grad = P.curv = P.bmax = P.pos = nullptr;      /* (the owner of the profile buffer fills these) */
+    P.loss = nullptr;
+    P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
+    P.coll = nullptr;
+    P.resto = d->no_restoration ? 0 : 1;
+    if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
+
+    int per_cu = 0, cus = 0;
+    int rc = kernel_limits(device, (const void *)geo.fn, geo.NT, lds, &per_cu);
+    if (rc != MSD_OK) return rc;
+    rc = cu_count(device, &cus);
+    if (rc != MSD_OK) return rc;
+    pl.max_grid = per_cu*cus;
+    pl.max_grid2 = 0;
+    if (geo.fn2) {
+        rc = kernel_limits(device, (const void *)geo.fn2, geo.NT, lds, &per_cu);
+        if (rc != MSD_OK) return rc;
+        pl.max_grid2 = per_cu*cus;
+    }
+    pl.max_grid_lsq = 0;
+    if (geo.fn_lsq) {
+        rc = kernel_limits(device, (const void *)geo.fn_lsq, geo.NT, lds, &per_cu);
+        if (rc != MSD_OK) return rc;
+        pl.max_grid_lsq = per_cu*cus;
+    }
+    pl.fused_family = geo.fn2 != nullptr && geo.xch == msd::XCH_FAST;
+    pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : msd::work_doubles(geo.NT*geo.SPT);
+    pl.nz = (4 + P.withPn)*N + 2; pl.nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
+    pl.kernel = geo.fn; pl.kernel2 = geo.fn2; pl.kernel_lsq = geo.fn_lsq;
+    return MSD_OK;
+}
+
+int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follow, int *d_queue, int nscen, const double *d_scen, const double *d_ovr,
+                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list)
+{
+    if (!pl.kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
+    msd::DevProb P = pl.P;
+    P.follow = nullptr; P.queue = nullptr;
+    P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
+    P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
+    const bool split = pl.kernel2 != nullptr;
+    if (d_list) {
+        /* the scenarios of a list, by the kernel that holds everything (an idle workgroup returns at once) */
+        const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
+        const int cap = split ? pl.max_grid2 : pl.max_grid;
+        P.follow = d_list;
+        hipLaunchKernelGGL(fn, dim3(std::min(nscen, cap)), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+        HIP_TRY(hipGetLastError());
+        return MSD_OK;
+    }
+    /* split solves (msd::Geometry::fn2): first pass + follow-up kernel behind it on the stream, the list of unfinished scenarios between them.
+     * The first pass is the kernel without the least-squares multiplier estimate when every scenario can start without it (profile start,
+     * primal-dual warm start), the one with it otherwise (the reference's starting point, a primal-only warm start) */
+    const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
+    const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);
+    const msd::KernelFn fn = (split && !first_pass) ? pl.kernel2 : plain ? pl.kernel : pl.kernel_lsq;
+    const int cap = (split && !first_pass) ? pl.max_grid2 : plain ? pl.max_grid : pl.max_grid_lsq;
+    const int grid = nscen < cap ? nscen : cap;
+    if (first_pass) {
+        if (!d_follow) return fail(MSD_E_INVALID, "split solve without its list");
+        P.follow = d_follow;
+    }
+    if (nscen > grid) {
+        /* more scenarios than resident workgroups: dynamic distribution through a counter */
+        if (!d_queue) return fail(MSD_E_INVALID, "launch without its scenario counter");
+        P.queue = d_queue;
+        HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), stream));
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+    HIP_TRY(hipGetLastError());
+    if (first_pass) {
+        /* the follow-up kernel: usually nothing to do (0 of the 1024 + 8192 benchmark scenarios of configs 1 and 2) -- a workgroup that finds
+         * the list empty returns at once, the others take scenarios off it until it is empty */
+        const int grid2 = std::min(nscen, pl.max_grid2);
+        P.queue = nullptr;
+        hipLaunchKernelGGL(pl.kernel2, dim3(grid2), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+        HIP_TRY(hipGetLastError());
+    }
+    return MSD_OK;
+}
+
+}  // namespace msd_host
+
+using msd_host::check_desc;
+
+extern "C" {
+
+const char *msd_last_error(void) { return g_err.c_str(); }
+
+int msd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/*
+ * Load a problem into a handle: its launch plan (make_plan) and the profile arrays in the handle's device buffer (grown when the horizon or
+ * the loss table outgrows it).  Streams, events and the scenario buffers are kept.
+ */
+static int configure(msd_problem *h, const msd_problem_desc *d)
+{
+    const int N = d->num_intervals;
+    msd_host::Plan pl;
+    int rc = msd_host::make_plan(h->device, d, &pl);
+    if (rc != MSD_OK) return rc;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));      /* nothing of the previous problem may still be running */
     h->kernel = nullptr;                           /* the handle holds no problem until every step below has succeeded (launch() checks) */
@@ -221,29 +289,16 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         HIP_TRY(hipMemcpy(h->d_coll, d->coll_tables, sizeof(double)*len, hipMemcpyHostToDevice));
     }
 
-    h->NT = geo.NT; h->SPT = geo.SPT; h->lds_bytes = lds;
+    h->NT = pl.NT; h->SPT = pl.SPT; h->lds_bytes = pl.lds_bytes; h->stream_kernel = pl.stream;
+    h->P = pl.P;
     msd::DevProb &P = h->P;
-    P.N = N; P.withPn = d->with_pn_brake != 0; P.hasPower = d->has_power_rows != 0; P.energyOpt = d->energy_optimal != 0;
-    P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
-    P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
-    P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
-    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = h->d_prof; P.grad = P.ds + N; P.curv = P.grad + N; P.bmax = P.curv + N; P.pos = P.bmax + N + 1;
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
-    P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
     P.coll = (d->integrator == MSD_INTEGRATOR_COLLOCATION) ? h->d_coll : nullptr;
-    P.resto = d->no_restoration ? 0 : 1;
-    if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
-
-    int per_cu = 0, cus = 0;
-    int rc = kernel_limits(h->device, (const void *)geo.fn, geo.NT, lds, &per_cu);
-    if (rc != MSD_OK) return rc;
-    rc = cu_count(h->device, &cus);
-    if (rc != MSD_OK) return rc;
-    h->max_grid = per_cu*cus;
+    h->max_grid = pl.max_grid; h->max_grid2 = pl.max_grid2; h->max_grid_lsq = pl.max_grid_lsq; h->fused_family = pl.fused_family;
+    h->work_per_wg = pl.work_doubles;
     {
-        const size_t need = (geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : msd::work_doubles(geo.NT*geo.SPT))*(size_t)h->max_grid;
+        const size_t need = pl.work_doubles*(size_t)std::max(h->max_grid, std::max(h->max_grid2, h->max_grid_lsq));
         if (need > h->cap_work) {
             hipFree(h->d_work); h->d_work = nullptr; h->cap_work = 0;
             HIP_TRY(hipMalloc((void **)&h->d_work, sizeof(double)*need));
@@ -258,7 +313,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         h->prev_nscen = 0;
         h->cap_nz = nz; h->cap_nl = nl;
     }
-    h->kernel = geo.fn;
+    h->kernel = pl.kernel; h->kernel2 = pl.kernel2; h->kernel_lsq = pl.kernel_lsq;
     return MSD_OK;
 }
 
@@ -295,7 +350,7 @@ int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue);
+    hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue); hipFree(h->d_follow);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess); hipFree(h->d_eval);
     hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
     if (h->h_stage) hipHostFree(h->h_stage);
@@ -311,28 +366,38 @@ int msd_problem_rows_per_interval(msd_handle h) { return h ? (h->P.hasPower ? 2 
 
 constexpr int QUEUE_RING = 64;
 
-struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0;
-                   const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr; };
+using msd_host::WarmStart;
+
+/* the launch plan a configured handle holds */
+static msd_host::Plan plan_of(const msd_problem *h)
+{
+    msd_host::Plan pl;
+    pl.P = h->P; pl.NT = h->NT; pl.SPT = h->SPT; pl.lds_bytes = h->lds_bytes; pl.stream = h->stream_kernel;
+    pl.kernel = h->kernel; pl.kernel_lsq = h->kernel_lsq; pl.kernel2 = h->kernel2;
+    pl.max_grid = h->max_grid; pl.max_grid_lsq = h->max_grid_lsq; pl.max_grid2 = h->max_grid2; pl.fused_family = h->fused_family;
+    pl.work_doubles = h->work_per_wg; pl.nz = msd_problem_nz(const_cast<msd_problem *>(h)); pl.nl = msd_problem_rows_per_interval(const_cast<msd_problem *>(h))*h->P.N;
+    return pl;
+}
 
 static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
                   const WarmStart &ws = WarmStart())
 {
     if (!h->kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
-    const int grid = nscen < h->max_grid ? nscen : h->max_grid;
-    msd::DevProb P = h->P;
-    if (nscen > grid) {
-        /* more scenarios than resident workgroups: dynamic distribution through a counter (one of QUEUE_RING, so that launches queued
-         * back to back on the stream do not share it) */
-        if (!h->d_queue) HIP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)*QUEUE_RING));
-        P.queue = h->d_queue + h->queue_slot;
-        h->queue_slot = (h->queue_slot + 1) % QUEUE_RING;
-        HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), h->stream));
+    if (h->kernel2) {
+        const size_t need = msd::FOLLOW_HDR + 2*(size_t)nscen;
+        if (need > h->cap_follow) {
+            HIP_TRY(hipStreamSynchronize(h->stream));      /* (a follow-up kernel in flight reads the old list) */
+            hipFree(h->d_follow); h->d_follow = nullptr; h->cap_follow = 0;
+            HIP_TRY(hipMalloc((void **)&h->d_follow, sizeof(int)*need));
+            HIP_TRY(hipMemsetAsync(h->d_follow, 0, sizeof(int)*msd::FOLLOW_HDR, h->stream));      /* afterwards the follow-up kernel leaves the header zeroed */
+            h->cap_follow = need;
+        }
     }
-    P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
-    P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
-    hipLaunchKernelGGL(h->kernel, dim3(grid), dim3(h->NT), h->lds_bytes, h->stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, h->d_work);
-    HIP_TRY(hipGetLastError());
-    return MSD_OK;
+    /* one of QUEUE_RING scenario counters, so that launches queued back to back on the stream do not share it */
+    if (!h->d_queue) HIP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)*QUEUE_RING));
+    int *queue = h->d_queue + h->queue_slot;
+    h->queue_slot = (h->queue_slot + 1) % QUEUE_RING;
+    return msd_host::launch_plan(plan_of(h), h->stream, h->d_work, h->d_follow, queue, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, ws);
 }
 
 int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats)
@@ -351,6 +416,17 @@ int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per
 {
     if (!h || !threads_per_scenario || !nodes_per_thread) return fail(MSD_E_INVALID, "bad argument");
     *threads_per_scenario = h->NT; *nodes_per_thread = h->SPT;
+    return MSD_OK;
+}
+
+int msd_problem_follow_counts(msd_handle h, int *counts, int n)
+{
+    if (!h || !counts || n < 1) return fail(MSD_E_INVALID, "bad argument");
+    if (n > 7) n = 7;
+    for (int k = 0; k < n; k++) counts[k] = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_follow) HIP_TRY(hipMemcpy(counts, h->d_follow + msd::FOLLOW_TOTAL, sizeof(int)*n, hipMemcpyDeviceToHost));
     return MSD_OK;
 }
 
@@ -392,6 +468,9 @@ static int check_batch(msd_handle h, int nscen, const double *scen, const double
             if (!(o[MSD_OV_OBJ_DEN] > 0) || !(o[MSD_OV_F_MAX] > o[MSD_OV_F_MIN]) || !(o[MSD_OV_SR0] >= 0) || !(o[MSD_OV_SR1] >= 0) || !(o[MSD_OV_SR2] >= 0) ||
                 !(o[MSD_OV_TOTAL_MASS] >= 0))
                 return fail(MSD_E_INVALID, "invalid rolling-stock override");
+            /* the kernels with the row structure compiled in take both power rows as two-sided (finite by construction in the problem record: ocp.py:186-187) */
+            if (h->fused_family && (!std::isfinite(o[MSD_OV_PW_UPPER]) || !std::isfinite(o[MSD_OV_PW_LOWER])))
+                return fail(MSD_E_INVALID, "rolling-stock override with an infinite power bound on a problem whose power rows are bounded");
         }
     for (int k = 0; k < nscen; k++) {
         const double *s = scen + (size_t)MSD_SC_COUNT*k;

@@ -16,10 +16,15 @@ struct Geometry {
     bool stream = false;                 /* stage blocks in device memory (long horizons) */
     int xch = XCH_GENERAL;               /* exchange arrays in LDS and cross-wave reduction scratch (lds_doubles) */
     int red = RED_DOUBLES;
+    KernelFn fn2 = nullptr;              /* not null: `fn` is the first pass of a split solve (solve_kernel's PART = 1) and this the follow-up kernel (PART = 2) */
+    KernelFn fn_lsq = nullptr;           /* first pass with the least-squares multiplier estimate in front (PART = 3): launches from the reference's starting point or a primal-only warm start */
 };
 
-Geometry pick_geometry_static(int N, bool full);     /* full: both brakes, power rows, energy objective -- the kernels with that structure compiled in */
+Geometry pick_geometry_static(int N, int full);     /* full: FULL_BOTH / FULL_RG -- the kernels with that structure compiled in (0: none) */
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
+KernelFn follow_kernel_full(int NT, int SPT);       /* follow-up kernels of that family (msd_kernels_full3.hip) */
+Geometry pick_geometry_full_rg(int N);                /* the same with the regenerative brake alone (FULL_RG: msd_kernels_rg.hip, msd_kernels_rg2.hip) */
+KernelFn follow_kernel_full_rg(int NT, int SPT);
 Geometry pick_geometry_dynamic(int N);
 Geometry pick_stream_geometry_static(int N);
 Geometry pick_geometry_general_long(int N);      /* 257 ... 640 nodes of the same family (msd_kernels_general2.hip) */

@@ -1,0 +1,99 @@
+/*
+ * msd_handle.hpp -- host-side internals shared by msd_api.hip and msd_mpc.hip (never included by the kernel units): the handle behind the
+ * C ABI, the launch plan of a problem (kernel geometry, resident workgroups, problem record) and the launch of a plan on a stream.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "msd_kernel.hpp"
+#include "msd_geometry.hpp"
+
+namespace msd_host {
+
+int fail(int code, const std::string &msg);      /* records the message of msd_last_error() and returns `code` */
+
+#define HIP_TRY(expr)                                                                                               \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) return msd_host::fail(MSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+/* what a launch of a problem needs besides buffers: the kernels of its horizon and structure, their limits, the problem record (the profile
+ * pointers of P are the owner's to fill) */
+struct Plan {
+    msd::DevProb P;
+    int NT = 0, SPT = 0;
+    size_t lds_bytes = 0;
+    bool stream = false;                              /* stage blocks in device memory (long horizons) */
+    msd::KernelFn kernel = nullptr;                   /* complete kernel, or the first pass of a split solve (kernel2 != nullptr) */
+    msd::KernelFn kernel_lsq = nullptr;               /* first pass for launches that need the least-squares multiplier estimate (msd::Geometry::fn_lsq) */
+    msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2) */
+    int max_grid = 0, max_grid_lsq = 0, max_grid2 = 0;      /* resident workgroups of the three */
+    bool fused_family = false;                        /* `kernel` runs the fused iteration only (needs a profile start or a primal-dual warm start) */
+    size_t work_doubles = 0;                          /* work area of one workgroup */
+    int nz = 0, nl = 0;                               /* variables / constraint multipliers per scenario */
+};
+
+int check_desc(const msd_problem_desc *d);
+int make_plan(int device, const msd_problem_desc *d, Plan *out);      /* (check_desc() must have accepted d) */
+
+struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0;
+                   const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr; };
+
+/*
+ * One batch on `stream`: the first pass + the follow-up kernel of a split solve, or the one kernel that holds everything.
+ *   d_follow : list between the two kernels of a split solve (FOLLOW_HDR + 2 nscen ints, header zero)
+ *   d_queue  : one int (zeroed here) for the dynamic distribution of more scenarios than resident workgroups
+ *   d_list   : not null -- only the scenarios of this list (layout of DevProb::follow: [0] count, [1] [2] zero, pairs from FOLLOW_HDR on) are
+ *              solved, by the complete kernel (the follow-up kernel of a split solve) from the problem's own starting point; the kernel
+ *              leaves the header zeroed
+ */
+int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follow, int *d_queue, int nscen, const double *d_scen, const double *d_ovr,
+                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list = nullptr);
+
+}  // namespace msd_host
+
+struct msd_problem {
+    msd::DevProb P;
+    int device = 0;
+    int NT = 0;
+    size_t lds_bytes = 0;
+    int max_grid = 0;
+    msd::KernelFn kernel = nullptr;
+    msd::KernelFn kernel_lsq = nullptr;               /* first pass for launches that need the least-squares multiplier estimate (msd::Geometry::fn_lsq) */
+    int max_grid_lsq = 0;
+    msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2), its resident workgroups and the list between the two */
+    int max_grid2 = 0;
+    int *d_follow = nullptr; size_t cap_follow = 0;
+    bool fused_family = false;                        /* `kernel` runs the fused iteration only (needs a profile start or a primal-dual warm start) */
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_prof = nullptr, *d_loss = nullptr;      /* ds | grad | curv | bmax | pos; loss table */
+    double *h_stage = nullptr; size_t cap_stage = 0;  /* pinned staging buffer for the profile upload */
+    double *d_work = nullptr;                         /* private work areas of the resident workgroups (msd::work_doubles each) */
+    double *d_eval = nullptr; size_t cap_eval = 0;    /* msd_stage_eval: inputs and outputs of n intervals (17 n doubles), grown on demand */
+    int *d_queue = nullptr;                           /* scenario counters of the launches (a ring: launches in flight on the stream each own one) */
+    int queue_slot = 0;
+    size_t cap_work = 0;
+    int SPT = 0;
+    bool stream_kernel = false;                       /* the problem runs on a streamed kernel (stage blocks in device memory) */
+    size_t work_per_wg = 0;                           /* doubles of work area per workgroup */
+    int cap_N = 0, cap_loss = 0, cap_nz = 0, cap_nl = 0;
+    /* grow-only scratch of the host-buffer entry point */
+    double *d_scen = nullptr, *d_ovr = nullptr, *d_z = nullptr, *d_lam = nullptr, *d_stats = nullptr, *d_hist = nullptr, *d_guess = nullptr;
+    /* second result buffers: a solve that warm-starts from the previous solve of the handle reads one pair while it writes the other */
+    double *d_z2 = nullptr, *d_stats2 = nullptr;
+    int prev_nscen = 0, prev_nz = 0, prev_stp = 0;      /* what d_z / d_stats hold (prev_nscen = 0: nothing) */
+    /* multipliers of the solves (msd_problem_keep_duals): written to d_dual, read from it by a shifted warm start that writes d_dual2 */
+    bool keep_duals = false;
+    double *d_dual = nullptr, *d_dual2 = nullptr;
+    double *d_coll = nullptr;                           /* tables of the collocation integrator */
+    size_t cap_dual = 0;
+    int prev_dual_nodes = 0;                            /* nodes per scenario of what d_dual holds (0: nothing) */
+    int cap_scen = 0, cap_guess = 0;
+    double *h_hist = nullptr;
+    int hist_cap = 0;
+};
+

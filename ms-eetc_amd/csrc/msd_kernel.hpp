@@ -48,6 +48,9 @@
 #ifndef MSD_FENCE_PHASES
 #define MSD_FENCE_PHASES 0x155      /* bit k: fence after phase k (enum PH_*): evaluation, assembly, read-back, step lengths, update (tools/ab.sh, round 2) */
 #endif
+#ifndef MSD_HOT_FENCES
+#define MSD_HOT_FENCES 0            /* 1: phase fences also in the first-pass kernels of the fused iteration (A/B builds) */
+#endif
 #ifndef MSD_FENCE_MAX_NT
 #define MSD_FENCE_MAX_NT 256        /* largest workgroup the phase fences are applied to (see Solver::phase_fence) */
 #endif
@@ -127,7 +130,16 @@ struct DevProb {
     double intAtol, intRtol; /* OptionsCVODES.absTol, .relTol */
     const double *coll;      /* C[(collD+1)^2], D[collD+1] of casadi.simpleIRK */
     int resto;               /* feasibility restoration phase where the line search breaks down (IPOPT's behaviour; msd_resto.hpp) */
+    /* split launches (solve_kernel's PART): the first-pass kernel appends the scenarios it does not finish to this list, the follow-up kernel drains it.
+     * follow[0] entries written, [1] entries taken, [2] follow-up workgroups that found the list empty (the last one zeroes the three for the next
+     * launch of the handle), [FOLLOW_HDR + 2k] scenario, [FOLLOW_HDR + 2k + 1] iterations already spent on it (>= 0: its first attempt broke down,
+     * the follow-up kernel begins with the second one) or -1 (nothing decided yet: the general iteration from the same starting point) */
+    int *follow;
 };
+/* behind the three counters: telemetry that is never reset -- [3] scenarios listed so far, [4 + why] by reason: 0 no fused start for the scenario
+ * (a warm start whose previous solve failed), 1 wrong inertia or a scan breakdown, 2 tiny step, 3 first trial point rejected where a
+ * second-order correction applies, 4 line search broke down (restoration phase), 5 a breakdown that asks for the second attempt */
+constexpr int FOLLOW_HDR = 16, FOLLOW_TOTAL = 3, FOLLOW_WHY = 4;
 
 /* IPOPT default option values */
 constexpr double K_BOUND_RELAX = 1e-8;
@@ -152,6 +164,11 @@ constexpr int RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5;
  * table (efficiency.py), 2 constant efficiencies integrated over the running time (integrateLosses, ocp.py:231-241; msd_lossint.hpp).
  * 1 and 2 couple the loss slack with b and Fpb and use the wider stage block */
 constexpr int LOSS_STATIC = 0, LOSS_TABLE = 1, LOSS_INTEGRATED = 2;
+/* FULL (template parameter of the kernels): structure of the NLP known at compile time -- 0 nothing (row set, brakes and objective read from the
+ * problem record), 1 both brakes + power rows + energy objective (the rolling stock of the reference's JSON files: BASELINE configs 1-4),
+ * 2 the same with the regenerative brake alone (forceMinPn = 0: what every script of the reference sets -- figure5.py:88, figure6.py:108,
+ * figure10.py:17, table3.py:18) */
+constexpr int FULL_BOTH = 1, FULL_RG = 2;
 constexpr int S_STRIDE_STATIC = 27, S_STRIDE_DYN = 31;
 __host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE_DYN : S_STRIDE_STATIC; }
 constexpr int FILT_CAP = 64;
@@ -209,13 +226,16 @@ __device__ __forceinline__ Jet chain(Jet a, double F, double f1, double f2)
 {
     return {F, f1*a.g0, f1*a.g1, f1*a.h00 + f2*a.g0*a.g0, f1*a.h01 + f2*a.g0*a.g1, f1*a.h11 + f2*a.g1*a.g1};
 }
-/* sqrt and its two derivatives from one reciprocal square root: 1/(2 sqrt(v)) = r/2, -1/(4 v sqrt(v)) = -r^3/4 */
+/* sqrt as a jet: the value is the IEEE square root -- the same number the value-only evaluation of a trial point computes (xsqrt(double)), so
+ * that the residual a Newton step is built on and the constraint violation the line search measures at the same point agree to the last bit --
+ * and the two derivative factors 1/(2 sqrt(v)) = r/2, -1/(4 v sqrt(v)) = -r^3/4 come from one reciprocal square root (they only shape the
+ * Newton direction) */
 #ifdef MSD_HOST_EMULATION
 __device__ __forceinline__ double rsqrt_(double v) { return 1.0/sqrt(v); }
 #else
 __device__ __forceinline__ double rsqrt_(double v) { return rsqrt(v); }
 #endif
-__device__ __forceinline__ Jet xsqrt(Jet a) { const double r = rsqrt_(a.v), f1 = 0.5*r; return chain(a, a.v*r, f1, -0.5*f1*(r*r)); }
+__device__ __forceinline__ Jet xsqrt(Jet a) { const double r = rsqrt_(a.v), f1 = 0.5*r; return chain(a, sqrt(a.v), f1, -0.5*f1*(r*r)); }
 __device__ __forceinline__ Jet xrecip(Jet a) { double r = 1.0/a.v; return chain(a, r, -r*r, 2*r*r*r); }
 __device__ __forceinline__ double xsqrt(double a) { return sqrt(a); }
 __device__ __forceinline__ double xrecip(double a) { return 1.0/a; }
@@ -666,11 +686,11 @@ struct Ev {
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
-template <bool DERIV, int DYN, bool GEN, bool FULL>
+template <bool DERIV, int DYN, bool GEN, int FULL>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
                                               double (&cv)[2], double (&dv)[NR], Ev &e)
 {
-    const double b = x[VB], f = x[VF], p = (FULL || P.withPn) ? x[VP] : 0.0, s = x[VS];
+    const double b = x[VB], f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
         if (GEN) interval_map_general<Jet>(P, b, f + p, nG, nds, tau, bp); else interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
@@ -719,12 +739,12 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
 }
 
 /* objective contribution of node i (interval terms + terminal time), scaled by sf */
-template <bool LI, bool FULL, class NodeT>
+template <bool LI, int FULL, class NodeT>
 __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &n, const double (&x)[NV], double q, double sf)
 {
     double J = 0;
     if (n.ival()) {
-        const double f = x[VF], p = (FULL || P.withPn) ? x[VP] : 0.0;
+        const double f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0;
         if (FULL || P.energyOpt) {
             J = LI ? n.ds*f + x[VS] : n.ds*(f + x[VS]);                       /* ocp.py:223 resp. :235 */
             if (n.i > 0) J += 1e-3*(f - q)*(f - q);                           /* ocp.py:245 */
@@ -1484,7 +1504,9 @@ struct ParallelRiccati {
  * ---------------------------------------------------------------------------------------- */
 enum { MODE_NEWTON = 0, MODE_LSQ = 1, MODE_RESTO = 2 };      /* (MODE_RESTO: Newton system of the restoration problem, msd_resto.hpp) */
 
-template <int NT, int SPT, int DYN, bool STREAM, bool GEN, bool FULL>
+/* PART: which part of a solve the enclosing kernel holds (solve_kernel) -- 0 everything, 1 the first pass (no restoration phase), 2 the follow-up,
+ * 3 the first pass with the least-squares multiplier estimate in front (any starting point) */
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL, int PART = 0>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -1509,7 +1531,7 @@ struct Solver {
     __device__ __forceinline__ bool rowOn(int r) const { return FULL ? true : U.rowOn[r]; }
     __device__ __forceinline__ bool rL(int r) const { return FULL ? true : U.rL[r]; }
     __device__ __forceinline__ bool rU(int r) const { return FULL ? (r <= RACC) : U.rU[r]; }
-    __device__ __forceinline__ bool withPn() const { return FULL ? true : P.withPn != 0; }
+    __device__ __forceinline__ bool withPn() const { return FULL == FULL_BOTH ? true : FULL == FULL_RG ? false : P.withPn != 0; }
     __device__ __forceinline__ bool energyOpt() const { return FULL ? true : P.energyOpt != 0; }
     __device__ __forceinline__ bool hasPower() const { return FULL ? true : P.hasPower != 0; }
 
@@ -1613,6 +1635,11 @@ struct Solver {
     __device__ __forceinline__ void phase_fence(int phase)
     {
 #if MSD_PHASE_FENCE
+        /* not in a first-pass kernel that holds the fused iteration alone (round 4): there the fences only cost -- with the general iteration and
+         * the restoration phase out of the code object the allocator keeps the iterate where it is, and the copies into architectural
+         * registers that an asm operand asks for (some 200 accumulation-register moves and 18 scratch round trips per fence) were a fifth of
+         * the run time: 858 k -> 1.03 M solves/s on config 1, 1.05 -> 1.26 M at 8192 per launch (gpurun_out/abhot1, profiles/r04) */
+        if (!MSD_HOT_FENCES && (PART == 1 || PART == 3) && FAST) return;
         if (!((MSD_FENCE_PHASES >> phase) & 1)) return;
         /* Up to four waves per workgroup (+30 ... 38 % at 192 x 2 and 256 x 2; the five-wave 320 x 2 kernel with its 256-register budget loses
          * 11 % to them).  Round 2 had switched them off above two waves after wrong results at 192 x 2 under the iterative-ilp scheduler it
@@ -2503,7 +2530,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < NR; r++) resd[j][r] = 0;
             if (nd.ival()) {
-                const double t = nd.x[VT], b = nd.x[VB], f = nd.x[VF], p = nd.x[VP], s = nd.x[VS];
+                const double t = nd.x[VT], b = nd.x[VB], f = nd.x[VF], p = withPn() ? nd.x[VP] : 0.0, s = nd.x[VS];
                 const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
                 const double q = (i > 0) ? c.xf[i - 1] : 0.0;
                 Jet tau, bp;
@@ -2527,7 +2554,7 @@ struct Solver {
                 gl[j][VT] = -l0;
                 gl[j][VB] = nd.nu[RPW0]*g.g0b + nd.nu[RACC]*g.g2b - (l0*tb + l1*Bb);
                 gl[j][VF] = of + nd.nu[RPW0]*g.g0f + nd.nu[RPW1]*g.g1f + nd.nu[RACC]*g.g2f + nd.nu[RLTR]*g.g3f + nd.nu[RLRG]*g.g4f - dyn_w;
-                gl[j][VP] = nd.nu[RACC]*g.g2f - dyn_w;
+                if (withPn()) gl[j][VP] = nd.nu[RACC]*g.g2f - dyn_w;
                 gl[j][VS] = os + nd.nu[RLTR]*g.g3s + nd.nu[RLRG]*g.g4s;
                 out_q = oq; out_t1 = l0; out_b1 = nd.nu[RPW1]*g.g1b1 + l1;
                 prim = fmax(prim, fmax(nd.sct*fabs(cv0), nd.scb*fabs(cv1)));
@@ -2540,7 +2567,8 @@ struct Solver {
                 if (i > 0) { Hqq = off; Hqf = -off; }
                 {
                     const double hbb = -(l0*tau.h00 + l1*bp.h00), hbw = -(l0*tau.h01 + l1*bp.h01), hww = -(l0*tau.h11 + l1*bp.h11);
-                    Hbb += hbb; Hbf += hbw; Hff += hww; Hbp += hbw; Hfp += hww; Hpp += hww;
+                    Hbb += hbb; Hbf += hbw; Hff += hww;
+                    if (withPn()) { Hbp += hbw; Hfp += hww; Hpp += hww; }
                 }
                 {
                     const double ib = isb*isb, ib1 = isb1*isb1;
@@ -2576,14 +2604,14 @@ struct Solver {
                 a0[1] += c0[RPW0]*g.g0b + c0[RACC]*g.g2b;                       a1[1] += c1[RPW0]*g.g0b + c1[RACC]*g.g2b;
                 a0[3] += c0[RPW0]*g.g0f + c0[RPW1]*g.g1f + c0[RACC]*g.g2f + c0[RLTR]*g.g3f + c0[RLRG]*g.g4f;
                 a1[3] += c1[RPW0]*g.g0f + c1[RPW1]*g.g1f + c1[RACC]*g.g2f + c1[RLTR]*g.g3f + c1[RLRG]*g.g4f;
-                a0[4] += c0[RACC]*g.g2f;                                         a1[4] += c1[RACC]*g.g2f;
+                if (withPn()) { a0[4] += c0[RACC]*g.g2f; a1[4] += c1[RACC]*g.g2f; }
                 a0[5] += c0[RLTR]*g.g3s + c0[RLRG]*g.g4s;                        a1[5] += c1[RLTR]*g.g3s + c1[RLRG]*g.g4s;
                 nhb0 = c0[RPW1]*g.g1b1; nhb1 = c1[RPW1]*g.g1b1;
                 Hbb += Sg[RPW0]*g.g0b*g.g0b + Sg[RACC]*g.g2b*g.g2b;
                 Hbf += Sg[RPW0]*g.g0b*g.g0f + Sg[RACC]*g.g2b*g.g2f;
-                Hbp += Sg[RACC]*g.g2b*g.g2f;
+                if (withPn()) Hbp += Sg[RACC]*g.g2b*g.g2f;
                 Hff += Sg[RPW0]*g.g0f*g.g0f + Sg[RPW1]*g.g1f*g.g1f + Sg[RACC]*g.g2f*g.g2f + Sg[RLTR]*g.g3f*g.g3f + Sg[RLRG]*g.g4f*g.g4f;
-                Hfp += Sg[RACC]*g.g2f*g.g2f; Hpp += Sg[RACC]*g.g2f*g.g2f;
+                if (withPn()) { Hfp += Sg[RACC]*g.g2f*g.g2f; Hpp += Sg[RACC]*g.g2f*g.g2f; }
                 Hfs += Sg[RLTR]*g.g3f*g.g3s + Sg[RLRG]*g.g4f*g.g4s;
                 Hss += Sg[RLTR]*g.g3s*g.g3s + Sg[RLRG]*g.g4s*g.g4s;
                 nHbq += Sg[RPW1]*g.g1f*g.g1b1; nHbb += Sg[RPW1]*g.g1b1*g.g1b1;
@@ -2594,7 +2622,7 @@ struct Solver {
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     Sv[k] = 0; g1v[k] = 0;
-                    if (!nd.on(k)) continue;
+                    if ((k == VP && !withPn()) || !nd.on(k)) continue;
                     {
                         const double sl = nd.x[k] - lbv(k), z = nd.zL[k], ri = 1.0/sl, cp = sl*z;
                         gl[j][k] -= z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= sl;
@@ -2612,7 +2640,7 @@ struct Solver {
                     double xl[NV];
 #pragma unroll
                     for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
-                    obj += objective_term<false, true>(P, nd, xl, (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
+                    obj += objective_term<false, FULL>(P, nd, xl, (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
                 }
                 double *sB = c.S + i*S_STRIDE;
                 if (nd.ival()) {
@@ -2650,7 +2678,7 @@ struct Solver {
             double *sB = c.S + i*S_STRIDE;
             sB[S_HBB] = Hbb; sB[S_HBQ] = Hbq;
 #pragma unroll
-            for (int k = 0; k < NV; k++) if (nd.on(k)) dual = fmax(dual, fabs(gl[j][k]));
+            for (int k = 0; k < NV; k++) if (!(k == VP && !withPn()) && nd.on(k)) dual = fmax(dual, fabs(gl[j][k]));
         }
         /* the row residuals wait for post_direction in five exchange arrays that are free until the next pass: not in registers
          * across the KKT solve */
@@ -2730,7 +2758,7 @@ struct Solver {
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) {
-                if (!nd.on(k)) continue;
+                if ((k == VP && !withPn()) || !nd.on(k)) continue;
                 const double dk = d.dx[k];
                 double gp;
                 {
@@ -2797,7 +2825,7 @@ struct Solver {
             const int i = nd.i;
             double prod = 1.0;
             if (nd.ival()) {
-                const double t = xt[j][VT], b = xt[j][VB], f = xt[j][VF], p = xt[j][VP], s = xt[j][VS];
+                const double t = xt[j][VT], b = xt[j][VB], f = xt[j][VF], p = withPn() ? xt[j][VP] : 0.0, s = xt[j][VS];
                 const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
                 double tau, bp;
                 interval_map<double>(P, b, f + p, nd.G, nd.ds, tau, bp);
@@ -2817,12 +2845,12 @@ struct Solver {
             if (nd.node()) {
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    if (!nd.on(k)) continue;
+                    if ((k == VP && !withPn()) || !nd.on(k)) continue;
                     { const double sl = xt[j][k] - lbv(k); if (sl <= 0) bad = 1; else prod *= sl; }
                     if (hasU(k)) { const double su = ubv(j, k) - xt[j][k]; if (su <= 0) bad = 1; else prod *= su; }
                     else damp += xt[j][k] - lbv(k);
                 }
-                obj += objective_term<false, true>(P, nd, xt[j], (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
+                obj += objective_term<false, FULL>(P, nd, xt[j], (i > 0) ? c.xf[i - 1] : 0.0, U.sf);
             }
             lsum.add(prod);
         }
@@ -2848,7 +2876,7 @@ struct Solver {
             Dir dd; load_dir(j, dd);
 #pragma unroll
             for (int k = 0; k < NV; k++) {
-                if (!nd.on(k)) continue;
+                if ((k == VP && !withPn()) || !nd.on(k)) continue;
                 const double dk = dd.dx[k], xo = nd.x[k], xn = step_to(xo, apr, dk);
                 {
                     const double s = xo - lbv(k), z = nd.zL[k], r = 1.0/s;
@@ -2900,7 +2928,7 @@ struct Solver {
                 if (!nd.node()) continue;
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    if (!nd.on(k)) continue;
+                    if ((k == VP && !withPn()) || !nd.on(k)) continue;
                     nd.zL[k] = sigma_clamp(nd.zL[k], mu_, nd.x[k] - lbv(k));
                     if (hasU(k)) nd.zU[k] = sigma_clamp(nd.zU[k], mu_, ubv(j, k) - nd.x[k]);
                 }
@@ -2918,6 +2946,7 @@ struct Solver {
      * FL: the fused iteration of the FAST kernels (no least-squares multiplier estimate: profile start or primal-dual warm start only);
      * it returns STATUS_GENERAL when something rare asks for the general iteration, and the caller solves the scenario again with FL = false */
     static constexpr int STATUS_GENERAL = -100;
+    int why_general = 0;      /* what sent the fused iteration to the general one (DevProb::follow telemetry) */
 #include "msd_resto.hpp"
 
     /* the general iteration hands a scenario whose line search broke down to the restoration phase (STATUS_RESTO, the iterate parked in the
@@ -2929,7 +2958,9 @@ struct Solver {
 #ifndef MSD_RESTO_VARIANT
 #define MSD_RESTO_VARIANT 0
 #endif
-    static constexpr bool HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM && !GEN && NT <= 256;
+    static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM && !GEN && NT <= 256;
+    static constexpr bool FIRST = PART == 1 || PART == 3;
+    static constexpr bool HAS_RESTO = FAMILY_HAS_RESTO && !FIRST;      /* (a first-pass kernel leaves the phase to its follow-up kernel) */
     static constexpr int STATUS_RESTO = -101;
 
     template <bool FL>
@@ -3099,8 +3130,11 @@ struct Solver {
         }
 
 
-        /* ---- least-squares multiplier estimate (W&B section 3.6) ---- */
-        if constexpr (!FL)
+        /* ---- least-squares multiplier estimate (W&B section 3.6) ----
+         * (the fused iteration of the first-pass kernels with PART = 3 takes it too -- one KKT solve of the general kind in front of the loop, not
+         * inside it -- and so serves the reference's starting point and primal-only warm starts; the kernels for the profile start and the
+         * primal-dual warm start, PART = 1, do not carry the code: 1.5 % on config 1) */
+        if constexpr (!FL || PART == 3)
         if (!dualStart)
 #if MSD_PROFILE_SKIP_LSQ
         if (ext || startKind != MSD_START_PROFILE)
@@ -3205,15 +3239,15 @@ struct Solver {
                 c.mark(PH_OTHER); phase_fence(PH_OTHER);
                 finish_blocks(h0, h1, mu);
                 c.mark(PH_ASSEMBLE); phase_fence(PH_ASSEMBLE);
-                const int par = ParallelRiccati<SPT, DYN>::solve(P.N, true, c);
+                const int par = ParallelRiccati<SPT, DYN>::solve(P.N, withPn(), c);
                 c.red_slot++;
                 c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
-                if (par != 1) { status = STATUS_GENERAL; break; }      /* wrong inertia or scan breakdown (never seen on the benchmark batches) */
+                if (par != 1) { status = STATUS_GENERAL; why_general = 1; break; }      /* wrong inertia or scan breakdown (never seen on the benchmark batches) */
                 double gphid, amax;
                 bool tiny_step;
                 post_direction(mu, tau, gphid, dnorm, tiny_step, amax, alpha_du);
                 c.mark(PH_GPHID); phase_fence(PH_GPHID);
-                if (tiny_step) { status = STATUS_GENERAL; break; }
+                if (tiny_step) { status = STATUS_GENERAL; why_general = 2; break; }
                 tiny_count = 0;
                 double amin = G_THETA;
                 if (gphid < 0) {
@@ -3237,12 +3271,15 @@ struct Solver {
                         accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
                         break;
                     }
-                    if (ls == 0 && okt && T.theta >= theta) { general = true; break; }      /* second-order correction: general path */
+                    /* second-order correction (W&B section 2.4): the follow-up kernel's general iteration.  (Round 4 tried it in here, as a cold
+                     * block made of the general iteration's pieces: same iterates as the oracle, but the block's register demand reaches into the
+                     * loop's allocation -- 594 instead of 256 spilled registers, 779 k instead of 1 044 k solves/s on config 1; profiles/r04) */
+                    if (ls == 0 && okt && T.theta >= theta) { general = true; break; }
                     alpha *= 0.5; n_back++;
                     if (alpha < amin) break;
                 }
-                if (general) { status = STATUS_GENERAL; break; }
-                if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; break; }      /* (the general iteration has the restoration phase) */
+                if (general) { status = STATUS_GENERAL; why_general = 3; break; }
+                if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; why_general = 4; break; }      /* (the general iteration has the restoration phase) */
                 alpha_pr = alpha;
                 c.mark(PH_MERIT); phase_fence(PH_MERIT);
                 if (!ftype_armijo && nfilt < FILT_CAP) {      /* filter augmentation (W&B eq. (22)) */
@@ -3536,7 +3573,7 @@ struct Solver {
 };
 
 /* the restoration phase as a function of its own: its code and its registers stay out of the iteration's */
-template <int NT, int SPT, int DYN, bool GEN, bool FULL>
+template <int NT, int SPT, int DYN, bool GEN, int FULL>
 __device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, Uni *U, const double *scen, double *hist, int hist_cap)
 {
     Solver<NT, SPT, DYN, true, GEN, FULL> r(*P, c, work, *U);
@@ -3557,13 +3594,22 @@ __device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, U
  * grid = min(nscen, resident workgroups); block = NT threads (multiple of 64), NT*SPT >= N + 1.
  * Dynamic LDS: lds_doubles(N, NT*SPT) * 8 bytes.  work: gridDim.x * work_doubles(NT*SPT) doubles of device memory, private to
  * the workgroups (the part of the iterate that does not stay in registers between the phases).  WPS = minimum waves per SIMD the register budget is planned for.
+ *
+ * PART -- a solve as one launch or as two (round 4):
+ *   0  everything in one kernel: fused iteration (FAST kernels), general iteration, restoration phase, second attempt
+ *   1  the first pass: the fused iteration alone (FAST kernels; otherwise the general iteration without the restoration phase).  A scenario
+ *      that needs anything else -- no fused start for it, a rare event that asks for the general iteration, a breakdown -- is appended to the
+ *      list P.follow and left to the follow-up kernel; the code and the registers of the cold paths stay out of this kernel's code object
+ *   2  the follow-up: general iteration + restoration phase + second attempt, for the scenarios of the list (P.follow) or, without a
+ *      list, for the whole batch (launches none of whose scenarios can start fused: the reference's starting point, a primal-only warm start)
  */
-template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
+template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     constexpr int NS = NT*SPT;     /* node slots */
+    if ((PART == 2 || PART == 0) && P.follow && P.follow[0] == 0) return;      /* nothing listed (the usual case): the list header is clear already */
     Ctx c;
     c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.nt = NT; c.red_slot = 0;
     double *wg_work = work + (STREAM ? stream_doubles(P.N, NS, DYN) : work_doubles(NS))*blockIdx.x;
@@ -3579,7 +3625,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     }
     c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
-    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL>;
+    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL, PART>;
     constexpr bool FASTK = SolverT::FAST;
     c.xs = c.o4 = c.o5 = c.o6 = c.o7 = nullptr;
     if (FASTK) { c.xs = c.o3 + NS; c.o4 = c.xs + NS; c.o5 = c.o4 + NS; c.o6 = c.o5 + NS; c.o7 = c.o6 + NS; }
@@ -3595,10 +3641,21 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     /* scenarios are pulled from a device-wide counter (zeroed by the launch code): solves differ in their iteration counts, and a
      * workgroup that finishes early takes the next scenario instead of idling behind a static stride (matters once the batch is
      * several times the resident workgroups: configs 2-4).  queue == null: static stride. */
-    constexpr int MISC_NEXT = 25;
+    constexpr int MISC_NEXT = 25, MISC_SPENT = 26;
+    const bool listed = (PART == 2 || PART == 0) && P.follow != nullptr;      /* the follow-up kernel works off the list of the first pass (any complete kernel can be launched on a list: msd_mpc.hip) */
     for (int turn = 0;; turn++) {
-        int sidx;
-        if (P.queue) {
+        int sidx, spent0 = -1;
+        if (listed) {
+            __syncthreads();
+            if (c.tid == 0) {
+                const int k = atomicAdd(P.follow + 1, 1);
+                const bool have = k < P.follow[0];      /* (complete: the first pass has ended) */
+                c.misc[MISC_NEXT] = have ? (double)P.follow[FOLLOW_HDR + 2*k] : (double)nscen;
+                c.misc[MISC_SPENT] = have ? (double)P.follow[FOLLOW_HDR + 2*k + 1] : -1.0;
+            }
+            __syncthreads();
+            sidx = wg_uniform((int)c.misc[MISC_NEXT]); spent0 = wg_uniform((int)c.misc[MISC_SPENT]);
+        } else if (P.queue) {
             __syncthreads();
             if (c.tid == 0) c.misc[MISC_NEXT] = (double)atomicAdd(P.queue, 1);
             __syncthreads();
@@ -3621,20 +3678,52 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         if (guess && P.guessStatus && P.guessStatus[(size_t)MSD_ST_COUNT*sidx + MSD_ST_STATUS] < 0) guess = nullptr;
         const double *dual_in = (guess && P.dualIn) ? P.dualIn + (size_t)P.dualInStride*sidx + (size_t)MSD_DUAL_STRIDE*P.dualShift : nullptr;
         double *dual_out = P.dualOut ? P.dualOut + (size_t)MSD_DUAL_STRIDE*(P.N + 1)*sidx : nullptr;
-        int startKind = P.start, spent = 0;
+        int startKind = P.start, spent = 0, attempt0 = 0;
+        if ((PART == 2 || PART == 0) && spent0 >= 0) {
+            /* the first pass broke down on this scenario: its second attempt */
+            attempt0 = 1; spent = spent0;
+            if (guess) guess = nullptr; else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;
+        }
         /* a solve that breaks down (not: runs out of iterations) is repeated from the other starting point */
 #pragma unroll 1
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = attempt0; attempt < 2; attempt++) {
             int iters = 0;
             int st = SolverT::STATUS_GENERAL;
-            if constexpr (FASTK) {
+            if constexpr (FASTK && PART != 2) {
                 /* the fused iteration needs no least-squares multiplier estimate: profile start or primal-dual warm start */
-                if ((guess && dual_in) || (!guess && startKind == MSD_START_PROFILE))
+                if (PART == 3 || (guess && dual_in) || (!guess && startKind == MSD_START_PROFILE))
                     st = s.template run<true>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
                                               lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
                                               (hist && sidx == 0) ? hist : nullptr, hist_cap);
                 __syncthreads();
             }
+            if constexpr (SolverT::FIRST && !FASTK) {
+                /* first pass of a family without a fused iteration: the general one without the restoration phase */
+                st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                           lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
+                                           (hist && sidx == 0) ? hist : nullptr, hist_cap);
+                __syncthreads();
+            }
+            if constexpr (SolverT::FIRST) {
+                /* done (solved, or out of iterations: no second attempt for that) -- or the follow-up kernel's: the general iteration from the same
+                 * starting point (also a line search that broke down where the follow-up kernel has the restoration phase).  A breakdown is
+                 * repeated here, from the other starting point, like in the kernels that hold everything */
+                if (st >= 0 || st == MSD_STATUS_INFEASIBLE || st == MSD_STATUS_MAXITER) break;
+                const bool again = st == SolverT::STATUS_GENERAL || (SolverT::FAMILY_HAS_RESTO && st == MSD_STATUS_LINESEARCH && P.resto);
+                if (again) {
+                    if (c.tid == 0) {
+                        const int k = atomicAdd(P.follow, 1);
+                        P.follow[FOLLOW_HDR + 2*k] = sidx; P.follow[FOLLOW_HDR + 2*k + 1] = attempt == 0 ? -1 : spent;
+                        atomicAdd(P.follow + FOLLOW_TOTAL, 1);
+                        atomicAdd(P.follow + FOLLOW_WHY + (st == SolverT::STATUS_GENERAL ? s.why_general : 4), 1);
+                    }
+                    break;
+                }
+                if (attempt == 0 && c.tid == 0) atomicAdd(P.follow + FOLLOW_WHY + 5, 1);      /* (telemetry: second attempts made here) */
+                spent = iters;
+                if (guess) guess = nullptr;
+                else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;
+            } else {
             if (st == SolverT::STATUS_GENERAL) {
                 /* one call site: a scenario whose line search broke down comes back with STATUS_RESTO, goes through the restoration phase and is
                  * resumed -- with the status the phase ended the solve with, if it did */
@@ -3660,6 +3749,15 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             spent = iters;
             if (guess) guess = nullptr;      /* a warm start that breaks down: once more from the problem's own starting point */
             else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;
+            }
+        }
+    }
+    if (listed) {
+        /* the last workgroup to find the list empty clears it for the next launch of the handle (launches of a handle are ordered on its stream) */
+        __syncthreads();
+        if (c.tid == 0) {
+            __threadfence();
+            if (atomicAdd(P.follow + 2, 1) == (int)gridDim.x - 1) { P.follow[0] = 0; P.follow[1] = 0; P.follow[2] = 0; __threadfence(); }
         }
     }
 }

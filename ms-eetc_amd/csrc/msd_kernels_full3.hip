@@ -1,0 +1,17 @@
+/* follow-up kernels of the split solves of msd_kernels_full.hip (solve_kernel's PART = 2): general iteration, restoration phase and second
+ * attempt for the scenarios the first pass hands over -- or for the whole batch when none of its scenarios can start with the fused iteration */
+#include <hip/hip_runtime.h>
+
+#include "msd_geometry.hpp"
+
+namespace msd {
+KernelFn follow_kernel_full(int NT, int SPT)
+{
+    if (NT == 64 && SPT == 1) return solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 2>;
+    if (NT == 64 && SPT == 2) return solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 2>;
+    if (NT == 128 && SPT == 2) return solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 2>;
+    if (NT == 192 && SPT == 2) return solve_kernel<192, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 2>;
+    if (NT == 256 && SPT == 2) return solve_kernel<256, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 2>;
+    return nullptr;
+}
+}

@@ -1,0 +1,29 @@
+/* solve-kernel instantiations with the structure of the reference's scripts compiled in (FULL_RG: regenerative brake only -- forceMinPn = 0,
+ * figure5.py:88, figure6.py:108, figure10.py:17, table3.py:18 --, power rows, energy objective, constant efficiencies); see msd_kernels_full.hip.
+ * These solves are split launches (solve_kernel: PART): this unit holds the first-pass kernels -- the fused iteration alone --,
+ * msd_kernels_rg2.hip the follow-up kernels (general iteration, restoration phase, second attempt). */
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "msd_geometry.hpp"
+
+namespace msd {
+/* the pickers below hand out XCH_FAST exchange arrays (and no reduction scratch for a single wave): the layout of a kernel whose Solver::FAST holds */
+static_assert(Solver<64, 2, LOSS_STATIC, false, false, FULL_RG, 1>::FAST && Solver<256, 2, LOSS_STATIC, false, false, FULL_RG, 3>::FAST, "the tuning switches of this build (MSD_MEM_*, MSD_PARALLEL_RICCATI) leave no fused iteration: pick_geometry_full would size the LDS wrongly");
+Geometry pick_geometry_full_rg(int N)
+{
+    const int nodes = N + 1;
+    const char *nf = getenv("MSD_NO_FULL");      /* MSD_NO_FULL=1: the general kernels (A/B runs) */
+    if (nf && *nf == '1') return {0, 0, nullptr};
+    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
+    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};     /* the benchmark geometry */
+    if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, RED_DOUBLES, follow_kernel_full_rg(128, 2), solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
+    /* longer horizons while the five additional exchange arrays still fit the LDS of a compute unit next to the stage blocks */
+    const auto fits = [&](int ns) { return sizeof(double)*(size_t)lds_doubles(N, ns, false, XCH_FAST, RED_DOUBLES) <= 160*1024; };
+    if (nodes <= 384 && fits(384)) return {192, 2, solve_kernel<192, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, RED_DOUBLES, follow_kernel_full_rg(192, 2), solve_kernel<192, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
+    if (nodes <= 512 && fits(512)) return {256, 2, solve_kernel<256, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, RED_DOUBLES, follow_kernel_full_rg(256, 2), solve_kernel<256, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
+    return {0, 0, nullptr};
+}
+}

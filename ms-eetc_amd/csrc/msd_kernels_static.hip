@@ -7,9 +7,9 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_geometry_static(int N, bool full)
+Geometry pick_geometry_static(int N, int full)
 {
-    if (full) { const Geometry g = pick_geometry_full(N); if (g.fn) return g; }
+    if (full) { const Geometry g = (full == FULL_RG) ? pick_geometry_full_rg(N) : pick_geometry_full(N); if (g.fn) return g; }
     return pick_geometry_t<LOSS_STATIC>(N);
 }
 }

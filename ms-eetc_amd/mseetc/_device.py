@@ -49,6 +49,18 @@ class ProblemDesc(ctypes.Structure):
                 ('loss_table', _dptr), ('loss_table_len', ctypes.c_int), ('reserved_tail', ctypes.c_int), ('coll_tables', _dptr)]
 
 
+class MpcPlan(ctypes.Structure):
+    "struct msd_mpc_plan (include/mseetc_mpc.h)"
+
+    _fields_ = [('num_resolves', ctypes.c_int), ('stride', ctypes.c_int), ('problems', ctypes.POINTER(ProblemDesc)), ('twins', ctypes.POINTER(ProblemDesc)),
+                ('vlim_first', _dptr), ('length', _dptr), ('tail', ctypes.POINTER(ctypes.c_ubyte)), ('vmin', ctypes.c_double), ('vmax_train', ctypes.c_double),
+                ('terminal_velocity', ctypes.c_double), ('warm_start', ctypes.c_int), ('warm_mu', ctypes.c_double), ('warm_push', ctypes.c_double),
+                ('noise', ctypes.c_double), ('relax_infeasible', ctypes.c_int), ('late_margin', ctypes.c_double)]
+
+
+MPC = dict(T0=0, V0=1, T=2, STATUS=3, ITERS=4, OBJ=5, RELAXED=6, COUNT=7)      # MSD_MPC_*
+
+
 class DeviceError(RuntimeError):
     pass
 
@@ -92,6 +104,7 @@ def lib():
         L.msd_solve_batch_device_ex.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
         L.msd_problem_geometry.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.msd_synchronize.argtypes = [vp]
+        L.msd_problem_follow_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
         L.msd_device_free.argtypes = [vp, vp]
         L.msd_copy_to_device.argtypes = [vp, vp, vp, ctypes.c_ulonglong]
@@ -105,6 +118,11 @@ def lib():
                                      ctypes.c_double, ctypes.c_double, _dptr, _dptr]
         L.msd_integrate_losses.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, ctypes.c_int,
                                            _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr]
+
+        L.msd_mpc_create.argtypes = [vp, vp, ctypes.POINTER(MpcPlan), ctypes.POINTER(vp)]
+        L.msd_mpc_destroy.argtypes = [vp]
+        L.msd_mpc_run.argtypes = [vp, ctypes.c_int, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
+        L.msd_mpc_nz.argtypes = [vp, ctypes.c_int]
 
         _lib = L
 
@@ -308,6 +326,12 @@ class DeviceProblem():
     def synchronize(self):
         _check(lib().msd_synchronize(self._h))
 
+    def follow_counts(self):
+        "Scenarios the first-pass kernel handed to the follow-up kernel so far: (total, by reason[6]) -- msd_problem_follow_counts."
+        out = (ctypes.c_int*7)()
+        _check(lib().msd_problem_follow_counts(self._h, out, 7))
+        return int(out[0]), [int(v) for v in out[1:]]
+
     def timer_begin(self):
         _check(lib().msd_timer_begin(self._h))
 
@@ -407,3 +431,65 @@ def integrate_losses(model, lossKind, ct, cr, lossTable, forceEl, forcePn, dts, 
                                            len(tab) if tab is not None else 0, _d(forceEl), _d(forcePn), _d(dts), _d(_c(grad)), _d(_c(curv)), _d(vstart),
                                            float(abstol), float(reltol), _d(etr), _d(ebr)))
     return etr, ebr
+
+
+class DeviceLoop():
+    """
+    Owner of an msd_mpc_handle: the shrinking-horizon loop with its bookkeeping on the device (include/mseetc_mpc.h).  `problem` / `twin`:
+    DeviceProblem of the first re-solve's energy problem / time-optimal twin (twin and twinDescs None: failed re-solves are left as they are).
+    """
+
+    def __init__(self, problem, twin, descs, twinDescs, stride, vlimFirst, lengths, tail, vmin, vmaxTrain, terminalVelocity, warmStart, warmMu, warmPush,
+                 noise, relaxInfeasible, lateMargin):
+
+        K = len(descs)
+        self.K, self.problem, self.twin = K, problem, twin
+        self._descs = (ProblemDesc*K)(*descs)
+        self._twins = (ProblemDesc*K)(*twinDescs) if twinDescs is not None else None
+        self._keep = [descs, twinDescs, np.ascontiguousarray(vlimFirst, dtype=np.float64), np.ascontiguousarray(lengths, dtype=np.float64),
+                      np.ascontiguousarray(tail, dtype=np.uint8)]
+        plan = MpcPlan()
+        plan.num_resolves, plan.stride = K, int(stride)
+        plan.problems = ctypes.cast(self._descs, ctypes.POINTER(ProblemDesc))
+        plan.twins = ctypes.cast(self._twins, ctypes.POINTER(ProblemDesc)) if self._twins is not None else None
+        plan.vlim_first, plan.length = _d(self._keep[2]), _d(self._keep[3])
+        plan.tail = self._keep[4].ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
+        plan.vmin, plan.vmax_train, plan.terminal_velocity = float(vmin), float(vmaxTrain), float(terminalVelocity)
+        plan.warm_start, plan.warm_mu, plan.warm_push = int(bool(warmStart)), float(warmMu), float(warmPush)
+        plan.noise, plan.relax_infeasible, plan.late_margin = float(noise), int(bool(relaxInfeasible)), float(lateMargin)
+        self._m = ctypes.c_void_p()
+        _check(lib().msd_mpc_create(problem._h, twin._h if twin is not None else None, ctypes.byref(plan), ctypes.byref(self._m)))
+        self.nz = [lib().msd_mpc_nz(self._m, k) for k in range(K)]
+
+    def run(self, T, initialTime, initialVelocity, n1, n2, keepZ=True):
+        "One loop over the scenarios with arrival times T.  Returns (log (K, B, MPC['COUNT']), list of z (B, nz_k) or None, device ms of the loop)."
+
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        B = T.shape[0]
+        n1 = np.ascontiguousarray(n1, dtype=np.float64) if n1 is not None else None
+        n2 = np.ascontiguousarray(n2, dtype=np.float64) if n2 is not None else None
+        if self.K > 1 and n1 is not None and (n1.shape != (self.K - 1, B) or n2.shape != (self.K - 1, B)):
+            raise ValueError("noise draws must have shape ({}, {})".format(self.K - 1, B))
+        log = np.zeros((self.K, B, MPC['COUNT']))
+        zflat = np.zeros(B*sum(self.nz)) if keepZ else None
+        ms = ctypes.c_float(0)
+        _check(lib().msd_mpc_run(self._m, B, _d(T), float(initialTime), float(initialVelocity), _d(n1) if n1 is not None else None,
+                                 _d(n2) if n2 is not None else None, _d(log), _d(zflat) if keepZ else None, ctypes.byref(ms)))
+        zs = None
+        if keepZ:
+            zs, off = [], 0
+            for nz in self.nz:
+                zs.append(zflat[off:off + B*nz].reshape(B, nz)); off += B*nz
+        return log, zs, float(ms.value)
+
+    def close(self):
+
+        if getattr(self, '_m', None):
+            lib().msd_mpc_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -15,7 +15,7 @@
 #include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
 
 
-template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, bool FULL = false>
+template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0>
 void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
@@ -30,7 +30,7 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL, PART>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -41,7 +41,7 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
 /* family dispatchers (emu_k_*.cpp): false when the family has no instantiation for (NT, SPT) */
 struct EmuArgs { msd::DevProb P; int nscen; const double *scen, *ovr; double *z, *lam, *stats, *hist; int cap; };
 bool emu_run_static(int NT, int SPT, const EmuArgs &a);
-bool emu_run_full(int NT, int SPT, const EmuArgs &a);
+bool emu_run_full(int NT, int SPT, const EmuArgs &a, int kind);      /* kind: msd::FULL_BOTH or msd::FULL_RG */
 bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general(int NT, int SPT, const EmuArgs &a);
 bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);

@@ -29,7 +29,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
                                    double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
-    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
+    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
     std::vector<double> pos(d->num_intervals + 1, 0.0);
     for (int i = 0; i < d->num_intervals; i++) pos[i + 1] = pos[i] + d->ds[i];
     P.pos = pos.data();
@@ -68,7 +68,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     if (NT*SPT < nodes) return -3;
     /* the kernels with the structure of the NLP compiled in (msd_kernels_full.hip), chosen like msd_api.hip does; EMU_NO_FULL=1: the general ones */
     const char *nofull = getenv("EMU_NO_FULL");
-    const bool full = !dyn && P.withPn && P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && !(nofull && *nofull == '1');
-    if (full && emu_run_full(NT, SPT, a)) return 0;
+    const bool full = !dyn && P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nofull && *nofull == '1');
+    if (full && emu_run_full(NT, SPT, a, P.withPn ? msd::FULL_BOTH : msd::FULL_RG)) return 0;
     return (dyn ? emu_run_dynamic(NT, SPT, a) : emu_run_static(NT, SPT, a)) ? 0 : -3;
 }

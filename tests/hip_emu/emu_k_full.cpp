@@ -1,10 +1,28 @@
 /* TEST-ONLY: host emulation, kernel family "full" (see emu_common.h) */
 #include "emu_common.h"
 
-bool emu_run_full(int NT, int SPT, const EmuArgs &a)
+/* split solves like msd_api.hip launches them: the first pass (fused iteration only), then the follow-up kernel over the list it left
+ * (EMU_MONOLITHIC=1: the kernel with everything in it) */
+template <int NT, int SPT, int KIND> static void run_split(EmuArgs a)
 {
-    if (NT == 64 && SPT == 1) { EMU_CALL(64, 1, false, false, false, true); return true; }
-    if (NT == 64 && SPT == 2) { EMU_CALL(64, 2, false, false, false, true); return true; }
-    if (NT == 128 && SPT == 2) { EMU_CALL(128, 2, false, false, false, true); return true; }
+    std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
+    a.P.follow = follow.data();
+    const bool plain = a.P.guess ? a.P.dualIn != nullptr : a.P.start == MSD_START_PROFILE;      /* like msd_api.hip: launch() */
+    if (plain) EMU_CALL(NT, SPT, false, false, false, KIND, 1); else EMU_CALL(NT, SPT, false, false, false, KIND, 3);
+    EMU_CALL(NT, SPT, false, false, false, KIND, 2);
+}
+
+template <int KIND> static bool run_kind(int NT, int SPT, const EmuArgs &a)
+{
+    const char *mono = getenv("EMU_MONOLITHIC");
+    const bool split = !(mono && *mono == '1');
+    if (NT == 64 && SPT == 1) { if (split) run_split<64, 1, KIND>(a); else EMU_CALL(64, 1, false, false, false, KIND); return true; }
+    if (NT == 64 && SPT == 2) { if (split) run_split<64, 2, KIND>(a); else EMU_CALL(64, 2, false, false, false, KIND); return true; }
+    if (NT == 128 && SPT == 2 && KIND == msd::FULL_BOTH) { if (split) run_split<128, 2, KIND>(a); else EMU_CALL(128, 2, false, false, false, KIND); return true; }
     return false;
+}
+
+bool emu_run_full(int NT, int SPT, const EmuArgs &a, int kind)
+{
+    return kind == msd::FULL_RG ? run_kind<msd::FULL_RG>(NT, SPT, a) : run_kind<msd::FULL_BOTH>(NT, SPT, a);
 }

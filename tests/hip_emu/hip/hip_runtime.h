@@ -63,6 +63,7 @@ static inline void emu_wave_fetch(const double *x, double *y, int K, int src)
 
 /* the blocks of an emulated launch run one after the other: a plain read-modify-write is atomic enough */
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 using std::isfinite;
 

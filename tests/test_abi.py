@@ -24,9 +24,9 @@ def built():
 
 
 def test_library_exports_every_declared_symbol(built):
-    header = (ROOT / 'include' / 'mseetc_hip.h').read_text()
+    header = (ROOT / 'include' / 'mseetc_hip.h').read_text() + (ROOT / 'include' / 'mseetc_mpc.h').read_text()
     names = set(re.findall(r'\b(msd_[a-z_]+)\s*\(', header))
-    assert len(names) >= 15
+    assert len(names) >= 19 and {'msd_mpc_create', 'msd_mpc_run', 'msd_mpc_destroy', 'msd_mpc_nz', 'msd_problem_follow_counts'} <= names
     lib = ctypes.CDLL(str(built))
     for n in sorted(names):
         assert hasattr(lib, n), n
@@ -47,6 +47,24 @@ def test_desc_struct_matches_header(built, tmp_path):
     out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert out[0] == ctypes.sizeof(ProblemDesc)
     assert out[1:] == [getattr(ProblemDesc, f).offset for f in fields]
+
+
+def test_mpc_plan_struct_matches_header(built, tmp_path):
+    "the ctypes mirror of msd_mpc_plan (include/mseetc_mpc.h) against the C compiler's layout, and the log's column indices"
+    from mseetc._device import MpcPlan, MPC
+    fields = [f[0] for f in MpcPlan._fields_]
+    src = tmp_path / 'layout_mpc.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mseetc_mpc.h"\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(msd_mpc_plan));\n'
+                   + ''.join('  printf("%zu\\n", offsetof(msd_mpc_plan, {}));\n'.format(f) for f in fields)
+                   + '  printf("%d %d %d %d %d %d %d %d\\n", MSD_MPC_T0, MSD_MPC_V0, MSD_MPC_T, MSD_MPC_STATUS, MSD_MPC_ITERS, MSD_MPC_OBJ, MSD_MPC_RELAXED, MSD_MPC_COUNT);\n  return 0;\n}\n')
+    exe = tmp_path / 'layout_mpc'
+    subprocess.run(['gcc', '-I', str(ROOT / 'include'), '-o', str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    n = len(fields)
+    assert out[0] == ctypes.sizeof(MpcPlan)
+    assert out[1:1 + n] == [getattr(MpcPlan, f).offset for f in fields]
+    assert out[1 + n:] == [MPC[k] for k in ('T0', 'V0', 'T', 'STATUS', 'ITERS', 'OBJ', 'RELAXED', 'COUNT')]
 
 
 def test_no_device_fails_loudly(built):

@@ -1088,3 +1088,126 @@ def test_edge_cases_sizes_and_errors():
     few = casadiSolver(train, track, dict(numIntervals=100, maxIterations=5, integrationOptions=dict(numApproxSteps=1)))
     r = few.solveBatch([1541.0])
     assert r['status'][0] == -1 and r['iterations'][0] == 5
+
+
+def test_second_order_corrections_go_through_the_follow_up_kernel():
+    """
+    Round 4: the first-pass kernels hold the fused iteration alone; a rejected first trial point that qualifies for a second-order
+    correction (W&B section 2.4) hands the scenario to the follow-up kernel, whose general iteration has the correction.  N = 40 on 16 km
+    from the profile start: a quarter of these running times take one correction (oracle: N_SOC = 1).  Same iterates as the oracle --
+    iteration counts, number of corrections, optimum -- and the telemetry counts exactly those scenarios (reason 3).
+    """
+    from oracle import oracle
+    from mseetc._device import ST
+    train, track = cases.train_default(), cases.track_00(16000)
+    s = _solver(train, track, 40, start='profile')
+    prob = cases.oracle_problem(train, track, 40)
+    T = 640.0*(1.0 + 0.5*np.random.default_rng(5).random(256))
+    T[0], T[1] = 804.9041795334854, 762.6780418513658
+    t0, why0 = s.problem.follow_counts()
+    res = s.solveBatch(T)
+    t1, why1 = s.problem.follow_counts()
+    assert np.all(res['status'] == 0)
+    scen = np.stack([np.zeros_like(T), T, np.ones_like(T), np.ones_like(T)], axis=1)
+    z, st, nfail = oracle.solve_batch(prob, scen, nthreads=0, start='profile')
+    assert nfail == 0
+    nsoc = res['stats'][:, ST['N_SOC']]
+    assert nsoc[0] == 1 and nsoc[1] == 1 and nsoc.sum() >= 20
+    assert np.array_equal(nsoc, st[:, ST['N_SOC']])
+    assert t1 - t0 == why1[3] - why0[3] == int((nsoc > 0).sum())
+    assert np.max(np.abs(res['iterations'] - st[:, ST['ITERS']])) <= 2
+    assert np.max(np.abs(res['cost'] - st[:, ST['OBJ']])/np.abs(st[:, ST['OBJ']])) <= 1e-7
+    assert np.max(np.abs(res['z'] - z)/np.maximum(1.0, np.abs(z))) <= 1e-5
+    s.close()
+
+
+def test_split_launches_hand_rare_scenarios_to_the_follow_up_kernel():
+    """
+    The two launches of a split solve (first pass + follow-up kernel, msd_api.hip: launch): a batch mixing ordinary running times with
+    very loose ones -- whose line search breaks down on the way, so that they need the restoration phase, which only the follow-up
+    kernel holds -- comes back complete: the ordinary scenarios are bit-identical to a batch without the loose ones, the loose ones
+    converge through the restoration phase, and the telemetry counts exactly the scenarios that were handed over.
+    """
+    from mseetc._device import ST
+    train, track = cases.train_default(), cases.track_00()
+    s = _solver(train, track, 100, start='reference')
+    T = cases.c1_times(48)
+    loose = np.linspace(12000.0, 19000.0, 16)
+    alone = s.solveBatch(T)
+    t0, why0 = s.problem.follow_counts()
+    mixed = s.solveBatch(np.concatenate([T[:24], loose, T[24:]]))
+    t1, why1 = s.problem.follow_counts()
+    assert np.all(mixed['status'] >= 0)
+    keep = np.r_[0:24, 40:64]
+    assert np.array_equal(mixed['z'][keep], alone['z']) and np.array_equal(mixed['iterations'][keep], alone['iterations'])
+    nresto = mixed['stats'][24:40, ST['N_RESTO']]
+    assert nresto.sum() >= 8                                      # most of the loose schedules go through at least one restoration phase
+    assert t1 - t0 >= int((nresto > 0).sum())                     # ... and every one of those went through the list
+    assert sum(why1[:5]) - sum(why0[:5]) == t1 - t0               # (every hand-over has its reason: tiny step, rejected trial point, line search ...)
+    s.close()
+
+
+def test_one_brake_kernels_vs_oracle():
+    """
+    The configuration of the reference's scripts (forceMinPn = 0: figure5.py:88, figure6.py:108, figure10.py:17, table3.py:18) runs on
+    kernels with that structure compiled in (FULL_RG: split launches with the fused iteration, like the rolling stock of the JSON files).
+    Against the oracle from both starting points on three launch geometries; the N = 300 optimum is the one that extrapolates to GPOPS-II.
+    """
+    train = cases.train_fig10()
+    for N, crop, T in ((40, 16000, [700.0, 760.0]), (100, None, [1541.0, 1600.0, 1700.0]), (300, None, [1541.0])):
+        track = cases.track_00(crop) if crop else cases.track_00()
+        prob = cases.oracle_problem(train, track, N)
+        for start in ('profile', 'reference'):
+            s = _solver(train, track, N, start=start)
+            assert not s.withPnBrake
+            res = _compare(s, prob, T)
+            if N == 300:
+                assert abs(res['cost'][0] - 441.0838) < 2e-3
+            s.close()
+
+
+def test_device_resident_shrinking_horizon_loop_vs_host_loop():
+    """
+    BASELINE config 4 with the loop's bookkeeping on the device (csrc/msd_mpc.hip: measured states, scenario records, warm starts, moved
+    arrival times and the log as kernels between the solver's launches) against the host loop of mseetc/mpc.py, 128 scenarios x 50
+    re-solves with 1 % noise.  Cold starts: the two loops launch the same kernels on the same records -- equal to the last bits (the device's
+    square root of the measured v^2 differs from numpy's in the last place now and then) until the first arrival time has to move (the device
+    repeats such a scenario with the follow-up kernel's iteration, the host with another first-pass launch: same optimum, other rounding).  Warm starts: the same closed loop to the tolerances of
+    test_config4_full_size_warm_and_cold.  Every re-solve ends with a solution in both.
+    """
+    from mseetc import workloads as wl
+    from mseetc.mpc import shrinkingHorizon, DeviceLoop
+    train, track, N = wl.config('c4')
+    T = wl.c1_times(128, seed=20260615)
+    for warm in (False, True):
+        host = shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=warm)
+        loop = DeviceLoop(train, track, wl.options(N), 50, noise=0.01, warmStart=warm)
+        dev = loop.run(T, seed=1)
+        again = loop.run(T, seed=1, keepZ=False)      # the loop object is reusable; same inputs, same log
+        loop.close()
+        assert len(host) == len(dev) == 50
+        moved = np.zeros(128, dtype=bool)
+        first_move = None
+        for k, (h, d, a) in enumerate(zip(host, dev, again)):
+            assert h['numIntervals'] == d['numIntervals'] == N - 2*k and abs(h['position'] - d['position']) < 1e-9
+            assert (h['status'] < 0).sum() <= (0 if k < 48 else 4) and (d['status'] < 0).sum() <= (0 if k < 48 else 4), (k, h['status'].min(), d['status'].min())
+            assert np.array_equal(d['status'], a['status']) and np.array_equal(d['t0'], a['t0']) and np.array_equal(d['cost'], a['cost']) and a['z'] is None
+            if first_move is None and (h['relaxed'].any() or d['relaxed'].any()):
+                first_move = k
+            if not warm and first_move is None:
+                assert np.array_equal(h['status'], d['status']) and np.max(np.abs(h['iterations'] - d['iterations'])) <= 1, k
+                for key, tol in (('t0', 1e-12), ('v0', 1e-12), ('T', 0.0), ('cost', 1e-9), ('z', 1e-7)):
+                    assert np.allclose(h[key], d[key], rtol=tol, atol=tol), (k, key)
+            moved |= h['relaxed'] | d['relaxed']
+            same = ~moved
+            assert np.allclose(h['t0'][same], d['t0'][same], rtol=1e-6, atol=1e-6), k
+            assert np.allclose(h['v0'][same], d['v0'][same], rtol=1e-5), k
+            assert np.allclose(h['cost'][same], d['cost'][same], rtol=1e-5 if k < 30 else 5e-3, atol=1e-5), k
+            for log in (h, d):
+                m = log['relaxed']
+                if m.any():
+                    assert np.all(log['T'][m] > T[m]) and np.all(log['T'][m] - T[m] < 0.08*T[m])
+        # arrival times move late in the journey, in both loops, for (nearly) the same scenarios
+        assert first_move is None or first_move >= 20
+        hm = np.any([h['relaxed'] for h in host], axis=0); dm = np.any([d['relaxed'] for d in dev], axis=0)
+        assert (hm != dm).sum() <= 2

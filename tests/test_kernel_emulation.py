@@ -44,7 +44,9 @@ def emu():
     return load_emulation()
 
 
-@pytest.mark.parametrize('N,crop,T,start', [(30, 12000, 520.0, 'reference'), (70, 30000, 1100.0, 'reference'), (70, 30000, 1100.0, 'profile')])
+@pytest.mark.parametrize('N,crop,T,start', [(30, 12000, 520.0, 'reference'), (70, 30000, 1100.0, 'reference'), (70, 30000, 1100.0, 'profile'),
+                                            # two solves with a second-order correction on the way (oracle: N_SOC = 1): the cold block inside the fused iteration
+                                            (40, 16000, 804.9041795334854, 'profile'), (60, 30000, 1140.8291957305269, 'profile')])
 def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
@@ -60,9 +62,35 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     ref = oracle.solve(prob, prob.scenario(T), start=start)
     assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert int(st[0, ST['N_SOC']]) == int(ref['stats']['N_SOC']) == (1 if T in (804.9041795334854, 1140.8291957305269) else 0)
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
     # the multipliers of a converged solve are determined to the solver tolerance (1e-8 on the scaled problem): relative bound
     assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
+
+
+@pytest.mark.parametrize('N,start', [(70, 'profile'), (70, 'reference'), (40, 'profile')])
+def test_emulated_one_brake_kernels_match_oracle(emu, N, start):
+    """
+    The kernels with the structure of the reference's scripts compiled in (FULL_RG: forceMinPn = 0, figure10.py:17): first pass (fused
+    iteration, behind the least-squares multiplier estimate when the start is the reference's) + follow-up kernel, as host threads.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train, track = cases.train_fig10(), cases.track_00(30000)
+    T = 1100.0
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint=start)
+    assert not solver.withPnBrake
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = 4*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(prob, prob.scenario(T), start=start)
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert abs(int(st[0, ST['ITERS']]) - int(ref['stats']['ITERS'])) <= 1
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
 
 
 @pytest.mark.parametrize('N,variant', [(300, 'fig10'), (300, 'both'), (530, 'fig10')])
