@@ -173,7 +173,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
 }
 
 int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follow, int *d_queue, int nscen, const double *d_scen, const double *d_ovr,
-                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list)
+                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list, hipEvent_t first_begin, hipEvent_t first_end)
 {
     if (!pl.kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
     msd::DevProb P = pl.P;
@@ -208,8 +208,10 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         P.queue = d_queue;
         HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), stream));
     }
+    if (first_begin) HIP_TRY(hipEventRecord(first_begin, stream));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
     HIP_TRY(hipGetLastError());
+    if (first_end) HIP_TRY(hipEventRecord(first_end, stream));
     if (first_pass) {
         /* the follow-up kernel: usually nothing to do (0 of the 1024 + 8192 benchmark scenarios of configs 1 and 2) -- a workgroup that finds
          * the list empty returns at once, the others take scenarios off it until it is empty */
@@ -354,6 +356,7 @@ int msd_problem_destroy(msd_handle h)
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess); hipFree(h->d_eval);
     hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
     if (h->h_stage) hipHostFree(h->h_stage);
+    for (int k = 0; k < msd_problem::FP_RING; k++) { if (h->fp_beg[k]) hipEventDestroy(h->fp_beg[k]); if (h->fp_end[k]) hipEventDestroy(h->fp_end[k]); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -397,7 +400,14 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
     if (!h->d_queue) HIP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)*QUEUE_RING));
     int *queue = h->d_queue + h->queue_slot;
     h->queue_slot = (h->queue_slot + 1) % QUEUE_RING;
-    return msd_host::launch_plan(plan_of(h), h->stream, h->d_work, h->d_follow, queue, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, ws);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->time_first_pass) {
+        const int k = (int)(h->fp_count % msd_problem::FP_RING);
+        if (!h->fp_beg[k]) { HIP_TRY(hipEventCreate(&h->fp_beg[k])); HIP_TRY(hipEventCreate(&h->fp_end[k])); }
+        e0 = h->fp_beg[k]; e1 = h->fp_end[k];
+        h->fp_count++;
+    }
+    return msd_host::launch_plan(plan_of(h), h->stream, h->d_work, h->d_follow, queue, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, ws, nullptr, e0, e1);
 }
 
 int msd_solve_batch_device(msd_handle h, int nscen, const double *d_scen, double *d_z, double *d_lam, double *d_stats)
@@ -427,6 +437,25 @@ int msd_problem_follow_counts(msd_handle h, int *counts, int n)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->d_follow) HIP_TRY(hipMemcpy(counts, h->d_follow + msd::FOLLOW_TOTAL, sizeof(int)*n, hipMemcpyDeviceToHost));
+    return MSD_OK;
+}
+
+int msd_problem_time_first_pass(msd_handle h, int on)
+{
+    if (!h) return fail(MSD_E_INVALID, "null handle");
+    h->time_first_pass = on != 0; h->fp_count = 0;
+    return MSD_OK;
+}
+
+int msd_problem_first_pass_ms(msd_handle h, float *mean_ms, int *launches)
+{
+    if (!h || !mean_ms || !launches) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int n = (int)std::min<long long>(h->fp_count, msd_problem::FP_RING);
+    double sum = 0;
+    for (int k = 0; k < n; k++) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, h->fp_beg[k], h->fp_end[k])); sum += ms; }
+    *mean_ms = n ? (float)(sum/n) : 0.0f; *launches = n;
     return MSD_OK;
 }
 

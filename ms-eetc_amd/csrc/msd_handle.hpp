@@ -9,6 +9,7 @@
 
 #include "msd_kernel.hpp"
 #include "msd_geometry.hpp"
+#include "../../include/mseetc_aux.h"
 
 namespace msd_host {
 
@@ -51,7 +52,8 @@ struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const 
  *              leaves the header zeroed
  */
 int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follow, int *d_queue, int nscen, const double *d_scen, const double *d_ovr,
-                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list = nullptr);
+                double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap, const WarmStart &ws, int *d_list = nullptr,
+                hipEvent_t first_begin = nullptr, hipEvent_t first_end = nullptr);      /* (events recorded around the first kernel of the launch) */
 
 }  // namespace msd_host
 
@@ -95,5 +97,11 @@ struct msd_problem {
     int cap_scen = 0, cap_guess = 0;
     double *h_hist = nullptr;
     int hist_cap = 0;
+    /* msd_problem_time_first_pass: events around the first kernel of the last launches (a ring), so that the dominant kernel's own duration can be
+     * reported next to the time of a whole launch (first pass + follow-up kernel) */
+    static constexpr int FP_RING = 64;
+    bool time_first_pass = false;
+    hipEvent_t fp_beg[FP_RING] = {}, fp_end[FP_RING] = {};
+    long long fp_count = 0;
 };
 

@@ -105,6 +105,8 @@ def lib():
         L.msd_problem_geometry.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.msd_synchronize.argtypes = [vp]
         L.msd_problem_follow_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.msd_problem_time_first_pass.argtypes = [vp, ctypes.c_int]
+        L.msd_problem_first_pass_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         L.msd_device_alloc.argtypes = [vp, ctypes.c_ulonglong, ctypes.POINTER(vp)]
         L.msd_device_free.argtypes = [vp, vp]
         L.msd_copy_to_device.argtypes = [vp, vp, vp, ctypes.c_ulonglong]
@@ -325,6 +327,16 @@ class DeviceProblem():
 
     def synchronize(self):
         _check(lib().msd_synchronize(self._h))
+
+    def time_first_pass(self, on=True):
+        "Record HIP events around the first kernel of every launch (msd_problem_time_first_pass)."
+        _check(lib().msd_problem_time_first_pass(self._h, int(bool(on))))
+
+    def first_pass_ms(self):
+        "(mean duration of the first kernel over the last launches [ms], launches averaged) -- msd_problem_first_pass_ms"
+        ms, n = ctypes.c_float(0), ctypes.c_int(0)
+        _check(lib().msd_problem_first_pass_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
 
     def follow_counts(self):
         "Scenarios the first-pass kernel handed to the follow-up kernel so far: (total, by reason[6]) -- msd_problem_follow_counts."

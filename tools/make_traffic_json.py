@@ -13,17 +13,37 @@ out = sys.argv[1]
 KEYS = dict(c1='c1', c1ref='c1/reference_start', c1b8192='c1/batch8192', c2='c2', c3='c3', intloss='c1/integrate_losses', irk='c1/irk_radau2', cvodes='c1/cvodes_tolerances')
 
 
-def mean_counter(d, counter):
-    vals = []
+def part_of(kernel_name):
+    "template argument PART of a solve kernel: 1 / 3 first pass of a split solve, 2 its follow-up kernel, 0 a kernel that holds everything"
+    import re
+    m = re.search(r'solve_kernel<([^>]*)>', kernel_name)
+    args = [a.strip() for a in m.group(1).split(',')] if m else []
+    return int(args[7]) if len(args) >= 8 else 0
+
+
+def mean_counter(d, counter, which='launch'):
+    """
+    Mean of a counter per launch of the solver: the first kernel of a launch (first pass, or the one kernel) plus -- which = 'launch' -- the
+    follow-up kernel of a split solve behind it.  which = 'first': the dominant kernel alone.  Returns (value, launches).
+    """
+    first, follow = [], []
     for f in glob.glob(os.path.join(out, d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'solve_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
-                vals.append(float(r['Counter_Value']))
-    return (sum(vals)/len(vals), len(vals)) if vals else (None, 0)
+                (follow if part_of(r['Kernel_Name']) == 2 and True else first).append(float(r['Counter_Value']))
+    if not first and follow:      # a launch that is the follow-up kernel's alone
+        first, follow = follow, []
+    if not first:
+        return None, 0
+    v = sum(first)/len(first)
+    if which == 'launch' and follow:
+        v += sum(follow)/len(first)
+    return v, len(first)
 
 
 rec = {"kernel_digest": entry.hip_digest(),
-       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (tools/profile_round.sh), means over the solve-kernel launches of a pass; "
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (tools/profile_round.sh), means per launch of the solver over a pass -- bytes: first-pass kernel + follow-up "
+                 "kernel of a split solve; issue statistics: the first-pass (dominant) kernel alone; "
                  "FETCH_SIZE as reported (the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams; this kernel's traffic is 8 B/lane "
                  "scratch and result stores, a width the guide calls uncalibrated; bytes_per_launch_with_fetch_doubled applies it anyway -- WRITE_SIZE dominates either way)",
        "workloads": {}}
@@ -39,7 +59,7 @@ for name, key in KEYS.items():
          "compulsory_bytes_per_launch": line['roofline']['compulsory_bytes_per_launch'],
          "stage_iterations_per_launch": line['roofline']['stage_iterations_per_launch']}
     # issue statistics of the same kernel from the SQ pass (units of four cycles per wave, summed over the waves of a launch)
-    sq = {k: mean_counter('pmc_sq_' + name, k)[0] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU')}
+    sq = {k: mean_counter('pmc_sq_' + name, k, 'first')[0] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU')}
     if all(v is not None for v in sq.values()):
         w["issue"] = {"valu_instructions_per_launch": sq['SQ_INSTS_VALU'], "lds_instructions_per_launch": sq['SQ_INSTS_LDS'], "salu_instructions_per_launch": sq['SQ_INSTS_SALU'],
                       "valu_instructions_per_stage_iteration": sq['SQ_INSTS_VALU']/w['stage_iterations_per_launch'],

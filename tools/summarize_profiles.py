@@ -17,12 +17,10 @@ for name, key in KEYS.items():
         line = json.loads([l for l in open(jf).read().splitlines() if l.startswith('{')][-1])
     except Exception:
         continue
-    row = None
-    for r in csv.DictReader(open(files[0])):
-        if 'solve_kernel' in r['Name']:
-            row = r
-    if row is None:
+    rows = [r for r in csv.DictReader(open(files[0])) if 'solve_kernel' in r['Name']]
+    if not rows:
         continue
+    row = max(rows, key=lambda r: float(r['TotalDurationNs']))      # the dominant kernel (first pass of a split solve); the follow-up kernel's row is in the csv
     w = tr["workloads"].get(key, {})
     its = line['config']['ip_iterations_mean']
     valu = w.get('issue', {}).get('valu_instructions_per_launch')
