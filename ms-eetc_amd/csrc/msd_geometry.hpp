@@ -54,6 +54,10 @@ template <int DYN> inline Geometry pick_geometry_t(int N)
 #endif
     if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, DYN>};
     if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, DYN>};
+    /* N = 512 ... 575 with static loss rows: three waves with three nodes per lane and the whole register file of a SIMD each -- the stage blocks and
+     * six exchange arrays of 576 slots still fit the LDS of a compute unit.  (Round 3 ran these horizons on five waves of two nodes per lane with
+     * half a register file each: 2 253 spilled registers, 25 ms per 1024 solves at N = 560 against 6.2 ms at N = 511.) */
+    if (DYN == LOSS_STATIC && nodes <= 576) return {192, 3, solve_kernel<192, 3, 1, DYN>};
     if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN>};
     return {0, 0, nullptr};
 }

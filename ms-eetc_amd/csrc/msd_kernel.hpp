@@ -911,24 +911,33 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
 {
     static_assert(DYN == LOSS_STATIC, "restoration phase: static loss rows");
     constexpr int S_STRIDE = stage_stride(DYN);
-    /* every array of the sweeps lives in `tmp` (work area), not on the stack: the stack of this cold function would size the scratch memory of
-     * every launch of the kernel (a launch whose scratch need exceeds the runtime's standing allocation pays for it: config 2 lost a third) */
-    double (*P)[3] = reinterpret_cast<double (*)[3]>(tmp + 198), *pv = tmp + 207;
-    double (*Pt)[3] = reinterpret_cast<double (*)[3]>(tmp + 210), *pt = tmp + 219, (*L)[3] = reinterpret_cast<double (*)[3]>(tmp + 222);
-    double (*K)[4] = reinterpret_cast<double (*)[4]>(tmp + 231), *h = tmp + 243, *g = tmp + 249, *gy = tmp + 255, *g2 = tmp + 261, *Pr = tmp + 267;
-    double (*F)[6] = reinterpret_cast<double (*)[6]>(tmp + 270), *r = tmp + 288;
-    for (int a = 0; a < 3; a++) { pv[a] = 0; for (int b = 0; b < 3; b++) P[a][b] = 0; }
+    /* Round 3 kept every array of the sweeps in `tmp` (work area, run-time indices): the stack of this cold function sized the scratch memory of
+     * every launch of the kernel it was compiled into.  Since round 4 it only lives in follow-up kernels (solve_kernel: PART = 2), so the
+     * arrays are locals with compile-time indices -- registers -- and the last interval is peeled off the stage loop: a stage costs a few
+     * hundred instructions instead of a few hundred round trips to device memory (8 ms -> 0.1 ms per sweep at N = 100) */
+    (void)tmp;
+    double P[3][3], pv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        pv[a] = 0;
+#pragma unroll
+        for (int b = 0; b < 3; b++) P[a][b] = 0;
+    }
     P[0][0] = S[N*S_STRIDE + S_HTT]; pv[0] = S[N*S_STRIDE + S_HT];
     bool ok = true;
-#pragma unroll 1
-    for (int i = N - 1; i >= 0; i--) {
+    auto backward = [&](const int i, auto last_tag) {
+        constexpr bool last = decltype(last_tag)::value;
+        constexpr int nu = last ? 3 : 2;      /* controls to eliminate: (f, p), in the last interval (v, p, s) */
         double *s = S + i*S_STRIDE;
-        const bool last = i == N - 1;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Dt = Dtv[i], Db = Dbv[i];
-        double (*H)[6] = reinterpret_cast<double (*)[6]>(tmp), (*G)[6] = reinterpret_cast<double (*)[6]>(tmp + 36), (*T)[6] = reinterpret_cast<double (*)[6]>(tmp + 72),
-               (*GT)[6] = reinterpret_cast<double (*)[6]>(tmp + 108), (*G2)[6] = reinterpret_cast<double (*)[6]>(tmp + 144), (*PF)[6] = reinterpret_cast<double (*)[6]>(tmp + 180);
-        for (int a = 0; a < 6; a++) { h[a] = 0; for (int b = 0; b < 6; b++) H[a][b] = 0; }
+        double H[6][6], G[6][6], h[6], g[6], Pt[3][3], pt[3], PF[3][6], Pr[3], F[3][6], r[3], L[3][3], K[3][4];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            h[a] = 0;
+#pragma unroll
+            for (int b = 0; b < 6; b++) H[a][b] = 0;
+        }
         H[0][0] = s[S_HTT]; H[1][1] = s[S_HBB]; H[1][2] = H[2][1] = s[S_HBQ]; H[1][3] = H[3][1] = s[S_HBF]; H[1][4] = H[4][1] = s[S_HBP];
         H[2][2] = s[S_HQQ]; H[2][3] = H[3][2] = s[S_HQF]; H[3][3] = s[S_HFF]; H[3][4] = H[4][3] = s[S_HFP]; H[4][4] = s[S_HPP];
         h[0] = s[S_HT]; h[1] = s[S_HB]; h[2] = s[S_HQ]; h[3] = s[S_HF]; h[4] = s[S_HP];
@@ -949,71 +958,145 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
             if (!(det > 0) || !(ma > 0)) ok = false;
             M00 = st*(mc/det)*st; M01 = -st*(mb/det)*sb; M11 = sb*(ma/det)*sb;
         }
+#pragma unroll
         for (int a = 0; a < 3; a++) {
             const double q0 = P[a][0]*M00 + P[a][1]*M01, q1 = P[a][0]*M01 + P[a][1]*M11;
+#pragma unroll
             for (int b = 0; b < 3; b++) Pt[a][b] = P[a][b] - (q0*P[0][b] + q1*P[1][b]);
             pt[a] = pv[a] - (q0*pv[0] + q1*pv[1]);
         }
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 6; b++) F[a][b] = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) F[a][b] = 0;
         F[0][0] = 1; F[0][1] = Tb; F[0][3] = Tw; F[0][4] = pn ? Tw : 0.0; F[1][1] = Bb; F[1][3] = Bw; F[1][4] = pn ? Bw : 0.0; F[2][3] = 1;
         r[0] = rt; r[1] = last ? 0.0 : rb; r[2] = 0;
         /* G = H + F^T P~ F, g = h + F^T (P~ r + p~) */
+#pragma unroll
         for (int a = 0; a < 3; a++) {
+#pragma unroll
             for (int b = 0; b < 6; b++) PF[a][b] = Pt[a][0]*F[0][b] + Pt[a][1]*F[1][b] + Pt[a][2]*F[2][b];
             Pr[a] = pt[a] + Pt[a][0]*r[0] + Pt[a][1]*r[1] + Pt[a][2]*r[2];
         }
+#pragma unroll
         for (int a = 0; a < 6; a++) {
+#pragma unroll
             for (int b = 0; b < 6; b++) G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b];
             g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2];
         }
-        if (!pn) { for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0; G[4][4] = 1; g[4] = 0; }
+        if (!pn) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0;
+            G[4][4] = 1; g[4] = 0;
+        }
         if (last) {
             /* df = eb db - dp + e0 - kap v */
             const double eb = -Bb/Bw, e0 = -rb/Bw, kap = sqrt(Db)/Bw;
-            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) T[a][b] = a == b ? 1.0 : 0.0;
+            double T[6][6], GT[6][6], G2[6][6], gy[6], g2[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) T[a][b] = a == b ? 1.0 : 0.0;
             T[3][3] = -kap; T[3][1] = eb; T[3][4] = pn ? -1.0 : 0.0;
-
+#pragma unroll
             for (int a = 0; a < 6; a++) {
-                for (int b = 0; b < 6; b++) { double v = 0; for (int m = 0; m < 6; m++) v += G[a][m]*T[m][b]; GT[a][b] = v; }
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    double v = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) v += G[a][m]*T[m][b];
+                    GT[a][b] = v;
+                }
                 gy[a] = g[a] + G[a][3]*e0;
             }
+#pragma unroll
             for (int a = 0; a < 6; a++) {
-                for (int b = 0; b < 6; b++) { double v = 0; for (int m = 0; m < 6; m++) v += T[m][a]*GT[m][b]; G2[a][b] = v; }
-                double v = 0; for (int m = 0; m < 6; m++) v += T[m][a]*gy[m]; g2[a] = v;
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    double v = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) v += T[m][a]*GT[m][b];
+                    G2[a][b] = v;
+                }
+                double v = 0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) v += T[m][a]*gy[m];
+                g2[a] = v;
             }
             G2[3][3] += 1.0;
-            for (int a = 0; a < 6; a++) { for (int b = 0; b < 6; b++) G[a][b] = G2[a][b]; g[a] = g2[a]; }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) G[a][b] = G2[a][b];
+                g[a] = g2[a];
+            }
         }
-        /* eliminate the controls: (f, p), in the last interval (v, p, s) */
-        const int nu = last ? 3 : 2;
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) L[a][b] = 0;
+        /* eliminate the controls: Cholesky of the control block */
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) L[a][b] = 0;
+#pragma unroll
         for (int j = 0; j < nu; j++) {
             double d = G[3 + j][3 + j];
+#pragma unroll
             for (int k = 0; k < j; k++) d -= L[j][k]*L[j][k];
             if (!(d > 0) || !isfinite(d)) { ok = false; d = 1.0; }
             L[j][j] = sqrt(d);
+#pragma unroll
             for (int a = j + 1; a < nu; a++) {
                 double v = G[3 + a][3 + j];
+#pragma unroll
                 for (int k = 0; k < j; k++) v -= L[a][k]*L[j][k];
                 L[a][j] = v/L[j][j];
             }
         }
+#pragma unroll
         for (int c = 0; c < 4; c++) {      /* K: columns t, b, q and the constant */
-            double y[3], x[3];
-            for (int a = 0; a < nu; a++) { double v = -(c < 3 ? G[3 + a][c] : g[3 + a]); for (int k = 0; k < a; k++) v -= L[a][k]*y[k]; y[a] = v/L[a][a]; }
-            for (int a = nu - 1; a >= 0; a--) { double v = y[a]; for (int k = a + 1; k < nu; k++) v -= L[k][a]*x[k]; x[a] = v/L[a][a]; }
+            double y[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < nu; a++) {
+                double v = -(c < 3 ? G[3 + a][c] : g[3 + a]);
+#pragma unroll
+                for (int k = 0; k < a; k++) v -= L[a][k]*y[k];
+                y[a] = v/L[a][a];
+            }
+#pragma unroll
+            for (int a = nu - 1; a >= 0; a--) {
+                double v = y[a];
+#pragma unroll
+                for (int k = a + 1; k < nu; k++) v -= L[k][a]*x[k];
+                x[a] = v/L[a][a];
+            }
+#pragma unroll
             for (int a = 0; a < 3; a++) K[a][c] = a < nu ? x[a] : 0.0;
         }
+#pragma unroll
         for (int a = 0; a < 3; a++) {
-            for (int b = 0; b < 3; b++) { double v = G[a][b]; for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][b]; P[a][b] = v; }
-            double v = g[a]; for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][3]; pv[a] = v;
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                double v = G[a][b];
+#pragma unroll
+                for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][b];
+                P[a][b] = v;
+            }
+            double v = g[a];
+#pragma unroll
+            for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][3];
+            pv[a] = v;
         }
-        for (int a = 0; a < 3; a++) for (int b = a + 1; b < 3; b++) { const double m = 0.5*(P[a][b] + P[b][a]); P[a][b] = P[b][a] = m; }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = a + 1; b < 3; b++) { const double m = 0.5*(P[a][b] + P[b][a]); P[a][b] = P[b][a] = m; }
         if (!pn) { K[1][0] = K[1][1] = K[1][2] = K[1][3] = 0; }
         s[S_K + 0] = K[0][0]; s[S_K + 1] = K[0][1]; s[S_K + 2] = K[0][2]; s[S_K + 3] = K[1][0]; s[S_K + 4] = K[1][1]; s[S_K + 5] = K[1][2];
         s[S_KV + 0] = K[0][3]; s[S_KV + 1] = K[1][3];
         if (last) { s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3]; }
-    }
+    };
+    backward(N - 1, std::true_type());
+#pragma unroll 1
+    for (int i = N - 2; i >= 0; i--) backward(i, std::false_type());
     if (!ok) return false;
 
     double x0 = 0, x1 = 0, x2 = 0;      /* (dt, db, dq) of the stage; x_0 is a parameter */

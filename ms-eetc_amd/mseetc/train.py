@@ -176,11 +176,17 @@ class Train():
             from .efficiency import TabulatedLosses
 
             size = tuple(getattr(self, 'lossesTableSize', (24, 32)))
-            key = (self.forceMin, self.forceMax, self.velocityMax, size)
+            # a limit the train does not have (None: ocp.py:104-108 bounds the specific force by accInf = 10 then) is that bound in newtons here
+            accInf = 10.0
+            fmax = self.forceMax if self.forceMax is not None else accInf*self.mass*self.rho
+            fmin = self.forceMin if self.forceMin is not None else -accInf*self.mass*self.rho
+            if self.velocityMax is None:
+                raise ValueError("A tabulated loss function needs the maximum velocity of the train!")
+            key = (fmin, fmax, self.velocityMax, size)
             cached = getattr(self, '_lossesTable', None)
 
             if cached is None or cached[0] is not fun or cached[1] != key:
-                cached = (fun, key, TabulatedLosses(fun, self.forceMin, self.forceMax, self.velocityMax, numForce=size[0], numVelocity=size[1]))
+                cached = (fun, key, TabulatedLosses(fun, fmin, fmax, self.velocityMax, numForce=size[0], numVelocity=size[1]))
                 self._lossesTable = cached
 
             return cached[2]

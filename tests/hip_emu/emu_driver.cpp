@@ -64,6 +64,8 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     else if (nodes <= 128) { NT = 64; SPT = 2; }
     else if (nodes <= 256) { NT = 128; SPT = 2; }
     else if (nodes <= 384) { NT = 192; SPT = 2; }
+    else if (nodes <= 512) { NT = 256; SPT = 2; }
+    else if (nodes <= 576 && !dyn) { NT = 192; SPT = 3; }      /* like pick_geometry_t: three nodes per lane on three waves */
     else { NT = 320; SPT = 2; }
     if (NT*SPT < nodes) return -3;
     /* the kernels with the structure of the NLP compiled in (msd_kernels_full.hip), chosen like msd_api.hip does; EMU_NO_FULL=1: the general ones */

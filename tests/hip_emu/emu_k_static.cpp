@@ -8,6 +8,8 @@ bool emu_run_static(int NT, int SPT, const EmuArgs &a)
     if (NT == 128 && SPT == 1) { EMU_CALL(128, 1, false); return true; }
     if (NT == 128 && SPT == 2) { EMU_CALL(128, 2, false); return true; }
     if (NT == 192 && SPT == 2) { EMU_CALL(192, 2, false); return true; }
+    if (NT == 256 && SPT == 2) { EMU_CALL(256, 2, false); return true; }
+    if (NT == 192 && SPT == 3) { EMU_CALL(192, 3, false); return true; }
     if (NT == 320 && SPT == 2) { EMU_CALL(320, 2, false); return true; }
     return false;
 }

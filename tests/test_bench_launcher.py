@@ -85,6 +85,29 @@ def test_two_ranks_on_the_gpu_box():
     assert line['value'] > 1e5 and 'alt' not in line and 'cpu_baseline' not in line
 
 
+@pytest.mark.gpu
+def test_eight_ranks_config3_and_config4_on_the_gpu_box():
+    """
+    The launcher path of an 8-GPU run for BASELINE configs 3 and 4 at their full sizes, on the one device of the box (MSD_BENCH_SHARE_DEVICES=1:
+    rank r -> device r % 1, gloo for the barrier and the reductions): config 3 = 8 x 8192 scenarios with per-scenario rolling stock -- the
+    aggregate line parses, every one of the 65 536 scenarios converges, the ranks solved different batches (seed + rank) --, config 4 =
+    8 x 512 scenarios x 50 re-solves through the device-resident loop.  No scaling number comes out of this: eight ranks share one GPU.
+    """
+    import json, os, subprocess, sys
+    env = dict(os.environ, MSD_BENCH_SHARE_DEVICES='1')
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '8', '--workload', 'c3', '--steps', '2', '--warmup', '1', '--no-build'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and line['config']['scenarios'] == 65536 and line['config']['converged'] == 65536
+    br = line['config']['by_rank']
+    assert len(br['ip_iterations_mean']) == 8 and len(set(br['first_running_time'])) == 8 and len(set(br['ip_iterations_mean'])) > 1
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '8', '--workload', 'c4', '--steps', '1', '--warmup', '1', '--no-build'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['config']['batch_per_gpu'] == 512
+    assert line['config']['resolves_successful'] + line['config']['resolves_failed'] == 8*512*50 and line['config']['resolves_failed'] <= 8*4
+
+
 def test_default_step_counts_and_options():
     "about a second of launches per workload without flags; explicit flags win; the transcriptions map onto the reference's options"
     a = bench.parse_args([])

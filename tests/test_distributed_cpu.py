@@ -59,11 +59,12 @@ def _worker(rank, world, port, B, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('B', [6, 5, 1])
-def test_two_rank_gloo_equals_single_process(tmp_path, B):
+@pytest.mark.parametrize('B,world', [(6, 2), (5, 2), (1, 2), (11, 4), (3, 4), (17, 8)])
+def test_gloo_ranks_equal_single_process(tmp_path, B, world):
+    "2, 4 and 8 ranks (the node sizes of BASELINE's metric), even, ragged and emptier-than-ranks splits: sharded + gathered == unsharded, bit for bit"
     out = str(tmp_path / 'res.npz')
-    port = 29500 + (os.getpid() + B) % 2000
-    mp.spawn(_worker, args=(2, port, B, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() + 7*B + world) % 2000
+    mp.spawn(_worker, args=(world, port, B, out), nprocs=world, join=True)
     got = np.load(out)
     prob = cases.oracle_problem(cases.train_default(), cases.track_00(crop=20000), 40)
     T = 700 + 300*np.random.default_rng(5).random(B)

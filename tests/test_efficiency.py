@@ -230,3 +230,17 @@ def test_oracle_constant_efficiencies_through_the_table_are_the_static_model():
     assert rs['stats']['STATUS'] == 0 and rt['stats']['STATUS'] == 0
     assert abs(rt['stats']['OBJ'] - rs['stats']['OBJ']) <= 1e-8*abs(rs['stats']['OBJ'])
     assert np.max(np.abs(rt['z'] - rs['z'])/np.maximum(1.0, np.abs(rs['z']))) <= 1e-5
+
+
+def test_tabulated_loss_function_on_a_train_without_a_force_limit():
+    """
+    train.py:36-66: a limit may be None (free; ocp.py:104-108 then bounds the specific force by accInf = 10).  A custom loss function on such a
+    train is tabulated over that bound instead of raising on float(None) (round-3 advisor finding).
+    """
+    train = cases.train_default()
+    train.forceMin = None
+    train.powerLosses = lambda F, v: 1e-6*F*F + 100.0*v + 0.01*abs(F)*v
+    tab = train.lossesCallable()
+    assert type(tab).__name__ == 'TabulatedLosses' and tab.maxDeviation < 1e-6
+    M = train.mass*train.rho
+    assert abs(tab.tabulated(-9.0*M, 20.0) - train.powerLosses(-9.0*M, 20.0)) < 1e-6*train.powerLosses(-9.0*M, 20.0)
