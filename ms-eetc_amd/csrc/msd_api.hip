@@ -154,8 +154,19 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     if (rc != MSD_OK) return rc;
     pl.max_grid = per_cu*cus;
     pl.max_grid2 = 0;
+    pl.NT2 = geo.NT; pl.SPT2 = geo.SPT; pl.lds_bytes2 = lds;
+    if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST) {
+        /* horizons of up to 63 intervals: the first pass runs one node per lane, the follow-up kernel is the two-nodes-per-lane one (its second node
+         * slots stay idle).  The follow-up kernel restarts a scenario from its starting point, so nothing ties its geometry to the first pass's; and
+         * the 64 x 1 instantiation of the one-brake follow-up kernel faults on the device (round 4: `solve_kernel<64, 1, 1, 0, false, false, 2, 2>`
+         * with the phase fences -- the host emulation of the same code runs clean under the sanitizers, a build of that kernel without the fences
+         * takes another path than every other implementation: a code-generation problem of that one instantiation, tools/probe_follow_rg*.py) */
+        geo.fn2 = full ? msd::follow_kernel_full(64, 2) : msd::follow_kernel_full_rg(64, 2);
+        pl.NT2 = 64; pl.SPT2 = 2;
+        pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles(N, 128, wide, geo.xch, geo.red);
+    }
     if (geo.fn2) {
-        rc = kernel_limits(device, (const void *)geo.fn2, geo.NT, lds, &per_cu);
+        rc = kernel_limits(device, (const void *)geo.fn2, pl.NT2, pl.lds_bytes2, &per_cu);
         if (rc != MSD_OK) return rc;
         pl.max_grid2 = per_cu*cus;
     }
@@ -166,7 +177,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
         pl.max_grid_lsq = per_cu*cus;
     }
     pl.fused_family = geo.fn2 != nullptr && geo.xch == msd::XCH_FAST;
-    pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : msd::work_doubles(geo.NT*geo.SPT);
+    pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : msd::work_doubles(std::max(geo.NT*geo.SPT, pl.NT2*pl.SPT2));
     pl.nz = (4 + P.withPn)*N + 2; pl.nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
     pl.kernel = geo.fn; pl.kernel2 = geo.fn2; pl.kernel_lsq = geo.fn_lsq;
     return MSD_OK;
@@ -186,7 +197,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
         const int cap = split ? pl.max_grid2 : pl.max_grid;
         P.follow = d_list;
-        hipLaunchKernelGGL(fn, dim3(std::min(nscen, cap)), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+        hipLaunchKernelGGL(fn, dim3(std::min(nscen, cap)), dim3(split ? pl.NT2 : pl.NT), split ? pl.lds_bytes2 : pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
         HIP_TRY(hipGetLastError());
         return MSD_OK;
     }
@@ -198,6 +209,8 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     const msd::KernelFn fn = (split && !first_pass) ? pl.kernel2 : plain ? pl.kernel : pl.kernel_lsq;
     const int cap = (split && !first_pass) ? pl.max_grid2 : plain ? pl.max_grid : pl.max_grid_lsq;
     const int grid = nscen < cap ? nscen : cap;
+    const int threads = (split && !first_pass) ? pl.NT2 : pl.NT;
+    const size_t lds_bytes = (split && !first_pass) ? pl.lds_bytes2 : pl.lds_bytes;
     if (first_pass) {
         if (!d_follow) return fail(MSD_E_INVALID, "split solve without its list");
         P.follow = d_follow;
@@ -209,15 +222,15 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), stream));
     }
     if (first_begin) HIP_TRY(hipEventRecord(first_begin, stream));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
     HIP_TRY(hipGetLastError());
     if (first_end) HIP_TRY(hipEventRecord(first_end, stream));
-    if (first_pass) {
+    if (first_pass && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) {      /* (debugging aid: leave the list as the first pass wrote it) */
         /* the follow-up kernel: usually nothing to do (0 of the 1024 + 8192 benchmark scenarios of configs 1 and 2) -- a workgroup that finds
          * the list empty returns at once, the others take scenarios off it until it is empty */
         const int grid2 = std::min(nscen, pl.max_grid2);
         P.queue = nullptr;
-        hipLaunchKernelGGL(pl.kernel2, dim3(grid2), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+        hipLaunchKernelGGL(pl.kernel2, dim3(grid2), dim3(pl.NT2), pl.lds_bytes2, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
         HIP_TRY(hipGetLastError());
     }
     return MSD_OK;
@@ -298,6 +311,7 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
     P.loss = (d->loss_kind == 2) ? h->d_loss : nullptr;
     P.coll = (d->integrator == MSD_INTEGRATOR_COLLOCATION) ? h->d_coll : nullptr;
     h->max_grid = pl.max_grid; h->max_grid2 = pl.max_grid2; h->max_grid_lsq = pl.max_grid_lsq; h->fused_family = pl.fused_family;
+    h->NT2 = pl.NT2; h->SPT2 = pl.SPT2; h->lds_bytes2 = pl.lds_bytes2;
     h->work_per_wg = pl.work_doubles;
     {
         const size_t need = pl.work_doubles*(size_t)std::max(h->max_grid, std::max(h->max_grid2, h->max_grid_lsq));
@@ -376,7 +390,7 @@ static msd_host::Plan plan_of(const msd_problem *h)
 {
     msd_host::Plan pl;
     pl.P = h->P; pl.NT = h->NT; pl.SPT = h->SPT; pl.lds_bytes = h->lds_bytes; pl.stream = h->stream_kernel;
-    pl.kernel = h->kernel; pl.kernel_lsq = h->kernel_lsq; pl.kernel2 = h->kernel2;
+    pl.kernel = h->kernel; pl.kernel_lsq = h->kernel_lsq; pl.kernel2 = h->kernel2; pl.NT2 = h->NT2; pl.SPT2 = h->SPT2; pl.lds_bytes2 = h->lds_bytes2;
     pl.max_grid = h->max_grid; pl.max_grid_lsq = h->max_grid_lsq; pl.max_grid2 = h->max_grid2; pl.fused_family = h->fused_family;
     pl.work_doubles = h->work_per_wg; pl.nz = msd_problem_nz(const_cast<msd_problem *>(h)); pl.nl = msd_problem_rows_per_interval(const_cast<msd_problem *>(h))*h->P.N;
     return pl;
@@ -432,7 +446,8 @@ int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per
 int msd_problem_follow_counts(msd_handle h, int *counts, int n)
 {
     if (!h || !counts || n < 1) return fail(MSD_E_INVALID, "bad argument");
-    if (n > 7) n = 7;
+    if (n > 7 && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) n = 7;      /* (debugging aid: the list's entries behind the counters) */
+    if (n > (int)h->cap_follow - msd::FOLLOW_TOTAL && h->d_follow) n = (int)h->cap_follow - msd::FOLLOW_TOTAL;
     for (int k = 0; k < n; k++) counts[k] = 0;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -691,6 +706,18 @@ int msd_solve_batch_multi(const msd_handle *handles, int nhandles, int nscen, co
     }
     if (first_error != MSD_OK) { g_err = first_msg; return first_error; }
     if (kernel_ms) *kernel_ms = worst;
+    return MSD_OK;
+}
+
+int msd_host_alloc(unsigned long long bytes, void **ptr)
+{
+    if (!ptr || bytes == 0) return fail(MSD_E_INVALID, "bad argument");
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return MSD_OK;
+}
+int msd_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return MSD_OK;
 }
 

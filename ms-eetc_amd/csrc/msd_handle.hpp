@@ -31,6 +31,8 @@ struct Plan {
     msd::KernelFn kernel = nullptr;                   /* complete kernel, or the first pass of a split solve (kernel2 != nullptr) */
     msd::KernelFn kernel_lsq = nullptr;               /* first pass for launches that need the least-squares multiplier estimate (msd::Geometry::fn_lsq) */
     msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2) */
+    int NT2 = 0, SPT2 = 0;                            /* its own launch geometry (it restarts a scenario from its starting point, so it need not share the first pass's) */
+    size_t lds_bytes2 = 0;
     int max_grid = 0, max_grid_lsq = 0, max_grid2 = 0;      /* resident workgroups of the three */
     bool fused_family = false;                        /* `kernel` runs the fused iteration only (needs a profile start or a primal-dual warm start) */
     size_t work_doubles = 0;                          /* work area of one workgroup */
@@ -68,6 +70,7 @@ struct msd_problem {
     int max_grid_lsq = 0;
     msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2), its resident workgroups and the list between the two */
     int max_grid2 = 0;
+    int NT2 = 0, SPT2 = 0; size_t lds_bytes2 = 0;     /* launch geometry of the follow-up kernel */
     int *d_follow = nullptr; size_t cap_follow = 0;
     bool fused_family = false;                        /* `kernel` runs the fused iteration only (needs a profile start or a primal-dual warm start) */
     hipStream_t stream = nullptr;

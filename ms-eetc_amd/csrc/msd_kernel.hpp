@@ -63,38 +63,6 @@
 #ifndef MSD_RICCATI_INLINE
 #define MSD_RICCATI_INLINE 1
 #endif
-/* where the iterate of a shooting node lives between the phases of an iteration: 0 = registers, 1 = the workgroup's private work
- * area in device memory (structure of arrays over the node slots: coalesced, L2-resident), loaded by the phases that need it */
-#ifndef MSD_MEM_X
-#define MSD_MEM_X 0
-#endif
-#ifndef MSD_MEM_SG
-#define MSD_MEM_SG 0
-#endif
-#ifndef MSD_MEM_LAM
-#define MSD_MEM_LAM 0
-#endif
-#ifndef MSD_MEM_NU
-#define MSD_MEM_NU 0
-#endif
-#ifndef MSD_MEM_Z
-#define MSD_MEM_Z 0
-#endif
-#ifndef MSD_MEM_DSG
-#define MSD_MEM_DSG 0
-#endif
-#ifndef MSD_MEM_RES
-#define MSD_MEM_RES 0
-#endif
-#ifndef MSD_MEM_EV
-#define MSD_MEM_EV 0
-#endif
-#ifndef MSD_STASH_KKT
-#define MSD_STASH_KKT 0             /* the register-resident iterate is written to the work area before the stage-parallel KKT solve and read back after it */
-#endif
-#ifndef MSD_PARK_STATE
-#define MSD_PARK_STATE 0            /* pin the iterate in accumulation registers across the stage-parallel KKT solve */
-#endif
 #ifndef MSD_TELEMETRY
 #define MSD_TELEMETRY 0             /* per-phase cycle counters of the logged scenario (Ctx::mark) */
 #endif
@@ -619,14 +587,14 @@ struct Node {
     unsigned flags;
     double ds, G, sct, scb, ubB;
     /* iterate */
-    Field<NV, NS, MSD_MEM_X != 0 || STREAM> x;
-    Field<NR, NS, MSD_MEM_SG != 0 || STREAM> sg;
-    Field<2, NS, MSD_MEM_LAM != 0 || STREAM> lam;
-    Field<NR, NS, MSD_MEM_NU != 0 || STREAM> nu;
-    Field<NV, NS, MSD_MEM_Z != 0 || STREAM> zL, zU;
-    Field<NR, NS, MSD_MEM_Z != 0 || STREAM> zLs, zUs;
+    Field<NV, NS, STREAM> x;
+    Field<NR, NS, STREAM> sg;
+    Field<2, NS, STREAM> lam;
+    Field<NR, NS, STREAM> nu;
+    Field<NV, NS, STREAM> zL, zU;
+    Field<NR, NS, STREAM> zLs, zUs;
     /* slack part of the direction; (dx, new dynamics multipliers) stay in the node's LDS stage block */
-    Field<NR, NS, MSD_MEM_DSG != 0 || STREAM> dsg;
+    Field<NR, NS, STREAM> dsg;
     __device__ __forceinline__ void bind(double *w)      /* w: work area of the workgroup + node slot */
     {
         x.bind(w + W_X*NS); sg.bind(w + W_SG*NS); lam.bind(w + W_LAM*NS); nu.bind(w + W_NU*NS); zL.bind(w + W_ZL*NS); zU.bind(w + W_ZU*NS);
@@ -1600,11 +1568,11 @@ struct Solver {
     NodeT n[SPT];
     Uni &U;                                /* workgroup-uniform data of the scenario, in LDS (like P): loaded where needed instead of held in registers */
     /* right-hand sides of the linearised constraints: c and d - sigma (or their SOC accumulation) */
-    Field<2, NS, MSD_MEM_RES != 0 || STREAM> resc[SPT];
-    Field<NR, NS, MSD_MEM_RES != 0 || STREAM> resd[SPT];
+    Field<2, NS, STREAM> resc[SPT];
+    Field<NR, NS, STREAM> resd[SPT];
     /* evaluation of the current point with derivatives (evaluate_current), read back by the phases that need it */
-    Field<13, NS, MSD_MEM_EV != 0 || STREAM> evs[SPT];
-    Field<10, NS, MSD_MEM_EV != 0 || STREAM> lgs[SPT];
+    Field<13, NS, STREAM> evs[SPT];
+    Field<10, NS, STREAM> lgs[SPT];
 
     __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_, double *work_, Uni &U_) : P(P_), c(c_), work(work_), U(U_) {}
 
@@ -1650,7 +1618,7 @@ struct Solver {
     }
     /* explicit home of the register-resident iterate in the work area (same layout as the memory-backed fields): stash() writes the
      * fields of node j selected by the mask, fetch() reads them back.  Between a stash and the next fetch the values are dead in
-     * registers, which is the point: the phase in between gets the register file (MSD_STASH_KKT: around the stage-parallel KKT solve) */
+     * registers, which is the point: the phase in between gets the register file */
     static constexpr unsigned H_X = 1u, H_SG = 2u, H_LAM = 4u, H_NU = 8u, H_Z = 16u, H_ZS = 32u, H_DSG = 64u, H_RES = 128u, H_EV = 256u, H_ALL = 511u;
     template <int CNT, class F> __device__ __forceinline__ void put(const F &f, int off, int slot)
     {
@@ -1737,23 +1705,6 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < NR; r++) { fence_v(nd.sg, r); if (MSD_FENCE_DUALS) { fence_d(nd.nu, r); fence_z(nd.zLs, r); fence_z(nd.zUs, r); fence_d(nd.dsg, r); fence_d(resd[j], r); } }
             if (MSD_FENCE_DUALS) { fence_d(nd.lam, 0); fence_d(nd.lam, 1); fence_d(resc[j], 0); fence_d(resc[j], 1); }
-        }
-#endif
-    }
-
-    /* the whole iterate into accumulation registers: the stage-parallel KKT solve touches none of it and needs the architectural
-     * registers for its scan (MSD_PARK_STATE) */
-    __device__ __forceinline__ void park_state()
-    {
-#if MSD_PARK_STATE
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            NodeT &nd = n[j];
-#pragma unroll
-            for (int k = 0; k < NV; k++) { fence_a(nd.x, k); fence_a(nd.zL, k); fence_a(nd.zU, k); }
-#pragma unroll
-            for (int r = 0; r < NR; r++) { fence_a(nd.sg, r); fence_a(nd.nu, r); fence_a(nd.zLs, r); fence_a(nd.zUs, r); fence_a(nd.dsg, r); fence_a(resd[j], r); }
-            fence_a(nd.lam, 0); fence_a(nd.lam, 1); fence_a(resc[j], 0); fence_a(resc[j], 1);
         }
 #endif
     }
@@ -2216,15 +2167,8 @@ struct Solver {
         /* (the scan keeps its wave totals for up to eight waves: the streamed kernels of 512 threads take it too, on their stage blocks in
          * device memory -- a serial sweep there pays a memory round trip per stage) */
         if (!STREAM || NT <= 512) {
-        park_state();
-#if MSD_STASH_KKT
-        stash<H_ALL & ~H_DSG>();
-#endif
         par = ParallelRiccati<SPT, DYN>::solve(P.N, withPn(), c);
         c.red_slot++;        /* one block reduction inside */
-#if MSD_STASH_KKT
-        fetch<H_ALL & ~H_DSG>();
-#endif
         if (par < 0) {       /* the scan broke down (cold path): the sweeps overwrite the blocks, so assemble again */
             assemble(mode, mu_, dw);
             if (c.tid == 0) c.misc[MISC_FALLBACKS] += 1.0;
@@ -2556,8 +2500,7 @@ struct Solver {
      * Anything rare -- wrong inertia, scan breakdown, a rejected first trial point (backtracking, second-order correction) --
      * repeats the iteration on the general path (run()).
      * ---------------------------------------------------------------------------------------- */
-    static constexpr bool FAST = FULL && DYN == LOSS_STATIC && !STREAM && !GEN && !MSD_MEM_X && !MSD_MEM_SG && !MSD_MEM_LAM && !MSD_MEM_NU && !MSD_MEM_Z
-                                 && !MSD_MEM_DSG && !MSD_MEM_RES && MSD_PARALLEL_RICCATI;
+    static constexpr bool FAST = FULL && DYN == LOSS_STATIC && !STREAM && !GEN && MSD_PARALLEL_RICCATI;
     static constexpr int HV = 6;      /* gradient side of a stage block: t, b, q, f, p and the slack row */
     double cnt_lam = 0, cnt_z = 0;    /* numbers of constraint and of bound multipliers (fused_pass) */
 
@@ -3037,9 +2980,6 @@ struct Solver {
      * waves (N <= 511: every BASELINE configuration); the others keep the restart from the other starting point */
 #ifndef MSD_RESTO
 #define MSD_RESTO 1      /* 0: kernels without the restoration phase (A/B builds) */
-#endif
-#ifndef MSD_RESTO_VARIANT
-#define MSD_RESTO_VARIANT 0
 #endif
     static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM && !GEN && NT <= 256;
     static constexpr bool FIRST = PART == 1 || PART == 3;
@@ -3661,7 +3601,7 @@ __device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, U
 {
     Solver<NT, SPT, DYN, true, GEN, FULL> r(*P, c, work, *U);
     int nit = 0;
-    const int rr = (MSD_RESTO_VARIANT == 3) ? 0 : r.restoration(scen, hist, hist_cap, nit);
+    const int rr = r.restoration(scen, hist, hist_cap, nit);
     /* hand-over to the general iteration: where it continues, and with which status if the solve ends here */
     __syncthreads();
     if (c.tid == 0) {
@@ -3819,7 +3759,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                     __syncthreads();
                     if constexpr (SolverT::HAS_RESTO) {
                         if (st != SolverT::STATUS_RESTO) break;
-                        if (MSD_RESTO_VARIANT != 2) resto_entry<NT, SPT, DYN, GEN, FULL>(Pl, c, wg_work, Ul, scen + (size_t)MSD_SC_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
+                        resto_entry<NT, SPT, DYN, GEN, FULL>(Pl, c, wg_work, Ul, scen + (size_t)MSD_SC_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
                         resume = true;
                     } else break;
                 }

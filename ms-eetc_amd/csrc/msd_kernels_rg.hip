@@ -11,7 +11,7 @@
 
 namespace msd {
 /* the pickers below hand out XCH_FAST exchange arrays (and no reduction scratch for a single wave): the layout of a kernel whose Solver::FAST holds */
-static_assert(Solver<64, 2, LOSS_STATIC, false, false, FULL_RG, 1>::FAST && Solver<256, 2, LOSS_STATIC, false, false, FULL_RG, 3>::FAST, "the tuning switches of this build (MSD_MEM_*, MSD_PARALLEL_RICCATI) leave no fused iteration: pick_geometry_full would size the LDS wrongly");
+static_assert(Solver<64, 2, LOSS_STATIC, false, false, FULL_RG, 1>::FAST && Solver<256, 2, LOSS_STATIC, false, false, FULL_RG, 3>::FAST, "the tuning switches of this build (MSD_PARALLEL_RICCATI) leave no fused iteration: pick_geometry_full would size the LDS wrongly");
 Geometry pick_geometry_full_rg(int N)
 {
     const int nodes = N + 1;

@@ -17,6 +17,8 @@ LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent
 ABI_VERSION = 5
 INTEGRATOR_ADAPTIVE, INTEGRATOR_COLLOCATION = 1, 2     # MSD_INTEGRATOR_* (also the methods of msd_interval_integrate)
 ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, N_RESTO=14, COUNT=15)
+# (ITERS counts both attempts of a solve that was repeated from the other starting point: after a breakdown, or after the iteration limit behind a
+#  restoration phase -- it can reach twice max_iterations then)
 SC_COUNT = 4
 OV = dict(SR0=0, SR1=1, SR2=2, F_MAX=3, F_MIN=4, F_MIN_PN=5, PW_UPPER=6, PW_LOWER=7, OBJ_DEN=8, TOTAL_MASS=9, COUNT=10)
 HIST_COLS = 8
@@ -121,6 +123,8 @@ def lib():
         L.msd_integrate_losses.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, ctypes.c_int,
                                            _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr]
 
+        L.msd_host_alloc.argtypes = [ctypes.c_ulonglong, ctypes.POINTER(vp)]
+        L.msd_host_free.argtypes = [vp]
         L.msd_mpc_create.argtypes = [vp, vp, ctypes.POINTER(MpcPlan), ctypes.POINTER(vp)]
         L.msd_mpc_destroy.argtypes = [vp]
         L.msd_mpc_run.argtypes = [vp, ctypes.c_int, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr, _dptr, ctypes.POINTER(ctypes.c_float)]
@@ -185,6 +189,48 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
     return d
 
 
+class _Pinned():
+    "Page-locked host memory (msd_host_alloc), freed with the object."
+
+    def __init__(self, nbytes):
+        self.ptr, self.nbytes = ctypes.c_void_p(), int(nbytes)
+        _check(lib().msd_host_alloc(self.nbytes, ctypes.byref(self.ptr)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().msd_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _ResultArrays():
+    """
+    Result arrays of the host-buffer entry points in page-locked memory: a device-to-host copy into them runs at the link's rate without
+    staging or page faults.  A buffer is handed out again once no array or view of its previous use is alive (reference count of the
+    ctypes object every such array has as its base); otherwise a new one is allocated.
+    """
+
+    def __init__(self):
+        self._cache = {}
+
+    def zeros(self, role, shape):
+        import sys
+        count = int(np.prod(shape))
+        if count == 0:
+            return np.zeros(shape)
+        ent = self._cache.get(role)
+        if ent is not None and len(ent) == count and sys.getrefcount(ent) == 3:      # (the cache, `ent` and getrefcount's own argument: no array or view of the last use is alive)
+            carr = ent
+        else:
+            buf = _Pinned(8*count)
+            carr = (ctypes.c_double*count).from_address(buf.ptr.value)
+            carr._owner = buf
+            self._cache[role] = carr
+        return np.frombuffer(carr, dtype=np.float64, count=count).reshape(shape)      # (every element is written by the copy that follows)
+
+
 class DeviceProblem():
     "Owner of an msd_handle."
 
@@ -198,6 +244,7 @@ class DeviceProblem():
         self.nz = L.msd_problem_nz(self._h)
         self.rowsPerInterval = L.msd_problem_rows_per_interval(self._h)
         self.device = device
+        self._results = _ResultArrays()
 
     def reconfigure(self, desc):
         "Load another problem into this handle (stream and device buffers are kept): msd_problem_reconfigure."
@@ -232,9 +279,9 @@ class DeviceProblem():
         L = lib()
         scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
         B = scen.shape[0]
-        z = np.zeros((B, self.nz))
-        st = np.zeros((B, ST['COUNT']))
-        lam = np.zeros((B, self.rowsPerInterval*self.N)) if want_multipliers else None
+        z = self._results.zeros('z', (B, self.nz))
+        st = self._results.zeros('st', (B, ST['COUNT']))
+        lam = self._results.zeros('lam', (B, self.rowsPerInterval*self.N)) if want_multipliers else None
         ms = ctypes.c_float(0)
         hist = None
 

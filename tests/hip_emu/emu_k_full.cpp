@@ -9,7 +9,8 @@ template <int NT, int SPT, int KIND> static void run_split(EmuArgs a)
     a.P.follow = follow.data();
     const bool plain = a.P.guess ? a.P.dualIn != nullptr : a.P.start == MSD_START_PROFILE;      /* like msd_api.hip: launch() */
     if (plain) EMU_CALL(NT, SPT, false, false, false, KIND, 1); else EMU_CALL(NT, SPT, false, false, false, KIND, 3);
-    EMU_CALL(NT, SPT, false, false, false, KIND, 2);
+    /* the follow-up kernel of the one-node-per-lane geometry is the two-nodes-per-lane one (msd_api.hip: make_plan) */
+    if (NT == 64 && SPT == 1) EMU_CALL(64, 2, false, false, false, KIND, 2); else EMU_CALL(NT, SPT, false, false, false, KIND, 2);
 }
 
 template <int KIND> static bool run_kind(int NT, int SPT, const EmuArgs &a)

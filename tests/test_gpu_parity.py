@@ -3,8 +3,18 @@ Parity of the HIP path (through the C ABI) with the CPU oracle on the same seede
 properties at the benchmark sizes.  Needs an MI355X: run with -m gpu.
 
 Tolerances: BASELINE.json's north_star asks for 1e-4 relative on energy and terminal constraints; the HIP kernel
-and the oracle implement the same algorithm, so much tighter bounds are asserted: 1e-8 relative on the objective,
-1e-6 (relative to max(1,|z|)) on every variable, identical iteration counts allowed to differ by at most 2.
+and the oracle implement the same algorithm, so much tighter bounds are asserted.  The default (`_compare`): objective 1e-8 relative,
+every variable 1e-6 relative to max(1,|z|), iteration counts within 2.  Where a test asserts something wider, it says why next to the
+number; the wider bounds in this file are
+  * objective 1e-7 where the two solvers end at different barrier parameters (the last barrier test looks at a dual infeasibility that is
+    rounding noise by then: one of them may stop one reduction further down the central path -- see test_randomized_problems_vs_oracle);
+  * variables 1e-5 on the 256-scenario samples and 1e-4 on the config-3 sample and the long horizons (flat directions of the optimum:
+    loss slacks and coasting speeds that the objective barely sees);
+  * objective 1e-6 / variables 1e-3 between the two starting points of one problem (two interior-point paths to one optimum);
+  * iteration counts within 5 on the dynamic-loss solves (spline rows: one backtracking decision taken differently costs several);
+  * the closed loops of config 4: measured times 1e-6, speeds 1e-5, costs 1e-5 early and 5e-3 late in the journey (the energy of the last
+    kilometres is steep in the running-time reserve).
+All of them are inside north_star's 1e-4 on energy and terminal constraints.
 """
 
 import numpy as np
@@ -1214,3 +1224,34 @@ def test_device_resident_shrinking_horizon_loop_vs_host_loop():
         assert first_move is None or first_move >= 20
         hm = np.any([h['relaxed'] for h in host], axis=0); dm = np.any([d['relaxed'] for d in dev], axis=0)
         assert (hm != dm).sum() <= 2
+
+
+@pytest.mark.parametrize('variant', ['rg', 'both'])
+def test_short_horizons_through_the_follow_up_kernel(variant):
+    """
+    Horizons of up to 63 intervals (one node per lane in the first pass) whose scenarios need the follow-up kernel: loose schedules from the
+    reference's starting point (inertia corrections, restoration phases) and from the profile start, N = 40 and N = 63, both rolling-stock
+    structures -- against the oracle.  (Round 4: the 64 x 1 instantiation of the one-brake follow-up kernel faulted on the device; the follow-up
+    kernel of these horizons is the two-nodes-per-lane one since, msd_api.hip: make_plan.  Found by tests/tools/random_sweep.py, seed 15.)
+    """
+    from oracle import oracle
+    from mseetc._device import ST
+    train = cases.train_fig10() if variant == 'rg' else cases.train_default()
+    for N, crop in ((40, 16000), (63, 30000)):
+        track = cases.track_00(crop)
+        prob = cases.oracle_problem(train, track, N, maxIterations=800)
+        T = np.array([700.0, 2500.0, 6000.0, 9000.0])*(crop/16000.0)
+        for start in ('profile', 'reference'):
+            s = _solver(train, track, N, start=start, maxIterations=800)
+            before = s.problem.follow_counts()[0]
+            res = s.solveBatch(T)
+            assert np.all(res['status'] == 0), (N, start, res['status'])
+            assert s.problem.follow_counts()[0] - before >= 2      # the loose ones went through the follow-up kernel
+            for k, t in enumerate(T):
+                ref = oracle.solve(prob, prob.scenario(float(t)), start=start)
+                assert ref['stats']['STATUS'] == 0
+                through_resto = res['stats'][k, ST['N_RESTO']] > 0 or ref['stats']['N_RESTO'] > 0
+                if not through_resto:      # (a hundred iterations through restoration phases do not repeat to the iteration: there the optimum is compared)
+                    assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2, (N, start, k, res['iterations'][k], ref['stats']['ITERS'])
+                assert abs(res['cost'][k] - ref['stats']['OBJ']) <= (1e-6 if through_resto else 1e-7)*max(1e-3, abs(ref['stats']['OBJ'])), (N, start, k)
+            s.close()

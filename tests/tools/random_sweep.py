@@ -20,6 +20,8 @@ bad = 0
 for seed in range(first, last):
     with tempfile.TemporaryDirectory() as tmp:
         train, track, N, rng = _random_problem(seed, Path(tmp))
+        if os.environ.get('SWEEP_VERBOSE'):
+            print('seed', seed, 'N', N, 'pn', train.forceMinPn, 'rg', train.forceMin, flush=True)
         v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
         fast = _solver(train, track, N, energyOptimal=False, start='profile')
         rt = fast.solveBatch([3*track.length/train.velocityMax], initialVelocity=v0, terminalVelocity=vN)
