@@ -30,6 +30,12 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 }
 using msd_host::fail;
 
+namespace msd {
+/* (msd_kernels_stream4.hip; declared here and not in msd_geometry.hpp, which every kernel unit depends on) */
+Geometry pick_stream_geometry_general_dynamic(int N);
+Geometry pick_stream_geometry_general_intloss(int N);
+}
+
 namespace msd_host {
 
 /* argument checks shared by create and reconfigure */
@@ -124,12 +130,11 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
-        geo = (gen && (dyn || intloss)) ? msd::Geometry{0, 0, nullptr} : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
+        geo = (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
               : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
         lds = sizeof(double)*(size_t)msd::lds_doubles_stream();
         if (!geo.fn)
-            return fail(MSD_E_UNSUPPORTED, (gen && (dyn || intloss)) ? "numIntervals = " + std::to_string(N) + " with a collocation or adaptive shooting integrator and the dynamic loss model or integrateLosses exceeds the 255 intervals of their kernels"
-                                           : (gen || intloss || dyn) ? "numIntervals = " + std::to_string(N) + " exceeds the 1023 intervals of the streamed kernels for the dynamic loss model, the collocation / adaptive shooting integrators and integrateLosses"
+            return fail(MSD_E_UNSUPPORTED, (gen || intloss || dyn) ? "numIntervals = " + std::to_string(N) + " exceeds the 1023 intervals of the streamed kernels for the dynamic loss model, the collocation / adaptive shooting integrators and integrateLosses"
                                            : "numIntervals = " + std::to_string(N) + " exceeds the 5119 intervals of the streamed kernel");
     }
     pl.NT = geo.NT; pl.SPT = geo.SPT; pl.lds_bytes = lds; pl.stream = geo.stream;

@@ -232,13 +232,39 @@ __global__ void adaptive_kernel(IvTrain T, int n, const double *t0, const double
     if (status) status[k] = st;
 }
 
+/* the same by casadi.simpleRK(fun, numSteps, 4) -- TrainIntegrator.initRollingResistance(solver='RK'), train.py:428-432: classic RK4, equal steps */
+__device__ int iv_rolling_rk(const IvTrain &T, double ds, double w, double G, double &b, double &e, int numSteps)
+{
+    auto f = [&](const double (&x)[2], double (&out)[2]) {
+        const double v = sqrt(x[0]), rr = T.sr0 + T.sr1*v + T.sr2*x[0];
+        out[0] = 2*ds*(w - rr - G); out[1] = ds*rr;
+    };
+    const double h = 1.0/numSteps;
+    double y[2] = {b, e};
+    for (int s = 0; s < numSteps; s++) {
+        double k1[2], k2[2], k3[2], k4[2], yt[2];
+        f(y, k1);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + 0.5*h*k1[m];
+        f(yt, k2);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + 0.5*h*k2[m];
+        f(yt, k3);
+        for (int m = 0; m < 2; m++) yt[m] = y[m] + h*k3[m];
+        f(yt, k4);
+        for (int m = 0; m < 2; m++) y[m] += (h/6)*((k1[m] + 2*k2[m]) + (2*k3[m] + k4[m]));
+    }
+    b = y[0]; e = y[1];
+    return (isfinite(b) && isfinite(e) && b > 0) ? 0 : 1;
+}
+
 __global__ void rolling_kernel(IvTrain T, int n, const double *b0, const double *ds, const double *w, const double *grad, const double *curv,
                                double atol, double rtol, double *e_out, double *b_out, int *status)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
     double b = b0[k], e = 0.0;
-    const int st = iv_rolling(T, ds[k], w[k], iv_resistance(T, grad[k], curv[k]), b, e, atol, rtol);
+    /* (atol < 0 with rtol = 0: -atol equal steps of classic RK4 instead of the adaptive pair) */
+    const int st = (atol < 0) ? iv_rolling_rk(T, ds[k], w[k], iv_resistance(T, grad[k], curv[k]), b, e, (int)(-atol))
+                              : iv_rolling(T, ds[k], w[k], iv_resistance(T, grad[k], curv[k]), b, e, atol, rtol);
     e_out[k] = e; b_out[k] = b;
     if (status) status[k] = st;
 }
@@ -285,7 +311,9 @@ int msd_interval_integrate(int device, int n, const double *train5, int method, 
     for (int k = 0; k < n; k++)
         if (!(b0[k] > 0) || !(ds[k] > 0)) return iv_fail(MSD_E_INVALID, "velocitySquared and ds must be positive");
     Colloc K = {0, 0, 0, 0, nullptr, nullptr};
-    if (method == MSD_INTEGRATOR_ADAPTIVE || method == MSD_INTEGRATOR_ROLLING_RESISTANCE) {
+    if (method == MSD_INTEGRATOR_ROLLING_RESISTANCE && nparams == 2 && params[1] == 0 && params[0] <= -1 && params[0] >= -1000 && params[0] == (double)(int)params[0]) {
+        /* (-numSteps, 0): fixed steps of classic RK4 (solver='RK' of TrainIntegrator.initRollingResistance, train.py:428-432) */
+    } else if (method == MSD_INTEGRATOR_ADAPTIVE || method == MSD_INTEGRATOR_ROLLING_RESISTANCE) {
         if (nparams != 2 || !(params[0] > 0) || !(params[1] > 0)) return iv_fail(MSD_E_INVALID, "adaptive integrator needs (abstol, reltol) > 0");
     } else if (method == MSD_INTEGRATOR_COLLOCATION) {
         if (nparams < 4) return iv_fail(MSD_E_INVALID, "collocation integrator needs (order, numSteps, numApproxSteps, maxIter, C, D)");

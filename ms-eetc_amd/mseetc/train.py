@@ -323,15 +323,13 @@ class TrainIntegrator():
         return {'time': float(out['time'][0]), 'velSquared': float(out['velSquared'][0])}
 
     def initRollingResistance(self, solver='CVODES'):
-        "Integrator of the energy dissipated by the rolling resistance (train.py:416-442); only the adaptive one runs on the device."
+        "Integrator of the energy dissipated by the rolling resistance (train.py:416-442): 'CVODES' (adaptive pair at 1e-8 / 1e-6) or 'RK' (two steps of RK4)."
 
         if solver not in {'RK', 'CVODES'}:
             raise ValueError("Unknown solver!")
 
-        if solver != 'CVODES':
-            raise NotImplementedError("Only the adaptive integrator of the rolling resistance runs on the device.")
-
-        self._rollingParams = np.array([1e-8, 1e-6])     # train.py:436
+        # train.py:436 (tolerances of the CVODES call) / train.py:431 (casadi.simpleRK(fun, 2, 4): (-numSteps, 0) selects the fixed steps on the device)
+        self._rollingParams = np.array([1e-8, 1e-6]) if solver == 'CVODES' else np.array([-2.0, 0.0])
 
     def calcRollingResistance(self, velocity, ds, traction=0, pnBrake=0, gradient=0, curvature=0):
         "(specific energy [J/kg] lost to the rolling resistance over ds, velocity at the end of the interval) (train.py:445-454)."

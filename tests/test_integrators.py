@@ -202,6 +202,21 @@ def test_rolling_resistance_integration_vs_scipy_and_post_processing():
         assert abs(vEnd[k] - np.sqrt(ref.y[0, -1])) <= 1e-5*vEnd[k]
     one = integ.calcRollingResistance(float(v0[0]), float(ds[0]), float(f[0]), 0.0, float(grad[0]), 0.0)
     assert one[0] == loss[0] and one[1] == vEnd[0]
+    # solver='RK' (train.py:428-432: casadi.simpleRK(fun, 2, 4)): two steps of classic RK4 on (b, e) over the unit interval, restated in numpy
+    rk = TrainIntegrator(model, 'RK')
+    rk.initRollingResistance(solver='RK')
+    lossRK, vEndRK = rk.calcRollingResistance(v0, ds, f, 0.0, grad, 0.0)
+    for k in range(n):
+        G = model.resistance(grad[k], 0.0)
+        fun = lambda y: np.array([2*ds[k]*(f[k] - (model.sr0 + model.sr1*np.sqrt(y[0]) + model.sr2*y[0]) - G), ds[k]*(model.sr0 + model.sr1*np.sqrt(y[0]) + model.sr2*y[0])])
+        y = np.array([v0[k]**2, 0.0])
+        if v0[k]**2 + 2*ds[k]*(f[k] - 0.05 - abs(G)) < 9.0:
+            continue
+        for _ in range(2):
+            k1 = fun(y); k2 = fun(y + 0.25*k1); k3 = fun(y + 0.25*k2); k4 = fun(y + 0.5*k3)
+            y = y + (0.5/6)*(k1 + 2*k2 + 2*k3 + k4)
+        assert abs(lossRK[k] - y[1]) <= 1e-12*abs(y[1]) and abs(vEndRK[k] - np.sqrt(y[0])) <= 1e-12*vEndRK[k]
+        assert abs(lossRK[k] - loss[k]) <= 1e-3*loss[k]      # two RK4 steps against the adaptive pair
     # post-processing column: present, NaN in the last row, close to the mid-point estimate on a solved trajectory
     solver = casadiSolver(train, cases.track_00(), dict(numIntervals=100, maxIterations=500, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
     df, stats = solver.solve(1600.0)

@@ -259,6 +259,48 @@ def test_gpu_other_integrators_with_dynamic_losses_vs_oracle(method, io, integra
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('method,io,integration,combo', [('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2, 'dynamic'), ('CVODES', dict(), ADAPT, 'dynamic'),
+                                                          ('IRK', dict(order=2, numSteps=1, numApproxSteps=1), IRK2, 'integrate_losses')])
+def test_gpu_combined_options_beyond_255_intervals_on_the_streamed_kernel(method, io, integration, combo):
+    """
+    Round 4: the collocation / adaptive shooting integrators together with the dynamic loss model or with integrateLosses no longer stop at the 255
+    intervals of their LDS-resident kernels (msd_kernels_compose.hip): N = 300 runs on the streamed kernels of msd_kernels_stream4.hip (the
+    reference builds any option set at any N, simulations/table3.py:34).  Against the oracle, figure5.py's problem resp. the figure-10 train.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc.track import computeDiscretizationPoints
+    from mseetc.train import collocationTables
+    N = 300
+    if method == 'IRK':
+        oracle.set_collocation(*collocationTables(integration['order'], integration['collMethod']))
+    if combo == 'dynamic':
+        train, track = _dynamic_train(), cases.track_00(8500)
+        oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+        pts = computeDiscretizationPoints(track, N)
+        opts = dict(numIntervals=N, maxIterations=500, energyOptimal=True, minimumVelocity=1, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0))
+        opts.update(integration)
+        prob = oracle.pack_problem(train, pts, opts, 2, 0.0, 0.0, track.length)
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationMethod=method, integrationOptions=io), startingPoint='profile')
+        T, kw = [272.4726*1.15, 272.4726*1.25], dict(terminalVelocity=100/3.6, initialVelocity=1)
+    else:
+        train, track = cases.train_fig10(), cases.track_00()
+        both = dict(integration); both['integrateLosses'] = True
+        prob = cases.oracle_problem(train, track, N, numSteps=io.get('numSteps', 1), numApproxSteps=io.get('numApproxSteps', 0), integration=both)
+        solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationMethod=method, integrationOptions=io, integrateLosses=True), startingPoint='profile')
+        T, kw = [1600.0], {}
+    assert solver.problem.geometry() == (512, 2)
+    res = solver.solveBatch(T, **kw)
+    assert np.all(res['status'] == 0), res['status']
+    for k, t in enumerate(T):
+        ref = oracle.solve(prob, prob.scenario(t, **kw), start='profile')
+        assert ref['stats']['STATUS'] == 0
+        assert abs(res['cost'][k] - ref['stats']['OBJ']) <= 1e-8*abs(ref['stats']['OBJ'])
+        assert np.max(np.abs(res['z'][k] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+        assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
+    solver.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('what', ['irk', 'cvodes', 'integrate_losses', 'dynamic'])
 def test_gpu_other_transcriptions_on_the_streamed_kernel(what):
     """
@@ -362,7 +404,7 @@ def test_gpu_other_integrators_surface_and_limits():
     with pytest.raises(DeviceError):
         casadiSolver(train, track, dict(numIntervals=1100, integrationMethod='CVODES')).solve(1541)      # beyond the streamed kernels of the other integrators
     with pytest.raises(DeviceError):
-        casadiSolver(train, track, dict(numIntervals=300, integrateLosses=True, integrationMethod='IRK')).solve(1541)      # that combination: up to 255 intervals
+        casadiSolver(train, track, dict(numIntervals=1100, integrateLosses=True, integrationMethod='IRK')).solve(1541)      # that combination: up to 1023 intervals too (round 4; 255 before)
     with pytest.raises(NotImplementedError):
         from mseetc.efficiency import totalLossesFunction
         dyn = cases.train_default(); dyn.forceMinPn = 0; dyn.powerLosses = totalLossesFunction(dyn)
