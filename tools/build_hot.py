@@ -24,7 +24,7 @@ def main():
     obj = out / ('obj_' + tag)
     obj.mkdir(parents=True, exist_ok=True)
     csrc = entry.PKG / 'csrc'
-    flags = [f for f in entry.HIP_FLAGS if f != '-shared'] + entry.SOLVE_KERNEL_FLAGS + defs + extra
+    flags = [f for f in entry.HIP_FLAGS if f != '-shared'] + ([] if '--no-solve-flags' in sys.argv else entry.SOLVE_KERNEL_FLAGS) + defs + extra
     t0 = time.time()
     subprocess.run([entry.HIPCC] + flags + ['-c', '-o', str(obj / (unit + '.o')), str(csrc / unit)], check=True)
     prod = entry.PKG / 'lib' / 'obj'
