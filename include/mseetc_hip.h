@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 5
+#define MSD_ABI_VERSION 6
 
 /* error codes */
 #define MSD_OK 0
@@ -68,6 +68,7 @@ enum {
     MSD_ST_CYC_KKT,      /* ... of which inside the serial stage recursion of the KKT solves (fallback path)  */
     MSD_ST_N_FALLBACK,   /* KKT solves that fell back from the stage-parallel scan to the serial sweep        */
     MSD_ST_N_RESTO,      /* restoration phases entered                                                        */
+    MSD_ST_N_WATCHDOG,   /* watchdog procedures started (IPOPT: watchdog_shortened_iter_trigger = 10)          */
     MSD_ST_COUNT
 };
 
@@ -117,7 +118,8 @@ typedef struct msd_problem_desc {
                               * over the running time of the interval; constant efficiencies (loss_kind 1), 'RK' shooting                          */
     int no_restoration;      /* 1: no feasibility restoration phase -- a solve whose line search breaks down ends with MSD_STATUS_LINESEARCH (after the
                               * restart from the other starting point), like ABI 4.  0 (default): IPOPT's behaviour                                         */
-    int reserved_i[1];
+    int watchdog_trigger;    /* IPOPT's watchdog_shortened_iter_trigger (the reference leaves it at its default, ocp.py:290): 0 = that default, 10 successive
+                              * shortened iterations start the watchdog procedure; < 0: no watchdog procedure; other values: tests                         */
     double sr0, sr1, sr2;    /* specific Davis coefficients (train.py:181-183)                */
     double g, rho;
     double f_max, f_min;     /* bounds of Fel (ocp.py:175-176; f_min = 0 without rg brake)    */
@@ -192,8 +194,8 @@ int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per
  * the first pass hands over through a list in device memory -- in the reference all of that is inside the one call of IPOPT (ocp.py:359).
  * Telemetry, never reset: counts[0] scenarios handed over since the handle was created, counts[1 + why] by reason (0 no fused start for the
  * scenario, 1 wrong inertia or scan breakdown, 2 tiny step, 3 rejected first trial point with a second-order correction due, 4 line search
- * broke down, 5 breakdown that asks for the second attempt).  Waits for the handle's stream.  n <= 7 entries are written (zeros for a
- * handle whose kernels are not split).
+ * broke down, 5 breakdown that asks for the second attempt, 6 ten shortened iterations in a row: the watchdog procedure is due).  Waits for the
+ * handle's stream.  n <= 8 entries are written (zeros for a handle whose kernels are not split).
  */
 int msd_problem_follow_counts(msd_handle h, int *counts, int n);
 

@@ -150,6 +150,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
     P.coll = nullptr;
     P.resto = d->no_restoration ? 0 : 1;
+    P.wdTrigger = d->watchdog_trigger == 0 ? 10 : d->watchdog_trigger;      /* IPOPT's default */
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
 
     int per_cu = 0, cus = 0;
@@ -170,6 +171,17 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
         pl.NT2 = 64; pl.SPT2 = 2;
         pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles(N, 128, wide, geo.xch, geo.red);
     }
+    size_t work2 = 0;
+    if (!geo.fn2 && !geo.stream && !dyn && !intloss && (gen || geo.NT == 320)) {
+        /* static loss rows, collocation / adaptive shooting or the five-wave geometry: these kernels are first-pass kernels without the restoration
+         * phase; a scenario whose line search breaks down is followed up by the streamed kernel of the family, which has it (msd_kernel.hpp:
+         * FAMILY_HAS_RESTO).  The follow-up restarts the scenario, so the two geometries need not agree */
+        const msd::Geometry g2 = gen ? msd::pick_stream_geometry_general(N) : msd::pick_stream_geometry_static(N);
+        if (!g2.fn) return fail(MSD_E_UNSUPPORTED, "no follow-up kernel for numIntervals = " + std::to_string(N));
+        geo.fn2 = g2.fn; pl.NT2 = g2.NT; pl.SPT2 = g2.SPT;
+        pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles_stream();
+        work2 = msd::stream_doubles(N, g2.NT*g2.SPT, wide);
+    }
     if (geo.fn2) {
         rc = kernel_limits(device, (const void *)geo.fn2, pl.NT2, pl.lds_bytes2, &per_cu);
         if (rc != MSD_OK) return rc;
@@ -182,7 +194,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
         pl.max_grid_lsq = per_cu*cus;
     }
     pl.fused_family = geo.fn2 != nullptr && geo.xch == msd::XCH_FAST;
-    pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : msd::work_doubles(std::max(geo.NT*geo.SPT, pl.NT2*pl.SPT2));
+    pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : std::max(work2, msd::work_doubles(std::max(geo.NT*geo.SPT, work2 ? 0 : pl.NT2*pl.SPT2)));
     pl.nz = (4 + P.withPn)*N + 2; pl.nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
     pl.kernel = geo.fn; pl.kernel2 = geo.fn2; pl.kernel_lsq = geo.fn_lsq;
     return MSD_OK;
@@ -451,7 +463,7 @@ int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per
 int msd_problem_follow_counts(msd_handle h, int *counts, int n)
 {
     if (!h || !counts || n < 1) return fail(MSD_E_INVALID, "bad argument");
-    if (n > 7 && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) n = 7;      /* (debugging aid: the list's entries behind the counters) */
+    if (n > 8 && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) n = 8;      /* (debugging aid: the list's entries behind the counters) */
     if (n > (int)h->cap_follow - msd::FOLLOW_TOTAL && h->d_follow) n = (int)h->cap_follow - msd::FOLLOW_TOTAL;
     for (int k = 0; k < n; k++) counts[k] = 0;
     HIP_TRY(hipSetDevice(h->device));

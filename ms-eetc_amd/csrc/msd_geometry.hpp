@@ -58,7 +58,7 @@ template <int DYN> inline Geometry pick_geometry_t(int N)
      * six exchange arrays of 576 slots still fit the LDS of a compute unit.  (Round 3 ran these horizons on five waves of two nodes per lane with
      * half a register file each: 2 253 spilled registers, 25 ms per 1024 solves at N = 560 against 6.2 ms at N = 511.) */
     if (DYN == LOSS_STATIC && nodes <= 576) return {192, 3, solve_kernel<192, 3, 1, DYN>};
-    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN>};
+    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN, false, false, 0, DYN == LOSS_STATIC ? 1 : 0>};      /* (static loss rows: a first-pass kernel, the streamed one follows up -- the restoration phase lives there) */
     return {0, 0, nullptr};
 }
 

@@ -98,6 +98,7 @@ struct DevProb {
     double intAtol, intRtol; /* OptionsCVODES.absTol, .relTol */
     const double *coll;      /* C[(collD+1)^2], D[collD+1] of casadi.simpleIRK */
     int resto;               /* feasibility restoration phase where the line search breaks down (IPOPT's behaviour; msd_resto.hpp) */
+    int wdTrigger;           /* shortened iterations in a row that start the watchdog procedure (IPOPT: 10; <= 0: never) */
     /* split launches (solve_kernel's PART): the first-pass kernel appends the scenarios it does not finish to this list, the follow-up kernel drains it.
      * follow[0] entries written, [1] entries taken, [2] follow-up workgroups that found the list empty (the last one zeroes the three for the next
      * launch of the handle), [FOLLOW_HDR + 2k] scenario, [FOLLOW_HDR + 2k + 1] iterations already spent on it (>= 0: its first attempt broke down,
@@ -573,12 +574,15 @@ constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_
  * the restoration problem (2 fields >= 2 FILT_CAP doubles), one field of scalars handed between the two iterations and five fields (>= 320
  * doubles) for the dense temporaries of riccati_resto -- on the stack they would size the scratch memory of every launch of the kernel */
 constexpr int W_SC = 72, W_RN = 74, W_RP = 81, W_RZN = 88, W_RZP = 95, W_RDN = 102, W_RDP = 109, W_RDZN = 116, W_RDZP = 123, W_XR = 130, W_SGR = 135,
-              W_OZL = 140, W_OZU = 145, W_OZLS = 150, W_OZUS = 155, W_RD = 160, W_DNU = 162, W_RFILT = 167, W_SCAL = 169, W_RTMP = 170, W_FIELDS = 175;
+              W_OZL = 140, W_OZU = 145, W_OZLS = 150, W_OZUS = 155, W_RD = 160, W_DNU = 162, W_RFILT = 167, W_SCAL = 169, W_RTMP = 170;
+/* behind that: the reference point of the watchdog procedure (Solver::watchdog_store): iterate (37 fields), search direction (7 + 5) */
+constexpr int W_WD = 175, W_WD_Z = 5, W_WD_ZU = 10, W_WD_SG = 15, W_WD_NU = 20, W_WD_ZLS = 25, W_WD_ZUS = 30, W_WD_LAM = 35, W_WD_DIR = 37, W_WD_DSG = 44,
+              W_FIELDS = 224;
 __host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
-/* work area of a workgroup of the streamed (long-horizon) kernel: node fields, stage blocks, six exchange arrays */
+/* work area of a workgroup of the streamed (long-horizon) kernel: node fields (the same fields as above), stage blocks, six exchange arrays */
 __host__ __device__ constexpr size_t stream_doubles(int N, int node_slots, bool dyn)
 {
-    return (size_t)W_FIELDS_ITERATE*node_slots + (size_t)(dyn ? 31 : 27)*(N + 1) + 6*(size_t)node_slots;
+    return (size_t)W_FIELDS*node_slots + (size_t)(dyn ? 31 : 27)*(N + 1) + 6*(size_t)node_slots;
 }
 
 template <int NS, bool STREAM>
@@ -2981,10 +2985,65 @@ struct Solver {
 #ifndef MSD_RESTO
 #define MSD_RESTO 1      /* 0: kernels without the restoration phase (A/B builds) */
 #endif
-    static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && !STREAM && !GEN && NT <= 256;
     static constexpr bool FIRST = PART == 1 || PART == 3;
+    /* static loss rows: the kernels of up to four waves whose horizon fits the LDS hold the phase themselves (in their follow-up kernels), so do the
+     * streamed kernels (N <= 5119); the other families with static loss rows -- collocation / adaptive shooting, 320 x 2 -- are compiled as first-pass
+     * kernels (PART = 1) and followed up by the streamed kernel of their family (msd_api.hip: make_plan).  Not: the dynamic and the integrated loss rows */
+    static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && (STREAM || FIRST || (!GEN && NT <= 256));
     static constexpr bool HAS_RESTO = FAMILY_HAS_RESTO && !FIRST;      /* (a first-pass kernel leaves the phase to its follow-up kernel) */
     static constexpr int STATUS_RESTO = -101;
+
+    /* ---- watchdog procedure (IPOPT: IpBacktrackingLineSearch::StartWatchDog / StopWatchDog, FilterLSAcceptor::StartWatchDog / StopWatchDog; the options
+     * the reference leaves at their defaults, ocp.py:290: watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3).  Restated step for step in
+     * oracle/ms_oracle.c (solve_core; the header there says what it was restated from).  The general iteration runs it; the fused iteration only counts
+     * the shortened iterations and hands the scenario over when the procedure would start.  Reference point: fields W_WD of the work area ---- */
+#ifndef MSD_WATCHDOG
+#define MSD_WATCHDOG 1
+#endif
+    static constexpr int WD_TRIGGER_DEFAULT = 10, WD_TRIAL_MAX = 3;
+    __device__ __forceinline__ void watchdog_store()
+    {
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const NodeT &nd = n[j];
+            if (!nd.node()) continue;
+            const double *s = c.S + nd.i*S_STRIDE;
+#pragma unroll
+            for (int k = 0; k < NV; k++) { wf(W_WD + k, nd.i) = nd.x[k]; wf(W_WD + W_WD_Z + k, nd.i) = nd.zL[k]; wf(W_WD + W_WD_ZU + k, nd.i) = nd.zU[k]; }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                wf(W_WD + W_WD_SG + r, nd.i) = nd.sg[r]; wf(W_WD + W_WD_NU + r, nd.i) = nd.nu[r]; wf(W_WD + W_WD_ZLS + r, nd.i) = nd.zLs[r];
+                wf(W_WD + W_WD_ZUS + r, nd.i) = nd.zUs[r]; wf(W_WD + W_WD_DSG + r, nd.i) = nd.dsg[r];
+            }
+            wf(W_WD + W_WD_LAM, nd.i) = nd.lam[0]; wf(W_WD + W_WD_LAM + 1, nd.i) = nd.lam[1];
+            wf(W_WD + W_WD_DIR + 0, nd.i) = s[S_DT]; wf(W_WD + W_WD_DIR + 1, nd.i) = s[S_DB]; wf(W_WD + W_WD_DIR + 2, nd.i) = s[S_DF]; wf(W_WD + W_WD_DIR + 3, nd.i) = s[S_DP];
+            wf(W_WD + W_WD_DIR + 4, nd.i) = s[S_DS]; wf(W_WD + W_WD_DIR + 5, nd.i) = s[S_LT]; wf(W_WD + W_WD_DIR + 6, nd.i) = s[S_LB];
+        }
+    }
+    /* StopWatchDog: the stored iterate and direction back in place, derivatives and residuals of that point */
+    __device__ __forceinline__ void watchdog_restore()
+    {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            NodeT &nd = n[j];
+            if (!nd.node()) continue;
+            double *s = c.S + nd.i*S_STRIDE;
+#pragma unroll
+            for (int k = 0; k < NV; k++) { nd.x[k] = wf(W_WD + k, nd.i); nd.zL[k] = wf(W_WD + W_WD_Z + k, nd.i); nd.zU[k] = wf(W_WD + W_WD_ZU + k, nd.i); }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                nd.sg[r] = wf(W_WD + W_WD_SG + r, nd.i); nd.nu[r] = wf(W_WD + W_WD_NU + r, nd.i); nd.zLs[r] = wf(W_WD + W_WD_ZLS + r, nd.i);
+                nd.zUs[r] = wf(W_WD + W_WD_ZUS + r, nd.i); nd.dsg[r] = wf(W_WD + W_WD_DSG + r, nd.i);
+            }
+            nd.lam[0] = wf(W_WD + W_WD_LAM, nd.i); nd.lam[1] = wf(W_WD + W_WD_LAM + 1, nd.i);
+            s[S_DT] = wf(W_WD + W_WD_DIR + 0, nd.i); s[S_DB] = wf(W_WD + W_WD_DIR + 1, nd.i); s[S_DF] = wf(W_WD + W_WD_DIR + 2, nd.i); s[S_DP] = wf(W_WD + W_WD_DIR + 3, nd.i);
+            s[S_DS] = wf(W_WD + W_WD_DIR + 4, nd.i); s[S_LT] = wf(W_WD + W_WD_DIR + 5, nd.i); s[S_LB] = wf(W_WD + W_WD_DIR + 6, nd.i);
+        }
+        __syncthreads();
+        evaluate_current();
+        __syncthreads();
+    }
 
     template <bool FL>
     __device__ __forceinline__ int run(const double *scen, const double *guess, const double *dual_in, int startKind, int iter_offset, int &iters_out,
@@ -3022,6 +3081,7 @@ struct Solver {
             if (ival) fl |= F_ON_S;
             nd.flags = fl;
             nd.ubB = bm + K_BOUND_RELAX*fmax(1.0, fabs(bm));
+            if (HAS_RESTO && !FL && resume) continue;      /* (the iterate is the one the restoration phase left: in the work area, which is where a streamed kernel's fields live) */
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
             nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = withPn() ? -0.1 : 0.0; nd.x[VS] = 1;
@@ -3194,6 +3254,9 @@ struct Solver {
         double delta_last = 0, theta_max = 0, theta_min = 0;
         int status = MSD_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
         int n_reg = 0, n_soc = 0, n_back = 0, n_resto = 0, iter_first = 0, forced = 0;
+        int wd_short = 0, wd_trial = 0, n_wd = 0;      /* watchdog: successive shortened iterations, trial iterations of a running procedure, procedures started */
+        bool in_wd = false;
+        double wd_theta = 0, wd_phi = 0, wd_gphid = 0, wd_dw = 0;
         Err E;
         double alpha_pr = 0, alpha_du = 0, dnorm = 0, objv = 0;
         const double mu_floor = fmin(P.tol, 1e-4)/(K_EPS + 1.0);
@@ -3208,6 +3271,7 @@ struct Solver {
                 theta_max = uni(wf(W_SCAL, SC_THETA_MAX)); theta_min = uni(wf(W_SCAL, SC_THETA_MIN)); delta_last = uni(wf(W_SCAL, SC_DELTA_LAST));
                 n_reg = (int)uni(wf(W_SCAL, SC_N_REG)); n_soc = (int)uni(wf(W_SCAL, SC_N_SOC)); n_back = (int)uni(wf(W_SCAL, SC_N_BACK));
                 n_resto = (int)uni(wf(W_SCAL, SC_N_RESTO)); forced = (int)uni(wf(W_SCAL, SC_FORCED));
+                wd_short = (int)uni(wf(W_SCAL, SC_WD_SHORT)); n_wd = (int)uni(wf(W_SCAL, SC_N_WD));
             }
         }
 
@@ -3254,9 +3318,9 @@ struct Solver {
                     if (nm >= mu) break;
                     mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = true;
                 }
-                if (changed) nfilt = 0;
+                if (changed) { nfilt = 0; in_wd = false; wd_short = 0; }      /* (a new barrier problem: filter and watchdog start afresh) */
             }
-            const double theta = E.theta, phi = E.obj - mu*E.L + K_D*mu*E.D;
+            double theta = E.theta, phi = E.obj - mu*E.L + K_D*mu*E.D;
 
             if constexpr (FL) {
                 c.mark(PH_OTHER); phase_fence(PH_OTHER);
@@ -3271,6 +3335,7 @@ struct Solver {
                 post_direction(mu, tau, gphid, dnorm, tiny_step, amax, alpha_du);
                 c.mark(PH_GPHID); phase_fence(PH_GPHID);
                 if (tiny_step) { status = STATUS_GENERAL; why_general = 2; break; }
+                if (MSD_WATCHDOG && P.wdTrigger > 0 && wd_short >= P.wdTrigger) { status = STATUS_GENERAL; why_general = 6; break; }      /* the watchdog procedure would start here */
                 tiny_count = 0;
                 double amin = G_THETA;
                 if (gphid < 0) {
@@ -3281,7 +3346,8 @@ struct Solver {
                 double alpha = amax;
                 bool accepted = false, ftype_armijo = false, general = false;
                 Err T = E;
-                for (int ls = 0;; ls++) {
+                int ls = 0;
+                for (;; ls++) {
                     double ph_t; bool okt;
                     merit_fast(alpha, mu, T, ph_t, okt);
                     bool ftype = false;
@@ -3304,6 +3370,7 @@ struct Solver {
                 if (general) { status = STATUS_GENERAL; why_general = 3; break; }
                 if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; why_general = 4; break; }      /* (the general iteration has the restoration phase) */
                 alpha_pr = alpha;
+                if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (shortened iterations: what starts the watchdog) */
                 c.mark(PH_MERIT); phase_fence(PH_MERIT);
                 if (!ftype_armijo && nfilt < FILT_CAP) {      /* filter augmentation (W&B eq. (22)) */
                     __syncthreads();
@@ -3329,8 +3396,13 @@ struct Solver {
             if (!ok) { status = MSD_STATUS_REGULARIZATION; break; }
             if (dw > 0) delta_last = dw;
 
-            /* directional derivative of the barrier function, step norms */
-            double gphid, amax;
+            /* directional derivative of the barrier function, step norms; line search.  The loop is gone round a second time when the watchdog procedure
+             * puts its reference point back: the stored direction is measured again at the stored iterate */
+            double gphid = 0, amax = 1.0, alpha = 0, th_ref = theta, ph_ref = phi, gd_ref = 0;
+            bool tiny = false, accepted = false, ftype_armijo = false, skip_first = false, wd_forced = false, quit_tiny = false, not_tiny = false;
+            int ls = 0;
+#pragma unroll 1
+            for (;;) {
             bool tiny_step;
             {
                 double gd = 0, dn = 0, rel = -1.0, rp = 0, rd = 0;
@@ -3404,38 +3476,53 @@ struct Solver {
             }
             c.mark(PH_GPHID); phase_fence(PH_GPHID);
 
-            const bool tiny = tiny_step;
-            double alpha = amax;
-            bool accepted = false, ftype_armijo = false;
+            tiny = tiny_step && !not_tiny;
+            if (MSD_WATCHDOG && in_wd && tiny) {
+                /* a tiny step ends a running watchdog procedure: everything resumes from the stored point with the stored direction */
+                watchdog_restore();
+                in_wd = false; wd_short = 0; dw = wd_dw; theta = wd_theta; phi = wd_phi; not_tiny = true;
+                continue;
+            }
+            if (MSD_WATCHDOG && P.wdTrigger > 0 && !in_wd && !tiny && wd_short >= P.wdTrigger) {
+                watchdog_store();
+                wd_theta = theta; wd_phi = phi; wd_gphid = gphid; wd_dw = dw; wd_trial = 0; in_wd = true; n_wd++;
+            }
+            alpha = amax; accepted = false;
             if (tiny) {
                 accepted = true;
-                if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { status = MSD_STATUS_TINY_STEP; break; }
+                if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { quit_tiny = true; break; }
             } else tiny_count = 0;
 
+            /* reference point of the acceptance tests: the current one, or the watchdog's */
+            th_ref = in_wd ? wd_theta : theta; ph_ref = in_wd ? wd_phi : phi; gd_ref = in_wd ? wd_gphid : gphid;
             double amin = G_THETA;
-            if (gphid < 0) {
-                amin = fmin(amin, G_PHI*theta/(-gphid));
-                if (theta <= theta_min) amin = fmin(amin, K_DELTA*hpow(theta, S_THETA)/hpow(-gphid, S_PHI));
+            if (gd_ref < 0) {
+                amin = fmin(amin, G_PHI*th_ref/(-gd_ref));
+                if (th_ref <= theta_min) amin = fmin(amin, K_DELTA*hpow(th_ref, S_THETA)/hpow(-gd_ref, S_PHI));
             }
             amin *= ALPHA_MIN_FRAC;
 
-            int ls = 0;
+            if (skip_first) alpha = 0.5*amax;
+            ls = 0;
+            bool okt_last = true;
             while (!accepted) {
                 double th_t, ph_t; bool okt;
                 merit(alpha, mu, th_t, ph_t, okt);
+                okt_last = okt;
                 /* switching condition (W&B eq. (19)): single-precision powers decide unless the two sides are within 1e-4 of each other */
                 bool ftype = false;
-                if (gphid < 0) {
-                    double lhs = alpha*hpow(-gphid, S_PHI), rhs = K_DELTA*hpow(theta, S_THETA);
-                    if (fabs(lhs - rhs) <= 1e-4*fmax(lhs, rhs)) { lhs = alpha*pow(-gphid, S_PHI); rhs = K_DELTA*pow(theta, S_THETA); }
+                if (gd_ref < 0) {
+                    double lhs = alpha*hpow(-gd_ref, S_PHI), rhs = K_DELTA*hpow(th_ref, S_THETA);
+                    if (fabs(lhs - rhs) <= 1e-4*fmax(lhs, rhs)) { lhs = alpha*pow(-gd_ref, S_PHI); rhs = K_DELTA*pow(th_ref, S_THETA); }
                     ftype = lhs > rhs;
                 }
-                if (acceptable(okt, th_t, ph_t, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
-                    accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
+                if (acceptable(okt, th_t, ph_t, th_ref, ph_ref, alpha, gd_ref, ftype, theta_max, theta_min, nfilt)) {
+                    accepted = true; ftype_armijo = ftype && cmp_le(ph_t - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref);
                     break;
                 }
+                if (MSD_WATCHDOG && in_wd) break;      /* only the full step is tried while the watchdog procedure runs */
                 /* second-order correction (W&B section 2.4): rare, kept out of the hot path */
-                if (ls == 0 && okt && th_t >= theta) {
+                if (ls == 0 && !skip_first && okt && th_t >= th_ref) {
                     double th_prev = th_t, alpha_soc = alpha; int nsoc = 0;
                     while (nsoc < P_MAX_SOC) {
                         /* c_soc = alpha_soc c_soc + c(trial) */
@@ -3454,8 +3541,8 @@ struct Solver {
                         double th_s, ph_s; bool oks;
                         merit(alpha_soc, mu, th_s, ph_s, oks);
                         nsoc++; n_soc++;
-                        if (acceptable(oks, th_s, ph_s, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
-                            accepted = true; ftype_armijo = ftype && cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
+                        if (acceptable(oks, th_s, ph_s, th_ref, ph_ref, alpha, gd_ref, ftype, theta_max, theta_min, nfilt)) {
+                            accepted = true; ftype_armijo = ftype && cmp_le(ph_s - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref);
                             alpha = alpha_soc; alpha_du = adu_soc;
                             break;
                         }
@@ -3472,6 +3559,15 @@ struct Solver {
                 alpha *= 0.5; ls++; n_back++;
                 if (alpha < amin) break;
             }
+            if (!(MSD_WATCHDOG && in_wd) || tiny) break;
+            if (accepted) { in_wd = false; break; }      /* the procedure has succeeded: the filter gets the reference point below */
+            wd_trial++;
+            if (okt_last && wd_trial <= WD_TRIAL_MAX) { accepted = true; wd_forced = true; break; }      /* taken although the filter does not accept it */
+            /* no success: back to the stored point, ordinary line search on the stored direction from half the maximal step */
+            watchdog_restore();
+            in_wd = false; wd_short = 0; dw = wd_dw; theta = wd_theta; phi = wd_phi; skip_first = true;
+            }
+            if (quit_tiny) { status = MSD_STATUS_TINY_STEP; break; }
             if (!accepted) {
                 /* the step became too small: feasibility restoration (IpBacktrackingLineSearch), unless the point is almost feasible
                  * (resto_failure_feasibility_threshold = 100 tol).  The current point enters the filter; the iterate and the scalars
@@ -3486,7 +3582,7 @@ struct Solver {
                         wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = theta; wf(W_SCAL, SC_PHI) = phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
                         wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
                         wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + 1;
-                        wf(W_SCAL, SC_FORCED) = 0;
+                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd;
                     }
                     __syncthreads();
                     status = STATUS_RESTO; break;
@@ -3494,12 +3590,13 @@ struct Solver {
                 status = MSD_STATUS_LINESEARCH; break;
             }
             alpha_pr = alpha;
+            if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (n_steps == 0 / n_steps > 1 of IpBacktrackingLineSearch: shortened iterations) */
             c.mark(PH_MERIT); phase_fence(PH_MERIT);
 
-            /* filter augmentation (W&B eq. (22)) */
-            if (!tiny && !ftype_armijo && nfilt < FILT_CAP) {
+            /* filter augmentation (W&B eq. (22)), with the reference point of the tests */
+            if (!tiny && !wd_forced && !ftype_armijo && nfilt < FILT_CAP) {
                 __syncthreads();
-                if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; }
+                if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*th_ref; c.filt[2*nfilt + 1] = ph_ref - G_PHI*th_ref; }
                 nfilt++;
                 __syncthreads();
             }
@@ -3584,7 +3681,7 @@ struct Solver {
             stats[MSD_ST_STATUS] = status; stats[MSD_ST_ITERS] = iter + iter_offset; stats[MSD_ST_OBJ] = objv;
             stats[MSD_ST_KKT] = total_err(E, 0.0); stats[MSD_ST_MU] = mu; stats[MSD_ST_DUAL_INF] = E.dual/U.sf;
             stats[MSD_ST_CONSTR_VIOL] = E.primal_u; stats[MSD_ST_COMPL] = compl_err(E, 0.0)/U.sf;
-            stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back; stats[MSD_ST_N_RESTO] = n_resto;
+            stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back; stats[MSD_ST_N_RESTO] = n_resto; stats[MSD_ST_N_WATCHDOG] = n_wd;
             stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1]; stats[MSD_ST_N_FALLBACK] = c.misc[MISC_FALLBACKS];
             /* phase telemetry of the logged scenario: the last two rows of the history buffer */
             if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
@@ -3639,7 +3736,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     if (STREAM) {
         /* long horizons (N > 560): stage blocks and exchange arrays behind the node fields in the workgroup's work area (device
          * memory, L2-resident); LDS keeps the filter, the reduction scratch and the uniform records */
-        c.S = wg_work + (size_t)W_FIELDS_ITERATE*NS;
+        c.S = wg_work + (size_t)W_FIELDS*NS;
         c.xt = c.S + stage_stride(DYN)*(P.N + 1);
         c.filt = lds;
     } else {

@@ -14,9 +14,9 @@ Geometry pick_geometry_general_long(int N)
 #ifdef MSD_MINIMAL_GEOMETRIES
     return {0, 0, nullptr};
 #endif
-    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, false, false, true>};
-    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, false, false, true>};
-    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, false, false, true>};
+    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, LOSS_STATIC, false, true, 0, 1>};
+    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, LOSS_STATIC, false, true, 0, 1>};
+    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, LOSS_STATIC, false, true, 0, 1>};
     return {0, 0, nullptr};
 }
 }

@@ -14,9 +14,9 @@ import numpy as np
 
 LIB_PATH = Path(os.environ.get('MSD_LIB', Path(__file__).resolve().parent.parent / 'lib' / 'libmseetc_hip.so'))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 INTEGRATOR_ADAPTIVE, INTEGRATOR_COLLOCATION = 1, 2     # MSD_INTEGRATOR_* (also the methods of msd_interval_integrate)
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, N_RESTO=14, COUNT=15)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, CYC_TOTAL=11, CYC_KKT=12, N_FALLBACK=13, N_RESTO=14, N_WATCHDOG=15, COUNT=16)
 # (ITERS counts both attempts of a solve that was repeated from the other starting point: after a breakdown, or after the iteration limit behind a
 #  restoration phase -- it can reach twice max_iterations then)
 SC_COUNT = 4
@@ -41,7 +41,7 @@ class ProblemDesc(ctypes.Structure):
                 ('has_power_rows', ctypes.c_int), ('energy_optimal', ctypes.c_int), ('num_steps', ctypes.c_int),
                 ('num_approx_steps', ctypes.c_int), ('loss_kind', ctypes.c_int), ('max_iterations', ctypes.c_int),
                 ('start_kind', ctypes.c_int), ('integrator', ctypes.c_int), ('coll_degree', ctypes.c_int), ('newton_iterations', ctypes.c_int),
-                ('integrate_losses', ctypes.c_int), ('no_restoration', ctypes.c_int), ('reserved_i', ctypes.c_int*1),
+                ('integrate_losses', ctypes.c_int), ('no_restoration', ctypes.c_int), ('watchdog_trigger', ctypes.c_int),
                 ('sr0', ctypes.c_double), ('sr1', ctypes.c_double), ('sr2', ctypes.c_double), ('g', ctypes.c_double), ('rho', ctypes.c_double),
                 ('f_max', ctypes.c_double), ('f_min', ctypes.c_double), ('f_min_pn', ctypes.c_double),
                 ('pw_upper', ctypes.c_double), ('pw_lower', ctypes.c_double), ('acc_min', ctypes.c_double), ('acc_max', ctypes.c_double),
@@ -153,7 +153,7 @@ START = dict(reference=0, profile=1)   # MSD_START_*
 
 def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, lossKind, maxIterations, sr, g, rho, fmax, fmin, fminPn,
               pwUpper, pwLower, accMin, accMax, ct, cr, vminSq, objDen, tol, ds, grad, curv, bmax, lossTable=None, start='reference',
-              integrator=None, integrateLosses=False, restoration=True):
+              integrator=None, integrateLosses=False, restoration=True, watchdogTrigger=0):
     """
     Fill a ProblemDesc; the numpy arrays are kept alive on the returned object.  integrator: None ('RK'), ('CVODES', absTol, relTol) or
     ('IRK', order, maxIter, C, D) with the tables of mseetc.train.collocationTables.  integrateLosses: ocp.py:28,231-241.
@@ -165,6 +165,7 @@ def make_desc(N, withPn, hasPower, energyOptimal, numSteps, numApproxSteps, loss
     d.num_steps, d.num_approx_steps, d.loss_kind, d.max_iterations = int(numSteps), int(numApproxSteps), int(lossKind), int(maxIterations)
     d.start_kind = START[start]
     d.no_restoration = 0 if restoration else 1
+    d.watchdog_trigger = int(watchdogTrigger)      # 0: IPOPT's default (10 shortened iterations in a row)
     d.sr0, d.sr1, d.sr2 = sr
     d.g, d.rho = g, rho
     d.f_max, d.f_min, d.f_min_pn = fmax, fmin, fminPn
@@ -386,9 +387,9 @@ class DeviceProblem():
         return float(ms.value), int(n.value)
 
     def follow_counts(self):
-        "Scenarios the first-pass kernel handed to the follow-up kernel so far: (total, by reason[6]) -- msd_problem_follow_counts."
-        out = (ctypes.c_int*7)()
-        _check(lib().msd_problem_follow_counts(self._h, out, 7))
+        "Scenarios the first-pass kernel handed to the follow-up kernel so far: (total, by reason[7]) -- msd_problem_follow_counts."
+        out = (ctypes.c_int*8)()
+        _check(lib().msd_problem_follow_counts(self._h, out, 8))
         return int(out[0]), [int(v) for v in out[1:]]
 
     def timer_begin(self):

@@ -72,7 +72,7 @@ class casadiSolver():
 
     TOLERANCE = 1e-8   # IPOPT default `tol`; the reference passes only max_iter (ocp.py:290)
 
-    def __init__(self, train, track, optsDict={}, device=0, startingPoint='profile', restoration=True):
+    def __init__(self, train, track, optsDict={}, device=0, startingPoint='profile', restoration=True, watchdogTrigger=0):
         """
         Same arguments as the reference (ocp.py:79) plus two that have no counterpart there: `device` (GPU index) and
         `startingPoint`: 'reference' starts every solve from the reference's point (ocp.py:325-339), 'profile' (default)
@@ -89,6 +89,7 @@ class casadiSolver():
 
         self.startingPoint = startingPoint
         self.restoration = bool(restoration)
+        self.watchdogTrigger = int(watchdogTrigger)      # IPOPT's watchdog_shortened_iter_trigger; 0 = its default (the reference's setting), < 0 = off
         self._optsDict = dict(optsDict)
 
         track.checkFields()
@@ -173,7 +174,7 @@ class casadiSolver():
             abs(pwUpper), abs(pwLower), accMin, accMax, ct, cr, float(opts.minimumVelocity)**2, scaling, self.TOLERANCE,
             self.steps, self.points['Gradient [permil]'].values[:N]/1e3, self.points['Curvature [1/m]'].values[:N], bmax,
             lossTable=train.lossesCallable().parameters(totalMass) if lossKind == LOSS_DYNAMIC else None, start=startingPoint, integrator=integrator,
-            integrateLosses=integrateLosses, restoration=restoration)
+            integrateLosses=integrateLosses, restoration=restoration, watchdogTrigger=watchdogTrigger)
 
         self._device = device
         self._problem = None   # created on first use: construction stays possible on a machine without GPU

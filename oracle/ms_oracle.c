@@ -182,10 +182,12 @@ enum { RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5 }; /* inequality
 /* local ordering of an interval: t_i b_i q_i f_i p_i s_i | t_{i+1} b_{i+1};  q_i := f_{i-1} */
 enum { LT = 0, LB = 1, LQ = 2, LF = 3, LP = 4, LS = 5, LT1 = 6, LB1 = 7, NL = 8 };
 static const int var2loc[NV] = {LT, LB, LF, LP, LS};
+enum { WD_TRIGGER_DEFAULT = 10 };      /* IPOPT: watchdog_shortened_iter_trigger */
 
 typedef struct {
     int N, withPn, hasPower, energyOpt, numSteps, numApprox, lossKind, maxIter;
     int integ, collD, newtonIters, intLosses;
+    int wdTrigger;          /* watchdog_shortened_iter_trigger (<= 0: no watchdog procedure) */
     double intAtol, intRtol;
     const double *ds, *grad, *curv, *bmax;
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
@@ -198,6 +200,7 @@ static void prob_init(Prob *P, const int *ip, const double *dp, const double *ds
     P->N = ip[OR_IP_N]; P->withPn = ip[OR_IP_WITH_PN]; P->hasPower = ip[OR_IP_HAS_POWER]; P->energyOpt = ip[OR_IP_ENERGY_OPT];
     P->numSteps = ip[OR_IP_NUM_STEPS]; P->numApprox = ip[OR_IP_NUM_APPROX]; P->lossKind = ip[OR_IP_LOSS_KIND]; P->maxIter = ip[OR_IP_MAX_ITER];
     P->intLosses = ip[OR_IP_INTEGRATE_LOSSES];
+    P->wdTrigger = ip[OR_IP_WATCHDOG_TRIGGER] == 0 ? WD_TRIGGER_DEFAULT : ip[OR_IP_WATCHDOG_TRIGGER];
     P->integ = ip[OR_IP_INTEGRATOR]; P->collD = ip[OR_IP_COLL_DEGREE]; P->newtonIters = ip[OR_IP_NEWTON_ITERS];
     P->intAtol = dp[OR_DP_INT_ATOL]; P->intRtol = dp[OR_DP_INT_RTOL];
     P->ds = ds; P->grad = grad; P->curv = curv; P->bmax = bmax;
@@ -671,7 +674,7 @@ typedef struct {
     /* inertia correction memory */
     double delta_last;
     /* stats */
-    int n_reg, n_soc, n_back, n_resto;
+    int n_reg, n_soc, n_back, n_resto, n_wd;
 } Ws;
 
 /* IPOPT default option values (Waechter & Biegler 2006, section 3 + IPOPT 3.14 defaults) */
@@ -1407,6 +1410,46 @@ static int filter_ok(const Ws *W, double theta, double phi)
 /* lhs <= rhs up to round-off relative to basval (IPOPT's Compare_le) */
 static int cmp_le(double lhs, double rhs, double basval) { return lhs - rhs <= 10.0*DBL_EPSILON*fabs(basval); }
 
+/* directional derivative of the barrier function along D, largest component of the step, largest relative component (tiny-step test) */
+static void step_measures(const Ws *W, double mu, const StageDir *D, double *gphid_out, double *dnorm_out, double *rel_out)
+{
+    const int N = W->N;
+    double gphid = 0, dnorm = 0, rel_step = 0;
+    for (int i = 0; i <= N; i++) {
+        const StageBd *B = &W->bd[i]; const StageIt *I = &W->it[i];
+        for (int k = 0; k < NV; k++) {
+            if (!B->on[k]) continue;
+            double Sg, gp; bar_terms(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], I->zL[k], I->zU[k], mu, &Sg, &gp);
+            double go = 0;
+            if (i < N) go = W->ev[i].objg[var2loc[k]];
+            if (i > 0 && k == VT) go += W->ev[i - 1].objg[LT1];
+            if (i > 0 && k == VB) go += W->ev[i - 1].objg[LB1];
+            if (k == VF && i + 1 < N) go += W->ev[i + 1].objg[LQ];
+            gphid += (go + gp)*D[i].dx[k];
+            dnorm = fmax(dnorm, fabs(D[i].dx[k]));
+            rel_step = fmax(rel_step, fabs(D[i].dx[k])/(1 + fabs(I->x[k])));
+        }
+        if (i == N) break;
+        for (int r = 0; r < NR; r++) {
+            if (!W->rowOn[r]) continue;
+            double Sg, gp; bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gp);
+            gphid += gp*D[i].dsig[r];
+            dnorm = fmax(dnorm, fabs(D[i].dsig[r]));
+            rel_step = fmax(rel_step, fabs(D[i].dsig[r])/(1 + fabs(I->sig[r])));
+        }
+    }
+    *gphid_out = gphid; *dnorm_out = dnorm; *rel_out = rel_step;
+}
+
+/* StopWatchDog: the stored iterate and the stored direction back in place, with the derivatives and residuals of that point */
+static void watchdog_restore(Ws *W, const StageIt *wd_it, const StageDir *wd_dir, double (*res_c)[2], double (*res_d)[NR])
+{
+    const int N = W->N;
+    memcpy(W->it, wd_it, (N + 1)*sizeof(StageIt)); memcpy(W->dir, wd_dir, (N + 1)*sizeof(StageDir));
+    for (int i = 0; i < N; i++) eval_interval(W, W->it, i, &W->ev[i], 2);
+    for (int i = 0; i < N; i++) { res_c[i][0] = W->ev[i].c[0]; res_c[i][1] = W->ev[i].c[1]; for (int r = 0; r < NR; r++) res_d[i][r] = W->rowOn[r] ? W->ev[i].d[r] - W->it[i].sig[r] : 0; }
+}
+
 /* ------------------------------------------------------------------------------------------
  * driver
  * ---------------------------------------------------------------------------------------- */
@@ -1444,9 +1487,41 @@ static int debug_level(void) { const char *s = getenv("ORACLE_DEBUG"); return s 
 static int g_resto = 1;
 void oracle_set_restoration(int on) { g_resto = on; }
 
-/* Telemetry for IPOPT's watchdog (IpBacktrackingLineSearch: watchdog_shortened_iter_trigger = 10): the longest run of successive
- * iterations whose accepted step was shortened by the backtracking line search, over all solves since the last reset.  The watchdog
- * procedure itself is not restated; a run of fewer than 10 means IPOPT would not have started it either. */
+/*
+ * IPOPT's watchdog procedure (IpBacktrackingLineSearch.cpp: StartWatchDog / StopWatchDog, FilterLSAcceptor::StartWatchDog / StopWatchDog;
+ * options watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3 -- the defaults the reference runs with, ocp.py:290).  IPOPT's
+ * sources are not part of the reference tree or of this image: the procedure is restated from the published implementation, parity unpinned.
+ *   - an iteration whose accepted step needed more than one backtracking step counts as shortened, one that took its first trial step
+ *     resets the count (n_steps > 1 / n_steps == 0 in FindAcceptableTrialPoint); a change of the barrier parameter resets it too
+ *     (BacktrackingLineSearch::Reset) and ends a running watchdog;
+ *   - after 10 shortened iterations the iterate, the search direction and (theta, phi, grad phi^T d) of that point are stored; from then on
+ *     only the full fraction-to-the-boundary step is tried, tested against the stored reference values; a trial point that passes ends the
+ *     procedure (the filter is augmented with the reference point), one that does not is taken all the same, without touching the filter;
+ *   - after 3 such trial iterations without success (or a tiny step, or a trial point that cannot be evaluated) the stored iterate comes
+ *     back and the ordinary backtracking line search runs on the stored direction, starting from half the maximal step.
+ * oracle_max_shortened_run: telemetry of round 3 -- the longest run of successive iterations with at least one backtracking step.
+ */
+static int g_watchdog = 1;
+void oracle_set_watchdog(int on) { g_watchdog = on; }
+static const int WD_TRIAL_MAX = 3;
+static int g_wd_started = 0, g_wd_succeeded = 0, g_wd_forced = 0;      /* procedures started, ended by an accepted trial point; trial points taken without the filter's consent */
+void oracle_watchdog_counts(int *started, int *succeeded, int reset)
+{
+#pragma omp critical(msd_shortened)
+    { *started = g_wd_started; *succeeded = g_wd_succeeded; if (reset) g_wd_started = g_wd_succeeded = 0; }
+}
+int oracle_watchdog_forced_steps(int reset)
+{
+    int v;
+#pragma omp critical(msd_shortened)
+    { v = g_wd_forced; if (reset) g_wd_forced = 0; }
+    return v;
+}
+static void note_watchdog(int started, int succeeded, int forced_steps)
+{
+#pragma omp critical(msd_shortened)
+    { g_wd_started += started; g_wd_succeeded += succeeded; g_wd_forced += forced_steps; }
+}
 static int g_max_shortened = 0;
 int oracle_max_shortened_run(int reset) { int v; 
 #pragma omp critical(msd_shortened)
@@ -2064,6 +2139,9 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
 
     int status = OR_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
     int short_run = 0, short_max = 0;      /* successive shortened steps (watchdog telemetry) */
+    int wd_short = 0, in_wd = 0, wd_trial = 0, wd_started = 0, wd_succeeded = 0, wd_forced_steps = 0;      /* watchdog */
+    double wd_theta = 0, wd_phi = 0, wd_gphid = 0, wd_dw = 0;
+    StageIt *wd_it = NULL; StageDir *wd_dir = NULL;
     Err R; memset(&R, 0, sizeof R);
     double alpha_pr = 0, alpha_du = 0, dnorm = 0;
 
@@ -2093,7 +2171,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
                 mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = 1;
                 kkt_error(W, mu, &Rm);
             }
-            if (changed) { W->nfilt = 0; }
+            if (changed) { W->nfilt = 0; in_wd = 0; wd_short = 0; }      /* (a new barrier problem: filter and watchdog start afresh) */
         }
         merit_terms(W, W->it, mu, &theta, &phi, &okp);
 
@@ -2115,98 +2193,117 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         if (dbg >= 2) fprintf(stderr, "[oracle]    dw %.2e newton residual %.3e\n", dw, direction_residual(W, mu, dw, (const double (*)[2])res_c, (const double (*)[NR])res_d, W->dir));
 
         /* directional derivative of the barrier function and step norms */
-        double gphid = 0; dnorm = 0; double rel_step = 0;
-        for (int i = 0; i <= N; i++) {
-            StageBd *B = &W->bd[i]; StageIt *I = &W->it[i];
-            for (int k = 0; k < NV; k++) {
-                if (!B->on[k]) continue;
-                double Sg, gp; bar_terms(I->x[k], B->lb[k], B->ub[k], B->hasL[k], B->hasU[k], I->zL[k], I->zU[k], mu, &Sg, &gp);
-                double go = 0;
-                if (i < N) go = W->ev[i].objg[var2loc[k]];
-                if (i > 0 && k == VT) go += W->ev[i - 1].objg[LT1];
-                if (i > 0 && k == VB) go += W->ev[i - 1].objg[LB1];
-                if (k == VF && i + 1 < N) go += W->ev[i + 1].objg[LQ];
-                gphid += (go + gp)*W->dir[i].dx[k];
-                dnorm = fmax(dnorm, fabs(W->dir[i].dx[k]));
-                rel_step = fmax(rel_step, fabs(W->dir[i].dx[k])/(1 + fabs(I->x[k])));
-            }
-            if (i == N) break;
-            for (int r = 0; r < NR; r++) {
-                if (!W->rowOn[r]) continue;
-                double Sg, gp; bar_terms(I->sig[r], W->dL[r], W->dU[r], W->rhasL[r], W->rhasU[r], I->zLs[r], I->zUs[r], mu, &Sg, &gp);
-                gphid += gp*W->dir[i].dsig[r];
-                dnorm = fmax(dnorm, fabs(W->dir[i].dsig[r]));
-                rel_step = fmax(rel_step, fabs(W->dir[i].dsig[r])/(1 + fabs(I->sig[r])));
-            }
-        }
+        double gphid, rel_step;
+        step_measures(W, mu, W->dir, &gphid, &dnorm, &rel_step);
 
         double amax = alpha_primal_max(W, W->dir, tau);
         alpha_du = alpha_dual_max(W, W->dir, tau);
 
         /* tiny step (IPOPT tiny_step_tol = 10 eps): accept the full step without line search */
         int tiny = rel_step < 10*DBL_EPSILON;
+
+        /* watchdog (see above): a tiny step ends a running one -- everything resumes from the stored point with the stored direction */
+        if (in_wd && tiny) {
+            watchdog_restore(W, wd_it, wd_dir, res_c, res_d);
+            in_wd = 0; wd_short = 0; dw = wd_dw; tiny = 0;
+            merit_terms(W, W->it, mu, &theta, &phi, &okp);
+            step_measures(W, mu, W->dir, &gphid, &dnorm, &rel_step);
+            amax = alpha_primal_max(W, W->dir, tau); alpha_du = alpha_dual_max(W, W->dir, tau);
+            if (dbg) fprintf(stderr, "[oracle]    watchdog stopped by a tiny step\n");
+        }
+        if (g_watchdog && P->wdTrigger > 0 && !in_wd && !tiny && wd_short >= P->wdTrigger) {
+            if (!wd_it) { wd_it = malloc((N + 1)*sizeof(StageIt)); wd_dir = malloc((N + 1)*sizeof(StageDir)); }
+            memcpy(wd_it, W->it, (N + 1)*sizeof(StageIt)); memcpy(wd_dir, W->dir, (N + 1)*sizeof(StageDir));
+            wd_theta = theta; wd_phi = phi; wd_gphid = gphid; wd_dw = dw; wd_trial = 0; in_wd = 1; W->n_wd++; wd_started++;
+            if (dbg) fprintf(stderr, "[oracle]    watchdog started (theta %.6e phi %.10e)\n", theta, phi);
+        }
+
         double alpha = amax; int accepted = 0; const StageDir *Dacc = W->dir; int ftype_armijo = 0;
         if (tiny) {
             accepted = 1; make_trial(W, W->dir, alpha);
             if (++tiny_count >= 2 && mu <= fmin(P->tol, 1e-4)/(K_EPS + 1.0)*(1 + 1e-12)) { status = OR_STATUS_TINY_STEP; break; }
         } else tiny_count = 0;
 
-        /* alpha_min (W&B eq. (23)) */
-        double amin;
-        if (gphid < 0) {
-            amin = G_THETA;
-            amin = fmin(amin, G_PHI*theta/(-gphid));
-            if (theta <= W->theta_min) amin = fmin(amin, K_DELTA*pow(theta, S_THETA)/pow(-gphid, S_PHI));
-        } else amin = G_THETA;
-        amin *= ALPHA_MIN_FRAC;
+        int ls = 0, skip_first = 0, forced = 0;
+        double th_ref = theta, ph_ref = phi, gd_ref = gphid;      /* reference point of the acceptance tests: the current one, or the watchdog's */
+        for (;;) {
+            if (in_wd) { th_ref = wd_theta; ph_ref = wd_phi; gd_ref = wd_gphid; }
+            else { th_ref = theta; ph_ref = phi; gd_ref = gphid; }
+            /* alpha_min (W&B eq. (23)) */
+            double amin;
+            if (gd_ref < 0) {
+                amin = G_THETA;
+                amin = fmin(amin, G_PHI*th_ref/(-gd_ref));
+                if (th_ref <= W->theta_min) amin = fmin(amin, K_DELTA*pow(th_ref, S_THETA)/pow(-gd_ref, S_PHI));
+            } else amin = G_THETA;
+            amin *= ALPHA_MIN_FRAC;
 
-        int ls = 0;
-        while (!accepted) {
-            make_trial(W, W->dir, alpha);
-            double th_t, ph_t; int okt;
-            merit_terms(W, W->trial, mu, &th_t, &ph_t, &okt);
-            int acc = 0;
-            int ftype = (gphid < 0) && (alpha*pow(-gphid, S_PHI) > K_DELTA*pow(theta, S_THETA));
-            if (okt && th_t <= W->theta_max) {
-                if (ftype && theta <= W->theta_min) acc = cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
-                else acc = cmp_le(th_t, (1 - G_THETA)*theta, theta) || cmp_le(ph_t - phi, -G_PHI*theta, phi);
-                if (acc) acc = filter_ok(W, th_t, ph_t);
-            }
-            if (acc) { accepted = 1; Dacc = W->dir; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi); break; }
-
-            /* second-order correction (W&B section 2.4) on the first trial step if infeasibility grew */
-            if (ls == 0 && okt && th_t >= theta) {
-                double th_old = theta, th_prev = th_t; int nsoc = 0;
-                for (int i = 0; i < N; i++) { soc_c[i][0] = W->ev[i].c[0]; soc_c[i][1] = W->ev[i].c[1]; for (int r = 0; r < NR; r++) soc_d[i][r] = res_d[i][r]; }
-                double alpha_soc = alpha;
-                while (nsoc < P_MAX_SOC) {
-                    /* c_soc = alpha_soc * c_soc + c(trial) */
-                    StageEv e;
-                    for (int i = 0; i < N; i++) {
-                        eval_interval(W, W->trial, i, &e, 0);
-                        soc_c[i][0] = alpha_soc*soc_c[i][0] + e.c[0]; soc_c[i][1] = alpha_soc*soc_c[i][1] + e.c[1];
-                        for (int r = 0; r < NR; r++) if (W->rowOn[r]) soc_d[i][r] = alpha_soc*soc_d[i][r] + (e.d[r] - W->trial[i].sig[r]);
-                    }
-                    if (!compute_direction(W, mu, dw, (const double (*)[2])soc_c, (const double (*)[NR])soc_d, W->soc)) break;
-                    alpha_soc = alpha_primal_max(W, W->soc, tau);
-                    make_trial(W, W->soc, alpha_soc);
-                    double th_s, ph_s; int oks;
-                    merit_terms(W, W->trial, mu, &th_s, &ph_s, &oks);
-                    nsoc++; W->n_soc++;
-                    int accs = 0;
-                    if (oks && th_s <= W->theta_max) {
-                        if (ftype && th_old <= W->theta_min) accs = cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi);
-                        else accs = cmp_le(th_s, (1 - G_THETA)*th_old, th_old) || cmp_le(ph_s - phi, -G_PHI*th_old, phi);
-                        if (accs) accs = filter_ok(W, th_s, ph_s);
-                    }
-                    if (accs) { accepted = 1; Dacc = W->soc; ftype_armijo = ftype && cmp_le(ph_s - phi, ETA_PHI*alpha*gphid, phi); alpha = alpha_soc; break; }
-                    if (!oks || th_s > K_SOC*th_prev) break;
-                    th_prev = th_s;
+            alpha = skip_first ? 0.5*amax : amax; ls = 0;
+            int okt_last = 1;
+            while (!accepted) {
+                make_trial(W, W->dir, alpha);
+                double th_t, ph_t; int okt;
+                merit_terms(W, W->trial, mu, &th_t, &ph_t, &okt);
+                okt_last = okt;
+                int acc = 0;
+                int ftype = (gd_ref < 0) && (alpha*pow(-gd_ref, S_PHI) > K_DELTA*pow(th_ref, S_THETA));
+                if (okt && th_t <= W->theta_max) {
+                    if (ftype && th_ref <= W->theta_min) acc = cmp_le(ph_t - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref);
+                    else acc = cmp_le(th_t, (1 - G_THETA)*th_ref, th_ref) || cmp_le(ph_t - ph_ref, -G_PHI*th_ref, ph_ref);
+                    if (acc) acc = filter_ok(W, th_t, ph_t);
                 }
-                if (accepted) break;
+                if (acc) { accepted = 1; Dacc = W->dir; ftype_armijo = ftype && cmp_le(ph_t - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref); break; }
+                if (in_wd) break;      /* only the full step is tried while the watchdog runs */
+
+                /* second-order correction (W&B section 2.4) on the first trial step if infeasibility grew */
+                if (ls == 0 && !skip_first && okt && th_t >= th_ref) {
+                    double th_old = th_ref, th_prev = th_t; int nsoc = 0;
+                    for (int i = 0; i < N; i++) { soc_c[i][0] = W->ev[i].c[0]; soc_c[i][1] = W->ev[i].c[1]; for (int r = 0; r < NR; r++) soc_d[i][r] = res_d[i][r]; }
+                    double alpha_soc = alpha;
+                    while (nsoc < P_MAX_SOC) {
+                        /* c_soc = alpha_soc * c_soc + c(trial) */
+                        StageEv e;
+                        for (int i = 0; i < N; i++) {
+                            eval_interval(W, W->trial, i, &e, 0);
+                            soc_c[i][0] = alpha_soc*soc_c[i][0] + e.c[0]; soc_c[i][1] = alpha_soc*soc_c[i][1] + e.c[1];
+                            for (int r = 0; r < NR; r++) if (W->rowOn[r]) soc_d[i][r] = alpha_soc*soc_d[i][r] + (e.d[r] - W->trial[i].sig[r]);
+                        }
+                        if (!compute_direction(W, mu, dw, (const double (*)[2])soc_c, (const double (*)[NR])soc_d, W->soc)) break;
+                        alpha_soc = alpha_primal_max(W, W->soc, tau);
+                        make_trial(W, W->soc, alpha_soc);
+                        double th_s, ph_s; int oks;
+                        merit_terms(W, W->trial, mu, &th_s, &ph_s, &oks);
+                        nsoc++; W->n_soc++;
+                        int accs = 0;
+                        if (oks && th_s <= W->theta_max) {
+                            if (ftype && th_old <= W->theta_min) accs = cmp_le(ph_s - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref);
+                            else accs = cmp_le(th_s, (1 - G_THETA)*th_old, th_old) || cmp_le(ph_s - ph_ref, -G_PHI*th_old, ph_ref);
+                            if (accs) accs = filter_ok(W, th_s, ph_s);
+                        }
+                        if (accs) { accepted = 1; Dacc = W->soc; ftype_armijo = ftype && cmp_le(ph_s - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref); alpha = alpha_soc; break; }
+                        if (!oks || th_s > K_SOC*th_prev) break;
+                        th_prev = th_s;
+                    }
+                    if (accepted) break;
+                }
+                alpha *= 0.5; ls++; W->n_back++;
+                if (alpha < amin) break;
             }
-            alpha *= 0.5; ls++; W->n_back++;
-            if (alpha < amin) break;
+            if (!in_wd || tiny) break;
+            if (accepted) {
+                in_wd = 0; wd_succeeded++;
+                if (dbg) fprintf(stderr, "[oracle]    watchdog: trial point accepted against the stored reference\n");
+                break;
+            }
+            wd_trial++;
+            if (okt_last && wd_trial <= WD_TRIAL_MAX) { accepted = 1; forced = 1; wd_forced_steps++; Dacc = W->dir; break; }      /* taken although the filter does not accept it */
+            /* no success: back to the stored point, ordinary line search on the stored direction from half the maximal step */
+            watchdog_restore(W, wd_it, wd_dir, res_c, res_d);
+            in_wd = 0; wd_short = 0; dw = wd_dw; skip_first = 1;
+            merit_terms(W, W->it, mu, &theta, &phi, &okp);
+            step_measures(W, mu, W->dir, &gphid, &dnorm, &rel_step);
+            amax = alpha_primal_max(W, W->dir, tau); alpha_du = alpha_dual_max(W, W->dir, tau);
+            if (dbg) fprintf(stderr, "[oracle]    watchdog stopped after %d trial iterations: back to the stored point\n", wd_trial);
         }
         if (!accepted) {
             /* the step became too small: feasibility restoration (IpBacktrackingLineSearch: goto_resto).  Not from an almost feasible
@@ -2225,10 +2322,12 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         }
         alpha_pr = alpha;
         if (!tiny) { short_run = (ls > 0) ? short_run + 1 : 0; if (short_run > short_max) short_max = short_run; }
+        if (ls == 0) wd_short = 0;      /* (n_steps == 0: the first trial step was taken) */
+        if (ls > 1) wd_short++;         /* (n_steps > 1: a shortened iteration) */
 
-        /* filter augmentation (W&B eq. (22)) */
-        if (!tiny && !ftype_armijo) {
-            if (W->nfilt < 512) { W->filt_theta[W->nfilt] = (1 - G_THETA)*theta; W->filt_phi[W->nfilt] = phi - G_PHI*theta; W->nfilt++; }
+        /* filter augmentation (W&B eq. (22)), with the reference point of the tests */
+        if (!tiny && !forced && !ftype_armijo) {
+            if (W->nfilt < 512) { W->filt_theta[W->nfilt] = (1 - G_THETA)*th_ref; W->filt_phi[W->nfilt] = ph_ref - G_PHI*th_ref; W->nfilt++; }
         }
 
         /* accept: primal from the trial point, equality multipliers with the primal step, bound multipliers with the
@@ -2297,9 +2396,10 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
     if (stats) {
         stats[OR_ST_STATUS] = status; stats[OR_ST_ITERS] = iter; stats[OR_ST_OBJ] = objective_value(W, W->it)/W->sf;
         stats[OR_ST_KKT] = R.E; stats[OR_ST_MU] = mu; stats[OR_ST_DUAL_INF] = R.dual_u; stats[OR_ST_CONSTR_VIOL] = R.primal_u; stats[OR_ST_COMPL] = R.compl_u;
-        stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back; stats[OR_ST_N_RESTO] = W->n_resto;
+        stats[OR_ST_N_REG] = W->n_reg; stats[OR_ST_N_SOC] = W->n_soc; stats[OR_ST_N_BACKTRACK] = W->n_back; stats[OR_ST_N_RESTO] = W->n_resto; stats[OR_ST_N_WATCHDOG] = W->n_wd;
     }
-    note_shortened_run(short_max);
+    note_shortened_run(short_max); note_watchdog(wd_started, wd_succeeded, wd_forced_steps);
+    free(wd_it); free(wd_dir);
     free(res_c); free(res_d); free(soc_c); free(soc_d);
     ws_free(W);
     return status;

@@ -58,6 +58,7 @@ enum {
     OR_IP_NEWTON_ITERS,   /* OptionsIRK.maxIter (train.py:493)                               */
     OR_IP_INTEGRATE_LOSSES, /* OptionsCasadiSolver.integrateLosses (ocp.py:28,231-241): loss slacks from the loss power integrated over the
                              * running time of the interval (static efficiencies only)                                    */
+    OR_IP_WATCHDOG_TRIGGER, /* IPOPT's watchdog_shortened_iter_trigger: 0 = its default (10), < 0 = no watchdog procedure */
     OR_IP_COUNT
 };
 
@@ -93,6 +94,7 @@ enum {
     OR_ST_N_SOC,          /* second-order corrections taken                                  */
     OR_ST_N_BACKTRACK,    /* total backtracking steps                                        */
     OR_ST_N_RESTO,        /* restoration phases entered                                      */
+    OR_ST_N_WATCHDOG,     /* watchdog procedures started                                     */
     OR_ST_COUNT
 };
 
@@ -158,6 +160,10 @@ void oracle_set_restoration(int on);
 /* longest run of successive iterations with a shortened (backtracked) step over the solves since the last reset: the quantity IPOPT's
  * watchdog compares with watchdog_shortened_iter_trigger = 10 (the watchdog itself is not restated) */
 int oracle_max_shortened_run(int reset);
+/* IPOPT's watchdog procedure (on by default, like in IPOPT); counts of procedures started / ended by an accepted trial point since the last reset */
+void oracle_set_watchdog(int on);
+void oracle_watchdog_counts(int *started, int *succeeded, int reset);
+int oracle_watchdog_forced_steps(int reset);      /* trial points taken without the filter's consent while a procedure ran */
 void oracle_loss_rows(const double *block, double f, double v, double *out12);
 
 /* NLP functions at z (reference layout): objective and the constraint rows in the reference's order. */

@@ -18,10 +18,10 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 
-IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, INTEGRATOR=8, COLL_DEGREE=9, NEWTON_ITERS=10, INTEGRATE_LOSSES=11, COUNT=12)
+IP = dict(N=0, WITH_PN=1, HAS_POWER=2, ENERGY_OPT=3, NUM_STEPS=4, NUM_APPROX=5, LOSS_KIND=6, MAX_ITER=7, INTEGRATOR=8, COLL_DEGREE=9, NEWTON_ITERS=10, INTEGRATE_LOSSES=11, WATCHDOG_TRIGGER=12, COUNT=13)
 DP = dict(SR0=0, SR1=1, SR2=2, G=3, RHO=4, FMAX=5, FMIN=6, FMIN_PN=7, PW_UPPER=8, PW_LOWER=9, ACC_MIN=10, ACC_MAX=11,
           LOSS_CT=12, LOSS_CR=13, VMIN_SQ=14, OBJ_DEN=15, TOL=16, T0=17, TEND=18, V0SQ=19, VNSQ=20, INT_ATOL=21, INT_RTOL=22, COUNT=23)
-ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, N_RESTO=11, COUNT=12)
+ST = dict(STATUS=0, ITERS=1, OBJ=2, KKT=3, MU=4, DUAL_INF=5, CONSTR_VIOL=6, COMPL=7, N_REG=8, N_SOC=9, N_BACKTRACK=10, N_RESTO=11, N_WATCHDOG=12, COUNT=13)
 
 _lib = None
 
@@ -232,6 +232,7 @@ def pack_problem(train, points, opts, lossKind, ct, cr, trackLength, tol=1e-8):
     ip[IP['COLL_DEGREE']] = int(opts.get('order', 0)) if ip[IP['INTEGRATOR']] == 1 else 0
     ip[IP['NEWTON_ITERS']] = int(opts.get('maxIter', 10))
     ip[IP['INTEGRATE_LOSSES']] = int(bool(opts.get('integrateLosses', False)))
+    ip[IP['WATCHDOG_TRIGGER']] = int(opts.get('watchdogTrigger', 0))      # IPOPT's watchdog_shortened_iter_trigger (0: its default, 10)
     if ip[IP['INTEGRATOR']] == 2:
         ip[IP['NUM_APPROX']] = 0     # train.py:314
 
@@ -338,6 +339,27 @@ def max_shortened_run(reset=True):
     L.oracle_max_shortened_run.argtypes = [ctypes.c_int]
 
     return int(L.oracle_max_shortened_run(1 if reset else 0))
+
+
+def set_watchdog(on):
+    "IPOPT's watchdog procedure on (default) / off."
+
+    lib().oracle_set_watchdog(1 if on else 0)
+
+
+def watchdog_counts(reset=True):
+    "(started, ended by an accepted trial point) over the solves since the last reset."
+
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    lib().oracle_watchdog_counts(ctypes.byref(a), ctypes.byref(b), 1 if reset else 0)
+
+    return a.value, b.value
+
+
+def watchdog_forced_steps(reset=True):
+    "Trial points a running watchdog procedure took without the filter's consent, over the solves since the last reset."
+
+    return int(lib().oracle_watchdog_forced_steps(1 if reset else 0))
 
 
 def stage_eval(prob_or_ipdp, b, w, ds, grad=0.0, curv=0.0):

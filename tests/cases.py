@@ -45,7 +45,7 @@ def train_fig5():
     return train
 
 
-def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1, integration=None):
+def oracle_problem(train, track, N, energyOptimal=True, losses='static', numSteps=1, numApproxSteps=1, maxIterations=500, vmin=1, integration=None, watchdogTrigger=0):
     """
     integration: None ('RK') or the reference's options of the other shooting integrators, e.g. dict(integrationMethod='IRK', order=2,
     collMethod='radau', maxIter=10) / dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6).  The oracle keeps ONE set of
@@ -53,7 +53,7 @@ def oracle_problem(train, track, N, energyOptimal=True, losses='static', numStep
     """
     pts = computeDiscretizationPoints(track, N)
     opts = dict(numIntervals=N, maxIterations=maxIterations, energyOptimal=energyOptimal, minimumVelocity=vmin,
-                numSteps=numSteps, numApproxSteps=numApproxSteps)
+                numSteps=numSteps, numApproxSteps=numApproxSteps, watchdogTrigger=watchdogTrigger)
     if integration:
         opts.update(integration)
         if integration.get('integrationMethod') == 'IRK':

@@ -1,10 +1,20 @@
 /* TEST-ONLY: host emulation, kernel family "general" (see emu_common.h) */
 #include "emu_common.h"
 
+/* like msd_api.hip launches this family: a first-pass kernel (general iteration without the restoration phase), then the streamed kernel of the
+ * family -- which has the phase -- over the list the first pass left (a stand-in geometry the emulation can afford: 128 x 5) */
+template <int NT, int SPT> static void run_split(EmuArgs a)
+{
+    std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
+    a.P.follow = follow.data();
+    EMU_CALL(NT, SPT, 0, false, true, 0, 1);
+    EMU_CALL(128, 5, 0, true, true);
+}
+
 bool emu_run_general(int NT, int SPT, const EmuArgs &a)
 {
-    if (NT == 64 && SPT == 1) { EMU_CALL(64, 1, false, false, true); return true; }
-    if (NT == 64 && SPT == 2) { EMU_CALL(64, 2, false, false, true); return true; }
+    if (NT == 64 && SPT == 1) { run_split<64, 1>(a); return true; }
+    if (NT == 64 && SPT == 2) { run_split<64, 2>(a); return true; }
     return false;
 }
 

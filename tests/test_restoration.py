@@ -93,6 +93,45 @@ def test_emulated_restoration_phase_follows_the_oracle():
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
 
 
+@pytest.mark.parametrize('family', ['streamed', 'collocation'])
+def test_emulated_restoration_phase_in_the_other_kernel_families(family, monkeypatch):
+    """
+    Round 4: the phase outside the LDS-resident Runge-Kutta kernels.  `streamed`: the long-horizon kernel (node fields and stage blocks in device
+    memory) holds the phase itself -- same history as the oracle, row by row.  `collocation`: the kernels of the other shooting integrators are
+    first-pass kernels; the scenario whose line search breaks down is listed and solved again, with the phase, by the streamed kernel of the family
+    (msd_api.hip: make_plan; the emulation launches the two like the host code does).
+    """
+    from test_kernel_emulation import load_emulation
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    emu = load_emulation()
+    N, crop, T, cap = 30, 12000, 300.0, 64
+    train, track = cases.train_default(), cases.track_00(crop)
+    if family == 'streamed':
+        monkeypatch.setenv('EMU_GEOMETRY', 'stream')
+        opts = dict(numIntervals=N, maxIterations=60, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        prob = cases.oracle_problem(train, track, N, maxIterations=60)
+    else:
+        opts = dict(numIntervals=N, maxIterations=60, integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))
+        prob = cases.oracle_problem(train, track, N, numSteps=1, numApproxSteps=0, maxIterations=60,
+                                    integration=dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10))
+    solver = casadiSolver(train, track, opts, startingPoint='reference')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((cap, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), cap) == 0
+    ref = oracle.solve(prob, prob.scenario(T), start='reference', history=True)
+    assert int(st[0, ST['STATUS']]) == int(ref['stats']['STATUS']) == -1
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 120
+    assert int(st[0, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
+    h = ref['hist']
+    for i in range(60 if family == 'streamed' else 36):      # (collocation: the Newton iteration inside the integrator lets the two drift apart by 1e-4 after forty iterations)
+        assert np.allclose(hist[i, 1:5], h[i, 1:5], rtol=1e-4, atol=1e-9), (i, hist[i], h[i])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < (1e-4 if family == 'streamed' else 1e-2)
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
 RK11 = dict(numSteps=1, numApproxSteps=1)      # the transcription cases.oracle_problem packs by default
@@ -179,3 +218,36 @@ def test_gpu_restoration_on_every_geometry(N, variant):
     s.close()
     assert np.all(best['status'] == 0) and np.all(res['status'] == 0), (best['status'], res['status'])
     assert np.max(np.abs(res['cost'] - best['cost'])/np.abs(best['cost'])) < 1e-6
+
+
+@gpu
+@pytest.mark.parametrize('family,N,T', [('CVODES', 100, 14000.0), ('CVODES', 100, 20000.0), ('IRK', 300, 9000.0), ('RK', 600, 9000.0), ('RK', 700, 9000.0), ('RK', 1200, 20000.0)])
+def test_gpu_restoration_in_the_other_kernel_families(family, N, T):
+    """
+    Round 4: the restoration phase for every kernel family with static loss rows.  Adaptive ('CVODES') and collocation ('IRK') shooting: first-pass
+    kernels + the streamed kernel of the family behind them; 600 intervals: the five-wave kernel + the streamed one; 700 and 1200 intervals: the streamed
+    kernels themselves.  A loose schedule from the reference's starting point goes through restoration phases in the oracle and on the device
+    and reaches the oracle's optimum.  (Not: the dynamic loss model and integrateLosses -- their loss rows couple neighbouring stages, the
+    restoration problem's Newton system is not restated for them, neither in the oracle nor here.)
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train, track = cases.train_default(), cases.track_00()
+    if family == 'RK':
+        opts, integ, kw = dict(numIntervals=N, maxIterations=800, integrationOptions=RK11), None, {}
+    elif family == 'IRK':
+        opts = dict(numIntervals=N, maxIterations=800, integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))
+        integ, kw = dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10), dict(numSteps=1, numApproxSteps=0)
+    else:
+        opts = dict(numIntervals=N, maxIterations=800, integrationMethod='CVODES', integrationOptions=dict())
+        integ, kw = dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6), dict(numSteps=1, numApproxSteps=0)
+    s = casadiSolver(train, track, opts, startingPoint='reference')
+    res = s.solveBatch([T])
+    s.close()
+    prob = cases.oracle_problem(train, track, N, maxIterations=800, integration=integ, **kw)
+    ref = oracle.solve(prob, prob.scenario(T), start='reference')
+    assert res['status'][0] == int(ref['stats']['STATUS']) == 0
+    assert int(ref['stats']['N_RESTO']) >= 1 and int(res['stats'][0, ST['N_RESTO']]) >= 1
+    assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ'])
+    assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4

@@ -1,11 +1,12 @@
 """
-Would IPOPT's watchdog have started on these problems?  (CPU only; checker-side tool.)
+Where does IPOPT's watchdog start on these problems?  (CPU only; checker-side tool.)
 
 IPOPT starts its watchdog procedure after `watchdog_shortened_iter_trigger` = 10 successive iterations whose step the backtracking line
-search shortened (IpBacktrackingLineSearch.cpp).  The procedure is restated neither in the oracle nor on the device;
-this survey runs the oracle -- the iterate-for-iterate restatement of the rest of the algorithm -- over the benchmark workloads and random
-problems from both starting points and reports the longest run of successive shortened steps in each group.  A maximum below 10 means the
-watchdog never starts there, i.e. leaving it out changes no iterate.
+search shortened (IpBacktrackingLineSearch.cpp).  Round 4 restates the procedure in the oracle (oracle/ms_oracle.c: solve_core) and in the
+general iteration of the kernels (msd_kernel.hpp: Solver::run); this survey runs the oracle over the benchmark workloads, loose schedules and
+random problems from both starting points and reports, per group: the longest run of successive iterations with a backtracking step (round 3's
+telemetry), the procedures started, those ended by an accepted trial point, and the trial points taken without the filter's consent.
+The device side of the same rows: tests/test_watchdog.py (GPU tests), tests/tools/random_sweep.py.
 
 usage: watchdog_survey.py [scenarios per workload = 256] [random problems = 40]
 """
@@ -30,13 +31,15 @@ worst = 0
 def group(label, prob, scen):
     global worst
     for start in ('profile', 'reference'):
-        oracle.max_shortened_run(reset=True)
+        oracle.max_shortened_run(reset=True); oracle.watchdog_counts(True); oracle.watchdog_forced_steps(True)
         z, st, nfail = oracle.solve_batch(prob, scen, start=start)
         run = oracle.max_shortened_run(reset=True)
+        started, succeeded = oracle.watchdog_counts(True)
+        forced = oracle.watchdog_forced_steps(True)
         worst = max(worst, run)
         it = st[:, oracle.ST['ITERS']]
-        print('{:<34s} {:<9s} solves {:5d}  failed {:3d}  iterations {:5.1f} (max {:3.0f})  backtracking steps / solve {:5.2f}  longest shortened run {:2d}'.format(
-            label, start, len(scen), int(nfail), it.mean(), it.max(), st[:, oracle.ST['N_BACKTRACK']].mean(), run), flush=True)
+        print('{:<34s} {:<9s} solves {:5d}  failed {:3d}  iterations {:5.1f} (max {:3.0f})  backtracking steps / solve {:5.2f}  longest shortened run {:2d}  watchdog started {:3d} succeeded {:3d} forced steps {:3d}  restoration phases {:3d}'.format(
+            label, start, len(scen), int(nfail), it.mean(), it.max(), st[:, oracle.ST['N_BACKTRACK']].mean(), run, started, succeeded, forced, int(st[:, oracle.ST['N_RESTO']].sum())), flush=True)
 
 
 def scenarios(times, v0=1.0, vN=1.0):
@@ -49,6 +52,8 @@ train, track, N = workloads.config('c2')
 group('config 2 (N = 200, CH_StGallen_Wil)', cases.oracle_problem(train, track, N), scenarios(workloads.c2_times(max(B//4, 16))))
 group('figure 10 train, N = 100', cases.oracle_problem(cases.train_fig10(), workloads.track_00(), 100), scenarios(workloads.c1_times(B, seed=7)))
 group('config 1, loose schedules', cases.oracle_problem(*workloads.config('c1')), scenarios(np.linspace(3000, 20000, 64)))
+for Nl in (300, 600, 700, 1200):      # the same track on longer horizons (192 x 2, 320 x 2 + streamed follow-up, streamed kernels)
+    group('loose schedules, N = {}'.format(Nl), cases.oracle_problem(workloads.train_default(), workloads.track_00(), Nl, maxIterations=800), scenarios(np.linspace(3000, 20000, 16)))
 
 # config 3: perturbed rolling stock, one oracle problem per scenario
 from mseetc.track import computeDiscretizationPoints      # noqa: E402
@@ -111,4 +116,4 @@ if NRANDOM:
     print('{} random problems x 5 running times x 2 starts: longest shortened run {} (histogram of the per-batch maxima: {})'.format(
         NRANDOM, max(runs), np.bincount(runs).tolist()))
 
-print('longest run of successive shortened steps over everything:', worst, '(IPOPT starts its watchdog at 10)')
+print('longest run of successive iterations with a backtracking step over everything:', worst, '(the watchdog counts iterations with MORE than one backtracking step and starts at 10 of them)')
