@@ -575,9 +575,10 @@ constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_
  * doubles) for the dense temporaries of riccati_resto -- on the stack they would size the scratch memory of every launch of the kernel */
 constexpr int W_SC = 72, W_RN = 74, W_RP = 81, W_RZN = 88, W_RZP = 95, W_RDN = 102, W_RDP = 109, W_RDZN = 116, W_RDZP = 123, W_XR = 130, W_SGR = 135,
               W_OZL = 140, W_OZU = 145, W_OZLS = 150, W_OZUS = 155, W_RD = 160, W_DNU = 162, W_RFILT = 167, W_SCAL = 169, W_RTMP = 170;
-/* behind that: the reference point of the watchdog procedure (Solver::watchdog_store): iterate (37 fields), search direction (7 + 5) */
-constexpr int W_WD = 175, W_WD_Z = 5, W_WD_ZU = 10, W_WD_SG = 15, W_WD_NU = 20, W_WD_ZLS = 25, W_WD_ZUS = 30, W_WD_LAM = 35, W_WD_DIR = 37, W_WD_DSG = 44,
-              W_FIELDS = 224;
+/* behind that: the reference point of the watchdog procedure -- a copy of the iterate's fields W_X ... W_ZUS in the same order (Solver::wd_restore) */
+constexpr int W_WD = 175, W_WD_FIELDS = 37;
+static_assert(W_DSG == W_WD_FIELDS, "the iterate proper: the fields in front of the slack steps");
+constexpr int W_FIELDS = W_WD + W_WD_FIELDS;
 __host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
 /* work area of a workgroup of the streamed (long-horizon) kernel: node fields (the same fields as above), stage blocks, six exchange arrays */
 __host__ __device__ constexpr size_t stream_doubles(int N, int node_slots, bool dyn)
@@ -1638,12 +1639,12 @@ struct Solver {
             for (int k = 0; k < CNT; k++) f.v[k] = work[(off + k)*NS + slot];
         }
     }
-    template <unsigned M> __device__ __forceinline__ void stash()
+    template <unsigned M, int BASE = 0> __device__ __forceinline__ void stash()      /* (BASE: another set of fields with the same layout -- the watchdog's copy) */
     {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             NodeT &nd = n[j];
-            const int sl = nd.i;
+            const int sl = nd.i + BASE*NS;
             if (M & H_X) put<NV>(nd.x, W_X, sl);
             if (M & H_SG) put<NR>(nd.sg, W_SG, sl);
             if (M & H_LAM) put<2>(nd.lam, W_LAM, sl);
@@ -3001,49 +3002,32 @@ struct Solver {
 #define MSD_WATCHDOG 1
 #endif
     static constexpr int WD_TRIGGER_DEFAULT = 10, WD_TRIAL_MAX = 3;
-    __device__ __forceinline__ void watchdog_store()
+    /* Who runs the procedure: the follow-up kernels and the streamed kernels -- the kernels that hold the cold paths.  With its blocks compiled into the
+     * general iteration of the LDS-resident kernels that are some family's hot kernel (dynamic loss table, integrateLosses, the other shooting
+     * integrators) the register allocation of their loop fell apart: 591 -> 3 172 spilled registers on the 64 x 2 kernel of the dynamic loss model, 295 k
+     * -> 163 k solves/s (profiles/r04).  A first-pass kernel counts the shortened iterations and hands the scenario over when the procedure is due; a
+     * complete LDS-resident kernel without a follow-up kernel (PART = 0: those families) only counts -- no watchdog procedure there */
+    static constexpr bool WD_FULL = MSD_WATCHDOG && (PART == 2 || STREAM);
+    static constexpr bool WD_HANDOVER = MSD_WATCHDOG && !WD_FULL && (PART == 1 || PART == 3);
+    static constexpr bool RESUMABLE = (FAMILY_HAS_RESTO && !(PART == 1 || PART == 3)) || WD_FULL;      /* the general iteration can be entered again (`resume`) */
+    /* StopWatchDog, the part outside the iteration (solve_kernel calls it between two entries of run): the watchdog's copy back to the iterate's fields in
+     * the work area -- their home (fetch) in the register-resident kernels, the fields themselves in a streamed one */
+    __device__ static __noinline__ void wd_restore(double *work, const int tid, const int nt)
     {
-#pragma unroll
         for (int j = 0; j < SPT; j++) {
-            const NodeT &nd = n[j];
-            if (!nd.node()) continue;
-            const double *s = c.S + nd.i*S_STRIDE;
-#pragma unroll
-            for (int k = 0; k < NV; k++) { wf(W_WD + k, nd.i) = nd.x[k]; wf(W_WD + W_WD_Z + k, nd.i) = nd.zL[k]; wf(W_WD + W_WD_ZU + k, nd.i) = nd.zU[k]; }
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                wf(W_WD + W_WD_SG + r, nd.i) = nd.sg[r]; wf(W_WD + W_WD_NU + r, nd.i) = nd.nu[r]; wf(W_WD + W_WD_ZLS + r, nd.i) = nd.zLs[r];
-                wf(W_WD + W_WD_ZUS + r, nd.i) = nd.zUs[r]; wf(W_WD + W_WD_DSG + r, nd.i) = nd.dsg[r];
-            }
-            wf(W_WD + W_WD_LAM, nd.i) = nd.lam[0]; wf(W_WD + W_WD_LAM + 1, nd.i) = nd.lam[1];
-            wf(W_WD + W_WD_DIR + 0, nd.i) = s[S_DT]; wf(W_WD + W_WD_DIR + 1, nd.i) = s[S_DB]; wf(W_WD + W_WD_DIR + 2, nd.i) = s[S_DF]; wf(W_WD + W_WD_DIR + 3, nd.i) = s[S_DP];
-            wf(W_WD + W_WD_DIR + 4, nd.i) = s[S_DS]; wf(W_WD + W_WD_DIR + 5, nd.i) = s[S_LT]; wf(W_WD + W_WD_DIR + 6, nd.i) = s[S_LB];
+            const int i = tid + j*nt;
+            for (int f = 0; f < W_WD_FIELDS; f++) work[(size_t)f*NS + i] = work[(size_t)(W_WD + f)*NS + i];
         }
     }
-    /* StopWatchDog: the stored iterate and direction back in place, derivatives and residuals of that point */
-    __device__ __forceinline__ void watchdog_restore()
+    __device__ static __noinline__ void wd_store(double *work, const int tid, const int nt)      /* StartWatchDog: the parked iterate to the watchdog's copy */
     {
-        __syncthreads();
-#pragma unroll
         for (int j = 0; j < SPT; j++) {
-            NodeT &nd = n[j];
-            if (!nd.node()) continue;
-            double *s = c.S + nd.i*S_STRIDE;
-#pragma unroll
-            for (int k = 0; k < NV; k++) { nd.x[k] = wf(W_WD + k, nd.i); nd.zL[k] = wf(W_WD + W_WD_Z + k, nd.i); nd.zU[k] = wf(W_WD + W_WD_ZU + k, nd.i); }
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                nd.sg[r] = wf(W_WD + W_WD_SG + r, nd.i); nd.nu[r] = wf(W_WD + W_WD_NU + r, nd.i); nd.zLs[r] = wf(W_WD + W_WD_ZLS + r, nd.i);
-                nd.zUs[r] = wf(W_WD + W_WD_ZUS + r, nd.i); nd.dsg[r] = wf(W_WD + W_WD_DSG + r, nd.i);
-            }
-            nd.lam[0] = wf(W_WD + W_WD_LAM, nd.i); nd.lam[1] = wf(W_WD + W_WD_LAM + 1, nd.i);
-            s[S_DT] = wf(W_WD + W_WD_DIR + 0, nd.i); s[S_DB] = wf(W_WD + W_WD_DIR + 1, nd.i); s[S_DF] = wf(W_WD + W_WD_DIR + 2, nd.i); s[S_DP] = wf(W_WD + W_WD_DIR + 3, nd.i);
-            s[S_DS] = wf(W_WD + W_WD_DIR + 4, nd.i); s[S_LT] = wf(W_WD + W_WD_DIR + 5, nd.i); s[S_LB] = wf(W_WD + W_WD_DIR + 6, nd.i);
+            const int i = tid + j*nt;
+            for (int f = 0; f < W_WD_FIELDS; f++) work[(size_t)(W_WD + f)*NS + i] = work[(size_t)f*NS + i];
         }
-        __syncthreads();
-        evaluate_current();
-        __syncthreads();
     }
+    static constexpr int STATUS_WDSTART = -103;     /* the watchdog procedure is due: the iterate is parked, the caller copies it (wd_store) and enters again */
+    static constexpr int STATUS_WDSTOP = -102;      /* the watchdog procedure has put its reference point back (in the work area): enter again with `resume` */
 
     template <bool FL>
     __device__ __forceinline__ int run(const double *scen, const double *guess, const double *dual_in, int startKind, int iter_offset, int &iters_out,
@@ -3081,7 +3065,7 @@ struct Solver {
             if (ival) fl |= F_ON_S;
             nd.flags = fl;
             nd.ubB = bm + K_BOUND_RELAX*fmax(1.0, fabs(bm));
-            if (HAS_RESTO && !FL && resume) continue;      /* (the iterate is the one the restoration phase left: in the work area, which is where a streamed kernel's fields live) */
+            if (RESUMABLE && !FL && resume) continue;      /* (the iterate is the one the restoration phase / the watchdog procedure left: in the work area, which is where a streamed kernel's fields live) */
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
             nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = withPn() ? -0.1 : 0.0; nd.x[VS] = 1;
@@ -3102,7 +3086,7 @@ struct Solver {
             nd.sct = nd.scb = 1;
         }
         double mu = mu_start, tau = fmax(K_TAU_MIN, 1 - mu);
-        if (!(HAS_RESTO && !FL && resume)) {
+        if (!(RESUMABLE && !FL && resume)) {
         if (!ext && startKind == MSD_START_PROFILE) profile_start(t0, tEnd, v0sq, vNsq);
         Uni u;     /* built in registers (uniform), published to the LDS copy every phase reads */
         u.tlo = t0 - K_BOUND_RELAX*fmax(1.0, fabs(t0)); u.thi = tEnd + K_BOUND_RELAX*fmax(1.0, fabs(tEnd));
@@ -3254,15 +3238,17 @@ struct Solver {
         double delta_last = 0, theta_max = 0, theta_min = 0;
         int status = MSD_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
         int n_reg = 0, n_soc = 0, n_back = 0, n_resto = 0, iter_first = 0, forced = 0;
-        int wd_short = 0, wd_trial = 0, n_wd = 0;      /* watchdog: successive shortened iterations, trial iterations of a running procedure, procedures started */
-        bool in_wd = false;
-        double wd_theta = 0, wd_phi = 0, wd_gphid = 0, wd_dw = 0;
+        int wd_short = 0, wd_trial = 0, n_wd = 0, wd_reg_inc = 0;      /* watchdog: successive shortened iterations, trial iterations of a running procedure, procedures started */
+        bool in_wd = false, wd_arm = false;      /* (wd_arm: the iterate of this iteration has been copied for the procedure, which starts at its line search) */
+        double wd_theta = 0, wd_phi = 0, wd_gphid = 0, wd_delta_last = 0;
         Err E;
         double alpha_pr = 0, alpha_du = 0, dnorm = 0, objv = 0;
         const double mu_floor = fmin(P.tol, 1e-4)/(K_EPS + 1.0);
-        if constexpr (HAS_RESTO && !FL) {
+        bool skip_first = false;      /* watchdog: the line search of this iteration starts from half the maximal step (the procedure has been stopped) */
+        if constexpr (RESUMABLE && !FL) {
             if (resume) {
-                /* the iterate from the work area (the restoration phase left the new point there), the scalars of the interrupted iteration */
+                /* the iterate from the work area (the restoration phase left the new point there, or the watchdog procedure its reference point), the
+                 * scalars of the interrupted iteration */
                 fetch<H_ALL>();
 #pragma unroll
                 for (int j = 0; j < SPT; j++) { n[j].sct = wf(W_SC, n[j].i); n[j].scb = wf(W_SC + 1, n[j].i); }
@@ -3271,11 +3257,36 @@ struct Solver {
                 theta_max = uni(wf(W_SCAL, SC_THETA_MAX)); theta_min = uni(wf(W_SCAL, SC_THETA_MIN)); delta_last = uni(wf(W_SCAL, SC_DELTA_LAST));
                 n_reg = (int)uni(wf(W_SCAL, SC_N_REG)); n_soc = (int)uni(wf(W_SCAL, SC_N_SOC)); n_back = (int)uni(wf(W_SCAL, SC_N_BACK));
                 n_resto = (int)uni(wf(W_SCAL, SC_N_RESTO)); forced = (int)uni(wf(W_SCAL, SC_FORCED));
-                wd_short = (int)uni(wf(W_SCAL, SC_WD_SHORT)); n_wd = (int)uni(wf(W_SCAL, SC_N_WD));
+                wd_short = (int)uni(wf(W_SCAL, SC_WD_SHORT)); n_wd = (int)uni(wf(W_SCAL, SC_N_WD)); skip_first = uni(wf(W_SCAL, SC_SKIP_FIRST)) != 0.0; wd_arm = uni(wf(W_SCAL, SC_WD_ARM)) != 0.0;
             }
         }
 
+        int park = 0;                      /* why the iterate is parked at the top of the next pass (STATUS_RESTO) */
+        double park_theta = 0, park_phi = 0;
         for (iter = iter_first;; iter++) {
+            if constexpr (RESUMABLE && !FL) {
+                /* The one place where the general iteration leaves with its iterate parked in the work area, to be entered again (`resume`): for the
+                 * restoration phase (the line search of the pass before broke down) and for the watchdog procedure, which is due when ten shortened
+                 * iterations have gone by -- solve_kernel then copies the parked iterate (Solver::wd_store), so that no store of the procedure sits inside
+                 * this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
+                int reason = park;
+                if (WD_FULL && reason == 0 && P.wdTrigger > 0 && !in_wd && !wd_arm && !skip_first && wd_short >= P.wdTrigger) reason = STATUS_WDSTART;
+                if (reason != 0) {
+                    __syncthreads();
+                    stash<H_ALL>();
+#pragma unroll
+                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
+                    if (c.tid == 0) {
+                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = park_theta; wf(W_SCAL, SC_PHI) = park_phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
+                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
+                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + (reason == STATUS_RESTO ? 1 : 0);
+                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = 0;
+                        wf(W_SCAL, SC_WD_ARM) = reason == STATUS_WDSTART ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    status = reason; break;
+                }
+            }
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
             double h0[SPT][HV], h1[SPT][HV];
             if constexpr (FL) {
@@ -3290,7 +3301,7 @@ struct Solver {
                 fused_pass(iter == 0, E, h0, h1);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
                 c.mark(PH_KKT); phase_fence(PH_KKT);
             } else {
-                if (iter > 0 || (HAS_RESTO && !FL && resume)) evaluate_current();
+                if (iter > 0 || (RESUMABLE && !FL && resume)) evaluate_current();
                 c.mark(PH_EVAL); phase_fence(PH_EVAL);
                 kkt_pass(E);
                 c.mark(PH_KKT); phase_fence(PH_KKT);
@@ -3384,6 +3395,8 @@ struct Solver {
             } else {
 
             /* search direction with inertia correction (W&B Algorithm IC); one call site */
+            const double delta_last_in = delta_last;      /* (inertia history as this iteration found it: what a repeat of the iteration has to start from) */
+            const int n_reg_in = n_reg;
             double dw = 0;
             bool ok;
             for (bool first = true;; first = false) {
@@ -3396,13 +3409,10 @@ struct Solver {
             if (!ok) { status = MSD_STATUS_REGULARIZATION; break; }
             if (dw > 0) delta_last = dw;
 
-            /* directional derivative of the barrier function, step norms; line search.  The loop is gone round a second time when the watchdog procedure
-             * puts its reference point back: the stored direction is measured again at the stored iterate */
+            /* directional derivative of the barrier function, step norms */
             double gphid = 0, amax = 1.0, alpha = 0, th_ref = theta, ph_ref = phi, gd_ref = 0;
-            bool tiny = false, accepted = false, ftype_armijo = false, skip_first = false, wd_forced = false, quit_tiny = false, not_tiny = false;
+            bool tiny = false, accepted = false, ftype_armijo = false, wd_forced = false, wd_stop = false;
             int ls = 0;
-#pragma unroll 1
-            for (;;) {
             bool tiny_step;
             {
                 double gd = 0, dn = 0, rel = -1.0, rp = 0, rd = 0;
@@ -3476,21 +3486,22 @@ struct Solver {
             }
             c.mark(PH_GPHID); phase_fence(PH_GPHID);
 
-            tiny = tiny_step && !not_tiny;
-            if (MSD_WATCHDOG && in_wd && tiny) {
-                /* a tiny step ends a running watchdog procedure: everything resumes from the stored point with the stored direction */
-                watchdog_restore();
-                in_wd = false; wd_short = 0; dw = wd_dw; theta = wd_theta; phi = wd_phi; not_tiny = true;
-                continue;
-            }
-            if (MSD_WATCHDOG && P.wdTrigger > 0 && !in_wd && !tiny && wd_short >= P.wdTrigger) {
-                watchdog_store();
-                wd_theta = theta; wd_phi = phi; wd_gphid = gphid; wd_dw = dw; wd_trial = 0; in_wd = true; n_wd++;
+            tiny = tiny_step;
+            bool wd_skip = false;      /* how the iteration is entered again after the watchdog procedure has been stopped */
+            if (WD_FULL && in_wd && tiny) wd_stop = true;      /* a tiny step ends a running procedure: everything resumes from the stored point */
+            if (WD_HANDOVER && P.wdTrigger > 0 && !tiny && wd_short >= P.wdTrigger) { status = STATUS_GENERAL; why_general = 6; break; }      /* the procedure is due: the follow-up kernel's */
+            if (WD_FULL && wd_arm) {
+                /* StartWatchDog: the iterate of this iteration is in the watchdog's copy already (parked at the top of the loop, copied by the caller).
+                 * The search direction is not kept: it is the Newton direction of that iterate, the same numbers when the iteration is entered again */
+                wd_arm = false;
+                if (P.wdTrigger > 0 && !in_wd && !tiny && wd_short >= P.wdTrigger) {
+                    wd_theta = theta; wd_phi = phi; wd_gphid = gphid; wd_delta_last = delta_last_in; wd_reg_inc = n_reg - n_reg_in; wd_trial = 0; in_wd = true; n_wd++;
+                }
             }
             alpha = amax; accepted = false;
-            if (tiny) {
+            if (tiny && !wd_stop) {
                 accepted = true;
-                if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { quit_tiny = true; break; }
+                if (++tiny_count >= 2 && mu <= mu_floor*(1 + 1e-12)) { status = MSD_STATUS_TINY_STEP; break; }
             } else tiny_count = 0;
 
             /* reference point of the acceptance tests: the current one, or the watchdog's */
@@ -3505,7 +3516,7 @@ struct Solver {
             if (skip_first) alpha = 0.5*amax;
             ls = 0;
             bool okt_last = true;
-            while (!accepted) {
+            while (!accepted && !wd_stop) {
                 double th_t, ph_t; bool okt;
                 merit(alpha, mu, th_t, ph_t, okt);
                 okt_last = okt;
@@ -3520,7 +3531,7 @@ struct Solver {
                     accepted = true; ftype_armijo = ftype && cmp_le(ph_t - ph_ref, ETA_PHI*alpha*gd_ref, ph_ref);
                     break;
                 }
-                if (MSD_WATCHDOG && in_wd) break;      /* only the full step is tried while the watchdog procedure runs */
+                if (WD_FULL && in_wd) break;      /* only the full step is tried while the watchdog procedure runs */
                 /* second-order correction (W&B section 2.4): rare, kept out of the hot path */
                 if (ls == 0 && !skip_first && okt && th_t >= th_ref) {
                     double th_prev = th_t, alpha_soc = alpha; int nsoc = 0;
@@ -3559,15 +3570,29 @@ struct Solver {
                 alpha *= 0.5; ls++; n_back++;
                 if (alpha < amin) break;
             }
-            if (!(MSD_WATCHDOG && in_wd) || tiny) break;
-            if (accepted) { in_wd = false; break; }      /* the procedure has succeeded: the filter gets the reference point below */
-            wd_trial++;
-            if (okt_last && wd_trial <= WD_TRIAL_MAX) { accepted = true; wd_forced = true; break; }      /* taken although the filter does not accept it */
-            /* no success: back to the stored point, ordinary line search on the stored direction from half the maximal step */
-            watchdog_restore();
-            in_wd = false; wd_short = 0; dw = wd_dw; theta = wd_theta; phi = wd_phi; skip_first = true;
+            if (WD_FULL && in_wd && !wd_stop) {
+                if (accepted) in_wd = false;      /* the procedure has succeeded: the filter gets the reference point below */
+                else {
+                    wd_trial++;
+                    if (okt_last && wd_trial <= WD_TRIAL_MAX) { accepted = true; wd_forced = true; }      /* taken although the filter does not accept it */
+                    else { wd_stop = true; wd_skip = true; }      /* no success: back to the stored point, ordinary line search from half the maximal step */
+                }
             }
-            if (quit_tiny) { status = MSD_STATUS_TINY_STEP; break; }
+            if (WD_FULL && wd_stop) {
+                /* StopWatchDog: the scalars of this iteration to the work area; the caller copies the stored iterate back (wd_restore) and enters the
+                 * iteration again (`resume`), which recomputes what belongs to that point -- the search direction included */
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
+                if (c.tid == 0) {
+                    wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
+                    wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = wd_delta_last;
+                    wf(W_SCAL, SC_N_REG) = n_reg - wd_reg_inc; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto;
+                    wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = 0; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = wd_skip ? 1.0 : 0.0; wf(W_SCAL, SC_WD_ARM) = 0;
+                }
+                __syncthreads();
+                status = STATUS_WDSTOP; break;
+            }
             if (!accepted) {
                 /* the step became too small: feasibility restoration (IpBacktrackingLineSearch), unless the point is almost feasible
                  * (resto_failure_feasibility_threshold = 100 tol).  The current point enters the filter; the iterate and the scalars
@@ -3575,21 +3600,13 @@ struct Solver {
                 if (HAS_RESTO && P.resto && E.primal > 1e2*P.tol) {
                     __syncthreads();
                     if (nfilt < FILT_CAP) { if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; } nfilt++; }
-                    stash<H_ALL>();
-#pragma unroll
-                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
-                    if (c.tid == 0) {
-                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = theta; wf(W_SCAL, SC_PHI) = phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
-                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
-                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + 1;
-                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd;
-                    }
                     __syncthreads();
-                    status = STATUS_RESTO; break;
+                    park = STATUS_RESTO; park_theta = theta; park_phi = phi;
+                    iter--; continue;      /* (to the park site at the top of the loop, in the same iteration) */
                 }
                 status = MSD_STATUS_LINESEARCH; break;
             }
-            alpha_pr = alpha;
+            alpha_pr = alpha; skip_first = false;
             if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (n_steps == 0 / n_steps > 1 of IpBacktrackingLineSearch: shortened iterations) */
             c.mark(PH_MERIT); phase_fence(PH_MERIT);
 
@@ -3638,8 +3655,8 @@ struct Solver {
             c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
             }      /* (general iteration) */
         }
-        if (FL && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path solves the scenario */
-        if (status == STATUS_RESTO) { iters_out = iter; return status; }
+        if ((FL || WD_HANDOVER) && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path / the follow-up kernel solves the scenario */
+        if (status == STATUS_RESTO || status == STATUS_WDSTOP || status == STATUS_WDSTART) { iters_out = iter; return status; }
 
         /* ---- the multipliers for a later primal-dual warm start ---- */
         if (dual_out) {
@@ -3819,10 +3836,19 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             }
             if constexpr (SolverT::FIRST && !FASTK) {
                 /* first pass of a family without a fused iteration: the general one without the restoration phase */
-                st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
-                                           lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                           (hist && sidx == 0) ? hist : nullptr, hist_cap);
-                __syncthreads();
+                bool resume = false;
+#pragma unroll 1
+                for (;;) {      /* (entered again when the watchdog procedure has put its reference point back) */
+                    st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                                               lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
+                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
+                    __syncthreads();
+                    if (st == SolverT::STATUS_WDSTART) SolverT::wd_store(wg_work, c.tid, c.nt);
+                    else if (st == SolverT::STATUS_WDSTOP) SolverT::wd_restore(wg_work, c.tid, c.nt);
+                    else break;
+                    __syncthreads();
+                    resume = true;
+                }
             }
             if constexpr (SolverT::FIRST) {
                 /* done (solved, or out of iterations: no second attempt for that) -- or the follow-up kernel's: the general iteration from the same
@@ -3854,6 +3880,8 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                                                lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
                                                (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
                     __syncthreads();
+                    if (st == SolverT::STATUS_WDSTOP) { SolverT::wd_restore(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* the watchdog procedure puts its reference point back */
+                    if (st == SolverT::STATUS_WDSTART) { SolverT::wd_store(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* ... takes its copy of the iterate */
                     if constexpr (SolverT::HAS_RESTO) {
                         if (st != SolverT::STATUS_RESTO) break;
                         resto_entry<NT, SPT, DYN, GEN, FULL>(Pl, c, wg_work, Ul, scen + (size_t)MSD_SC_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);

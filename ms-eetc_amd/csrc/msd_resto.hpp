@@ -25,7 +25,7 @@ static constexpr int RESTO_MAX_ITER = 100;             /* iterations of one rest
                                                         * those that succeed take 1 to 30 -- is given up: Restoration_Failed, then the restart from the other starting point) */
 static constexpr int NCR = 2 + NR;
 /* scalars handed over in field W_SCAL */
-enum { SC_MU = 0, SC_THETA, SC_PHI, SC_ITER, SC_NFILT, SC_THETA_MAX, SC_THETA_MIN, SC_DELTA_LAST, SC_N_REG, SC_N_SOC, SC_N_BACK, SC_N_RESTO, SC_FORCED, SC_OBJ, SC_WD_SHORT, SC_N_WD };
+enum { SC_MU = 0, SC_THETA, SC_PHI, SC_ITER, SC_NFILT, SC_THETA_MAX, SC_THETA_MIN, SC_DELTA_LAST, SC_N_REG, SC_N_SOC, SC_N_BACK, SC_N_RESTO, SC_FORCED, SC_OBJ, SC_WD_SHORT, SC_N_WD, SC_SKIP_FIRST, SC_WD_ARM };
 
 __device__ __forceinline__ double &wf(int field, int slot) const { return work[(size_t)field*NS + slot]; }
 __device__ __forceinline__ bool rs_on(int jr) const { return jr < 2 || rowOn(jr >= 2 ? jr - 2 : 0); }

@@ -7,6 +7,11 @@
  * (one thread per stage, sparsity-exploiting Riccati); the two only share the mathematics.
  *
  * Reference citations are relative to the reference repository root.
+ *
+ * What pins it (ms_oracle.h has the list): the reference's stored solutions and figures for the NLP and its optimum.  The interior-point
+ * algorithm itself is IPOPT's, an un-vendored dependency of the reference (ocp.py:290,359): restated from the published algorithm (Waechter &
+ * Biegler 2006) and implementation -- for the restoration phase and the watchdog procedure no vector of the reference exists: PARITY UNPINNED
+ * for those two (their sections below say what they were restated from and what the tests check instead).
  */
 #include "ms_oracle.h"
 

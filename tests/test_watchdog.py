@@ -140,23 +140,27 @@ def test_gpu_watchdog_with_a_lowered_trigger_vs_oracle():
 
 
 @gpu
-@pytest.mark.parametrize('N,T', [(600, 12000.0), (600, 14000.0), (700, 12000.0), (700, 20000.0)])
-def test_gpu_watchdog_starts_at_ipopts_trigger_on_loose_schedules_of_long_horizons(N, T):
+@pytest.mark.parametrize('N', [600, 700])
+def test_gpu_watchdog_starts_at_ipopts_trigger_on_loose_schedules_of_long_horizons(N):
     """
     IPOPT's own trigger (10 shortened iterations in a row): loose schedules on 600 / 700 intervals from the reference's starting point run into it
     -- in the oracle and on the device (five-wave kernel followed up by the streamed one; the streamed kernel) -- between restoration phases.
+    These solves crawl for hundreds of iterations with steps of 1e-4 and less; the two implementations do not stay together iterate for iterate
+    there (tools/wd_probe.py, profiles/r04/watchdog_device.txt: the procedure starts in both, not always in the same scenarios), the optimum
+    they reach is the same to the last digits.
     """
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
     from oracle import oracle
     train, track = cases.train_default(), cases.track_00()
+    Ts = np.linspace(8000, 20000, 8)
     s = casadiSolver(train, track, dict(numIntervals=N, maxIterations=800, integrationOptions=RK11), startingPoint='reference')
-    res = s.solveBatch([T])
+    res = s.solveBatch(Ts)
     s.close()
     prob = cases.oracle_problem(train, track, N, maxIterations=800)
-    ref = oracle.solve(prob, prob.scenario(T), start='reference')
-    assert res['status'][0] == int(ref['stats']['STATUS']) == 0
-    assert int(ref['stats']['N_WATCHDOG']) >= 1 and int(res['stats'][0, ST['N_WATCHDOG']]) >= 1
-    assert int(ref['stats']['N_RESTO']) >= 1 and int(res['stats'][0, ST['N_RESTO']]) >= 1
-    assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ'])
-    assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
+    z, st, nfail = oracle.solve_batch(prob, np.array([[0.0, T, 1.0, 1.0] for T in Ts]), start='reference')
+    assert nfail == 0 and np.all(res['status'] == 0)
+    assert st[:, oracle.ST['N_WATCHDOG']].sum() >= 1 and res['stats'][:, ST['N_WATCHDOG']].sum() >= 1
+    assert st[:, oracle.ST['N_RESTO']].sum() >= 1 and res['stats'][:, ST['N_RESTO']].sum() >= 1
+    assert np.max(np.abs(res['cost'] - st[:, oracle.ST['OBJ']])/np.abs(st[:, oracle.ST['OBJ']])) <= 1e-7
+    assert np.max(np.abs(res['z'] - z)/np.maximum(1, np.abs(z))) < 1e-4
