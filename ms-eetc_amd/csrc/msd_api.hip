@@ -144,7 +144,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = P.grad = P.curv = P.bmax = P.pos = nullptr;      /* (the owner of the profile buffer fills these) */
     P.loss = nullptr;
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
@@ -205,15 +205,26 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
 {
     if (!pl.kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
     msd::DevProb P = pl.P;
-    P.follow = nullptr; P.queue = nullptr;
+    P.follow = nullptr; P.list = nullptr; P.queue = nullptr;
     P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
     P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
     const bool split = pl.kernel2 != nullptr;
+    const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
+    const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);
     if (d_list) {
-        /* the scenarios of a list, by the kernel that holds everything (an idle workgroup returns at once) */
+        /* the scenarios of a list (an idle workgroup returns at once): through the first pass + follow-up kernel like a whole batch when the plan is split
+         * -- the list is the first pass's input, its own hand-overs go to d_follow -- otherwise by the kernel that holds everything */
+        P.list = d_list;
+        if (first_pass) {
+            if (!d_follow) return fail(MSD_E_INVALID, "split solve without its list");
+            P.follow = d_follow;
+            const msd::KernelFn f1 = plain ? pl.kernel : pl.kernel_lsq;
+            hipLaunchKernelGGL(f1, dim3(std::min(nscen, plain ? pl.max_grid : pl.max_grid_lsq)), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
+            HIP_TRY(hipGetLastError());
+            P.list = d_follow; P.follow = nullptr;
+        }
         const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
         const int cap = split ? pl.max_grid2 : pl.max_grid;
-        P.follow = d_list;
         hipLaunchKernelGGL(fn, dim3(std::min(nscen, cap)), dim3(split ? pl.NT2 : pl.NT), split ? pl.lds_bytes2 : pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
         HIP_TRY(hipGetLastError());
         return MSD_OK;
@@ -221,8 +232,6 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     /* split solves (msd::Geometry::fn2): first pass + follow-up kernel behind it on the stream, the list of unfinished scenarios between them.
      * The first pass is the kernel without the least-squares multiplier estimate when every scenario can start without it (profile start,
      * primal-dual warm start), the one with it otherwise (the reference's starting point, a primal-only warm start) */
-    const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
-    const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);
     const msd::KernelFn fn = (split && !first_pass) ? pl.kernel2 : plain ? pl.kernel : pl.kernel_lsq;
     const int cap = (split && !first_pass) ? pl.max_grid2 : plain ? pl.max_grid : pl.max_grid_lsq;
     const int grid = nscen < cap ? nscen : cap;
@@ -246,7 +255,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         /* the follow-up kernel: usually nothing to do (0 of the 1024 + 8192 benchmark scenarios of configs 1 and 2) -- a workgroup that finds
          * the list empty returns at once, the others take scenarios off it until it is empty */
         const int grid2 = std::min(nscen, pl.max_grid2);
-        P.queue = nullptr;
+        P.queue = nullptr; P.list = d_follow; P.follow = nullptr;
         hipLaunchKernelGGL(pl.kernel2, dim3(grid2), dim3(pl.NT2), pl.lds_bytes2, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
         HIP_TRY(hipGetLastError());
     }

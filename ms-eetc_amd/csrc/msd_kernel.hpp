@@ -104,6 +104,8 @@ struct DevProb {
      * launch of the handle), [FOLLOW_HDR + 2k] scenario, [FOLLOW_HDR + 2k + 1] iterations already spent on it (>= 0: its first attempt broke down,
      * the follow-up kernel begins with the second one) or -1 (nothing decided yet: the general iteration from the same starting point) */
     int *follow;
+    int *list;               /* not null: the kernel solves the scenarios of this list only (same layout as `follow`: the follow-up kernel's input is the first pass's
+                              * `follow`; a first-pass kernel can be given a list too -- msd_mpc.hip's re-solves -- and hands over through `follow` as usual) */
 };
 /* behind the three counters: telemetry that is never reset -- [3] scenarios listed so far, [4 + why] by reason: 0 no fused start for the scenario
  * (a warm start whose previous solve failed), 1 wrong inertia or a scan breakdown, 2 tiny step, 3 first trial point rejected where a
@@ -3065,7 +3067,7 @@ struct Solver {
             if (ival) fl |= F_ON_S;
             nd.flags = fl;
             nd.ubB = bm + K_BOUND_RELAX*fmax(1.0, fabs(bm));
-            if (RESUMABLE && !FL && resume) continue;      /* (the iterate is the one the restoration phase / the watchdog procedure left: in the work area, which is where a streamed kernel's fields live) */
+            if (STREAM && RESUMABLE && !FL && resume) continue;      /* (the iterate is the one the restoration phase / the watchdog procedure left: in the work area, which is where a streamed kernel's fields live) */
             /* cold start (ocp.py:325-339) */
             const double dt = (tEnd - t0)/N, vel0 = (60/3.6)*(60/3.6);
             nd.x[VT] = t0 + dt*nd.i; nd.x[VB] = vel0; nd.x[VF] = 0.5; nd.x[VP] = withPn() ? -0.1 : 0.0; nd.x[VS] = 1;
@@ -3261,32 +3263,7 @@ struct Solver {
             }
         }
 
-        int park = 0;                      /* why the iterate is parked at the top of the next pass (STATUS_RESTO) */
-        double park_theta = 0, park_phi = 0;
         for (iter = iter_first;; iter++) {
-            if constexpr (RESUMABLE && !FL) {
-                /* The one place where the general iteration leaves with its iterate parked in the work area, to be entered again (`resume`): for the
-                 * restoration phase (the line search of the pass before broke down) and for the watchdog procedure, which is due when ten shortened
-                 * iterations have gone by -- solve_kernel then copies the parked iterate (Solver::wd_store), so that no store of the procedure sits inside
-                 * this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
-                int reason = park;
-                if (WD_FULL && reason == 0 && P.wdTrigger > 0 && !in_wd && !wd_arm && !skip_first && wd_short >= P.wdTrigger) reason = STATUS_WDSTART;
-                if (reason != 0) {
-                    __syncthreads();
-                    stash<H_ALL>();
-#pragma unroll
-                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
-                    if (c.tid == 0) {
-                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = park_theta; wf(W_SCAL, SC_PHI) = park_phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
-                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
-                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + (reason == STATUS_RESTO ? 1 : 0);
-                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = 0;
-                        wf(W_SCAL, SC_WD_ARM) = reason == STATUS_WDSTART ? 1.0 : 0.0;
-                    }
-                    __syncthreads();
-                    status = reason; break;
-                }
-            }
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
             double h0[SPT][HV], h1[SPT][HV];
             if constexpr (FL) {
@@ -3395,6 +3372,7 @@ struct Solver {
             } else {
 
             /* search direction with inertia correction (W&B Algorithm IC); one call site */
+            int park = 0;      /* why the iteration leaves with its iterate parked (STATUS_RESTO, STATUS_WDSTART), at the end of this block */
             const double delta_last_in = delta_last;      /* (inertia history as this iteration found it: what a repeat of the iteration has to start from) */
             const int n_reg_in = n_reg;
             double dw = 0;
@@ -3601,11 +3579,10 @@ struct Solver {
                     __syncthreads();
                     if (nfilt < FILT_CAP) { if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; } nfilt++; }
                     __syncthreads();
-                    park = STATUS_RESTO; park_theta = theta; park_phi = phi;
-                    iter--; continue;      /* (to the park site at the top of the loop, in the same iteration) */
-                }
-                status = MSD_STATUS_LINESEARCH; break;
+                    park = STATUS_RESTO;      /* (to the park site at the end of the loop body) */
+                } else { status = MSD_STATUS_LINESEARCH; break; }
             }
+            if (park == 0) {
             alpha_pr = alpha; skip_first = false;
             if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (n_steps == 0 / n_steps > 1 of IpBacktrackingLineSearch: shortened iterations) */
             c.mark(PH_MERIT); phase_fence(PH_MERIT);
@@ -3653,6 +3630,30 @@ struct Solver {
                 }
             }
             c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
+            }      /* (park == 0: the step has been taken) */
+            if constexpr (RESUMABLE) {
+                /* The one place where the general iteration leaves with its iterate parked in the work area, to be entered again (`resume`): for the
+                 * restoration phase (the line search of this iteration broke down; the step above was skipped) and for the watchdog procedure, which is due
+                 * when ten shortened iterations have gone by -- solve_kernel then copies the parked iterate (Solver::wd_store), so that no store of the
+                 * procedure sits inside this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
+                int at = iter;      /* the iteration that is entered again */
+                if (WD_FULL && park == 0 && P.wdTrigger > 0 && !in_wd && wd_short >= P.wdTrigger) { park = STATUS_WDSTART; at = iter + 1; }
+                if (park != 0) {
+                    __syncthreads();
+                    stash<H_ALL>();
+#pragma unroll
+                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
+                    if (c.tid == 0) {
+                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = theta; wf(W_SCAL, SC_PHI) = phi; wf(W_SCAL, SC_ITER) = at; wf(W_SCAL, SC_NFILT) = nfilt;
+                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
+                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + (park == STATUS_RESTO ? 1 : 0);
+                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = 0;
+                        wf(W_SCAL, SC_WD_ARM) = park == STATUS_WDSTART ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    status = park; iter = at; break;
+                }
+            }
             }      /* (general iteration) */
         }
         if ((FL || WD_HANDOVER) && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path / the follow-up kernel solves the scenario */
@@ -3746,7 +3747,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
 {
     HIP_DYNAMIC_SHARED(double, lds)
     constexpr int NS = NT*SPT;     /* node slots */
-    if ((PART == 2 || PART == 0) && P.follow && P.follow[0] == 0) return;      /* nothing listed (the usual case): the list header is clear already */
+    if (P.list && P.list[0] == 0) return;      /* nothing listed (the usual case): the list header is clear already */
     Ctx c;
     c.tid = threadIdx.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = NT/64; c.nt = NT; c.red_slot = 0;
     double *wg_work = work + (STREAM ? stream_doubles(P.N, NS, DYN) : work_doubles(NS))*blockIdx.x;
@@ -3779,16 +3780,16 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
      * workgroup that finishes early takes the next scenario instead of idling behind a static stride (matters once the batch is
      * several times the resident workgroups: configs 2-4).  queue == null: static stride. */
     constexpr int MISC_NEXT = 25, MISC_SPENT = 26;
-    const bool listed = (PART == 2 || PART == 0) && P.follow != nullptr;      /* the follow-up kernel works off the list of the first pass (any complete kernel can be launched on a list: msd_mpc.hip) */
+    const bool listed = P.list != nullptr;      /* the follow-up kernel works off the list of the first pass (any complete kernel can be launched on a list: msd_mpc.hip) */
     for (int turn = 0;; turn++) {
         int sidx, spent0 = -1;
         if (listed) {
             __syncthreads();
             if (c.tid == 0) {
-                const int k = atomicAdd(P.follow + 1, 1);
-                const bool have = k < P.follow[0];      /* (complete: the first pass has ended) */
-                c.misc[MISC_NEXT] = have ? (double)P.follow[FOLLOW_HDR + 2*k] : (double)nscen;
-                c.misc[MISC_SPENT] = have ? (double)P.follow[FOLLOW_HDR + 2*k + 1] : -1.0;
+                const int k = atomicAdd(P.list + 1, 1);
+                const bool have = k < P.list[0];      /* (complete: the kernel that wrote the list has ended) */
+                c.misc[MISC_NEXT] = have ? (double)P.list[FOLLOW_HDR + 2*k] : (double)nscen;
+                c.misc[MISC_SPENT] = have ? (double)P.list[FOLLOW_HDR + 2*k + 1] : -1.0;
             }
             __syncthreads();
             sidx = wg_uniform((int)c.misc[MISC_NEXT]); spent0 = wg_uniform((int)c.misc[MISC_SPENT]);
@@ -3843,11 +3844,13 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                                                lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
                                                (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
                     __syncthreads();
-                    if (st == SolverT::STATUS_WDSTART) SolverT::wd_store(wg_work, c.tid, c.nt);
-                    else if (st == SolverT::STATUS_WDSTOP) SolverT::wd_restore(wg_work, c.tid, c.nt);
-                    else break;
-                    __syncthreads();
-                    resume = true;
+                    if constexpr (SolverT::WD_FULL) {
+                        if (st == SolverT::STATUS_WDSTART) SolverT::wd_store(wg_work, c.tid, c.nt);
+                        else if (st == SolverT::STATUS_WDSTOP) SolverT::wd_restore(wg_work, c.tid, c.nt);
+                        else break;
+                        __syncthreads();
+                        resume = true;
+                    } else break;
                 }
             }
             if constexpr (SolverT::FIRST) {
@@ -3880,8 +3883,10 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                                                lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
                                                (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
                     __syncthreads();
-                    if (st == SolverT::STATUS_WDSTOP) { SolverT::wd_restore(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* the watchdog procedure puts its reference point back */
-                    if (st == SolverT::STATUS_WDSTART) { SolverT::wd_store(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* ... takes its copy of the iterate */
+                    if constexpr (SolverT::WD_FULL) {
+                        if (st == SolverT::STATUS_WDSTOP) { SolverT::wd_restore(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* the watchdog procedure puts its reference point back */
+                        if (st == SolverT::STATUS_WDSTART) { SolverT::wd_store(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* ... takes its copy of the iterate */
+                    }
                     if constexpr (SolverT::HAS_RESTO) {
                         if (st != SolverT::STATUS_RESTO) break;
                         resto_entry<NT, SPT, DYN, GEN, FULL>(Pl, c, wg_work, Ul, scen + (size_t)MSD_SC_COUNT*sidx, (hist && sidx == 0) ? hist : nullptr, hist_cap);
@@ -3905,7 +3910,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         __syncthreads();
         if (c.tid == 0) {
             __threadfence();
-            if (atomicAdd(P.follow + 2, 1) == (int)gridDim.x - 1) { P.follow[0] = 0; P.follow[1] = 0; P.follow[2] = 0; __threadfence(); }
+            if (atomicAdd(P.list + 2, 1) == (int)gridDim.x - 1) { P.list[0] = 0; P.list[1] = 0; P.list[2] = 0; __threadfence(); }
         }
     }
 }

@@ -10,6 +10,7 @@ template <int NT, int SPT, int KIND> static void run_split(EmuArgs a)
     const bool plain = a.P.guess ? a.P.dualIn != nullptr : a.P.start == MSD_START_PROFILE;      /* like msd_api.hip: launch() */
     if (plain) EMU_CALL(NT, SPT, false, false, false, KIND, 1); else EMU_CALL(NT, SPT, false, false, false, KIND, 3);
     /* the follow-up kernel of the one-node-per-lane geometry is the two-nodes-per-lane one (msd_api.hip: make_plan) */
+    a.P.list = follow.data(); a.P.follow = nullptr;
     if (NT == 64 && SPT == 1) EMU_CALL(64, 2, false, false, false, KIND, 2); else EMU_CALL(NT, SPT, false, false, false, KIND, 2);
 }
 

@@ -8,6 +8,7 @@ template <int NT, int SPT> static void run_split(EmuArgs a)
     std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
     a.P.follow = follow.data();
     EMU_CALL(NT, SPT, 0, false, true, 0, 1);
+    a.P.list = follow.data(); a.P.follow = nullptr;
     EMU_CALL(128, 5, 0, true, true);
 }
 

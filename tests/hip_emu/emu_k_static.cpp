@@ -15,7 +15,9 @@ bool emu_run_static(int NT, int SPT, const EmuArgs &a)
         EmuArgs b = a;
         std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
         b.P.follow = follow.data();
-        { const EmuArgs &a = b; EMU_CALL(320, 2, 0, false, false, 0, 1); EMU_CALL(128, 5, 0, true); }
+        { const EmuArgs &a = b; EMU_CALL(320, 2, 0, false, false, 0, 1); }
+        b.P.list = follow.data(); b.P.follow = nullptr;
+        { const EmuArgs &a = b; EMU_CALL(128, 5, 0, true); }
         return true;
     }
     return false;
