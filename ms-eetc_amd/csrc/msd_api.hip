@@ -212,19 +212,12 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
     const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);
     if (d_list) {
-        /* the scenarios of a list (an idle workgroup returns at once): through the first pass + follow-up kernel like a whole batch when the plan is split
-         * -- the list is the first pass's input, its own hand-overs go to d_follow -- otherwise by the kernel that holds everything */
-        P.list = d_list;
-        if (first_pass) {
-            if (!d_follow) return fail(MSD_E_INVALID, "split solve without its list");
-            P.follow = d_follow;
-            const msd::KernelFn f1 = plain ? pl.kernel : pl.kernel_lsq;
-            hipLaunchKernelGGL(f1, dim3(std::min(nscen, plain ? pl.max_grid : pl.max_grid_lsq)), dim3(pl.NT), pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
-            HIP_TRY(hipGetLastError());
-            P.list = d_follow; P.follow = nullptr;
-        }
+        /* the scenarios of a list, by the kernel that holds everything (an idle workgroup returns at once).  (A first-pass kernel takes an input list
+         * too -- DevProb::list next to DevProb::follow -- but sending the receding-horizon loop's few re-solves through first pass + follow-up kernel
+         * costs more in launches than the fused iteration saves: 184 k against 205 k successful re-solves/s on config 4, gpurun_out/bench_wd4.json) */
         const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
         const int cap = split ? pl.max_grid2 : pl.max_grid;
+        P.list = d_list;
         hipLaunchKernelGGL(fn, dim3(std::min(nscen, cap)), dim3(split ? pl.NT2 : pl.NT), split ? pl.lds_bytes2 : pl.lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
         HIP_TRY(hipGetLastError());
         return MSD_OK;

@@ -3263,7 +3263,32 @@ struct Solver {
             }
         }
 
+        int park = 0;                      /* why the iterate is parked at the top of the next pass (STATUS_RESTO) */
+        double park_theta = 0, park_phi = 0;
         for (iter = iter_first;; iter++) {
+            if constexpr (RESUMABLE && !FL) {
+                /* The one place where the general iteration leaves with its iterate parked in the work area, to be entered again (`resume`): for the
+                 * restoration phase (the line search of the pass before broke down) and for the watchdog procedure, which is due when ten shortened
+                 * iterations have gone by -- solve_kernel then copies the parked iterate (Solver::wd_store), so that no store of the procedure sits inside
+                 * this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
+                int reason = park;
+                if (WD_FULL && reason == 0 && P.wdTrigger > 0 && !in_wd && !wd_arm && !skip_first && wd_short >= P.wdTrigger) reason = STATUS_WDSTART;
+                if (reason != 0) {
+                    __syncthreads();
+                    stash<H_ALL>();
+#pragma unroll
+                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
+                    if (c.tid == 0) {
+                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = park_theta; wf(W_SCAL, SC_PHI) = park_phi; wf(W_SCAL, SC_ITER) = iter; wf(W_SCAL, SC_NFILT) = nfilt;
+                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
+                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + (reason == STATUS_RESTO ? 1 : 0);
+                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = 0;
+                        wf(W_SCAL, SC_WD_ARM) = reason == STATUS_WDSTART ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    status = reason; break;
+                }
+            }
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
             double h0[SPT][HV], h1[SPT][HV];
             if constexpr (FL) {
@@ -3372,7 +3397,6 @@ struct Solver {
             } else {
 
             /* search direction with inertia correction (W&B Algorithm IC); one call site */
-            int park = 0;      /* why the iteration leaves with its iterate parked (STATUS_RESTO, STATUS_WDSTART), at the end of this block */
             const double delta_last_in = delta_last;      /* (inertia history as this iteration found it: what a repeat of the iteration has to start from) */
             const int n_reg_in = n_reg;
             double dw = 0;
@@ -3579,10 +3603,11 @@ struct Solver {
                     __syncthreads();
                     if (nfilt < FILT_CAP) { if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; } nfilt++; }
                     __syncthreads();
-                    park = STATUS_RESTO;      /* (to the park site at the end of the loop body) */
-                } else { status = MSD_STATUS_LINESEARCH; break; }
+                    park = STATUS_RESTO; park_theta = theta; park_phi = phi;
+                    iter--; continue;      /* (to the park site at the top of the loop, in the same iteration) */
+                }
+                status = MSD_STATUS_LINESEARCH; break;
             }
-            if (park == 0) {
             alpha_pr = alpha; skip_first = false;
             if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (n_steps == 0 / n_steps > 1 of IpBacktrackingLineSearch: shortened iterations) */
             c.mark(PH_MERIT); phase_fence(PH_MERIT);
@@ -3630,30 +3655,6 @@ struct Solver {
                 }
             }
             c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
-            }      /* (park == 0: the step has been taken) */
-            if constexpr (RESUMABLE) {
-                /* The one place where the general iteration leaves with its iterate parked in the work area, to be entered again (`resume`): for the
-                 * restoration phase (the line search of this iteration broke down; the step above was skipped) and for the watchdog procedure, which is due
-                 * when ten shortened iterations have gone by -- solve_kernel then copies the parked iterate (Solver::wd_store), so that no store of the
-                 * procedure sits inside this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
-                int at = iter;      /* the iteration that is entered again */
-                if (WD_FULL && park == 0 && P.wdTrigger > 0 && !in_wd && wd_short >= P.wdTrigger) { park = STATUS_WDSTART; at = iter + 1; }
-                if (park != 0) {
-                    __syncthreads();
-                    stash<H_ALL>();
-#pragma unroll
-                    for (int j = 0; j < SPT; j++) { wf(W_SC, n[j].i) = n[j].sct; wf(W_SC + 1, n[j].i) = n[j].scb; }
-                    if (c.tid == 0) {
-                        wf(W_SCAL, SC_MU) = mu; wf(W_SCAL, SC_THETA) = theta; wf(W_SCAL, SC_PHI) = phi; wf(W_SCAL, SC_ITER) = at; wf(W_SCAL, SC_NFILT) = nfilt;
-                        wf(W_SCAL, SC_THETA_MAX) = theta_max; wf(W_SCAL, SC_THETA_MIN) = theta_min; wf(W_SCAL, SC_DELTA_LAST) = delta_last;
-                        wf(W_SCAL, SC_N_REG) = n_reg; wf(W_SCAL, SC_N_SOC) = n_soc; wf(W_SCAL, SC_N_BACK) = n_back; wf(W_SCAL, SC_N_RESTO) = n_resto + (park == STATUS_RESTO ? 1 : 0);
-                        wf(W_SCAL, SC_FORCED) = 0; wf(W_SCAL, SC_WD_SHORT) = wd_short; wf(W_SCAL, SC_N_WD) = n_wd; wf(W_SCAL, SC_SKIP_FIRST) = 0;
-                        wf(W_SCAL, SC_WD_ARM) = park == STATUS_WDSTART ? 1.0 : 0.0;
-                    }
-                    __syncthreads();
-                    status = park; iter = at; break;
-                }
-            }
             }      /* (general iteration) */
         }
         if ((FL || WD_HANDOVER) && status == STATUS_GENERAL) { iters_out = iter; return status; }      /* nothing is written: the general path / the follow-up kernel solves the scenario */

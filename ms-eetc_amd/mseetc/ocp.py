@@ -356,7 +356,7 @@ class casadiSolver():
             opts = dict(self._optsDict)
             opts['energyOptimal'] = False
             opts.pop('integrateLosses', None)      # (the loss slacks do not exist in the time-optimal problem)
-            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile', restoration=self.restoration)
+            twin = self._twin = casadiSolver(self.train, self.track, opts, device=self._device, startingPoint='profile', restoration=self.restoration, watchdogTrigger=self.watchdogTrigger)
 
         sub = np.atleast_2d(np.asarray(scen, dtype=float))
         loose = sub.copy()

@@ -29,7 +29,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
                                    double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
-    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
+    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
     std::vector<double> pos(d->num_intervals + 1, 0.0);
     for (int i = 0; i < d->num_intervals; i++) pos[i + 1] = pos[i] + d->ds[i];
     P.pos = pos.data();
