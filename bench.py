@@ -673,6 +673,20 @@ def alt_workloads(args, device):
     out["workload"] = ("config 1 problem, 64 running times 11000 ... 20000 s (8 to 13 times the minimum) from the reference's starting point: with the feasibility "
                        "restoration phase (IPOPT's behaviour, default) and with the restart from the other starting point only")
     alt["loose_schedules_reference_start"] = out
+    # the same kind of schedule on horizons that the streamed kernels solve (700 intervals; 600: five-wave first pass + streamed follow-up kernel): restoration phases
+    # and IPOPT's watchdog procedure (ten shortened iterations in a row) on the device -- profiles/r04/watchdog_survey.txt has the CPU oracle's counts
+    long_out = {}
+    for Nl in (600, 700):
+        s = casadiSolver(train, track, dict(numIntervals=Nl, maxIterations=800, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='reference', device=device)
+        s.solveBatch(np.linspace(8000.0, 20000.0, 16))
+        r = s.solveBatch(np.linspace(8000.0, 20000.0, 16))
+        s.close()
+        long_out["N%d" % Nl] = {"converged": int(np.sum(r['status'] >= 0)), "scenarios": 16, "restoration_phases": int(np.sum(r['stats'][:, ST['N_RESTO']])),
+                                "watchdog_procedures": int(np.sum(r['stats'][:, ST['N_WATCHDOG']])), "ip_iterations_mean": float(np.mean(r['iterations'])),
+                                "kernel_ms": float(r['kernel_ms']), "cost_sum": float(np.sum(r['cost'][r['status'] >= 0]))}
+    long_out["workload"] = ("config 1 track and train on 600 / 700 intervals, 16 running times 8000 ... 20000 s from the reference's starting point: the five-wave kernel followed up by "
+                            "the streamed kernel / the streamed kernel itself, through restoration phases and watchdog procedures")
+    alt["loose_schedules_long_horizons"] = long_out
     return alt
 
 
