@@ -214,7 +214,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     if (d_list) {
         /* the scenarios of a list, by the kernel that holds everything (an idle workgroup returns at once).  (A first-pass kernel takes an input list
          * too -- DevProb::list next to DevProb::follow -- but sending the receding-horizon loop's few re-solves through first pass + follow-up kernel
-         * costs more in launches than the fused iteration saves: 184 k against 205 k successful re-solves/s on config 4, gpurun_out/bench_wd4.json) */
+         * buys nothing: 184 k successful re-solves/s on config 4 either way) */
         const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
         const int cap = split ? pl.max_grid2 : pl.max_grid;
         P.list = d_list;

@@ -87,7 +87,7 @@ class DeviceLoop():
             opts = dict(optsDict); opts['numIntervals'] = Nk
             # (no restoration phase, like shrinkingHorizon: a re-solve that fails is certified and relaxed by the loop itself; no watchdog procedure for the same
             #  reason -- a re-solve that crawls through ten shortened iterations would leave the fused iteration for the follow-up kernel, and a launch lasts as
-            #  long as its slowest scenario: 184 k instead of 205 k successful re-solves/s on config 4)
+            #  long as its slowest scenario.  On config 4 it makes no measurable difference either way)
             solver = casadiSolver(train, current, opts, device=device, restoration=False, watchdogTrigger=-1)
             self.solvers.append(solver)
             if relaxInfeasible:
