@@ -339,10 +339,14 @@ def roofline_block(entry, key, B, N, nz, stage_iters, launch_ms, geo, kernel_ms=
     """
     The roofline object of the bench line for one launch of the solver over B scenarios (stage_iters = N x sum of IP iterations).
     kernel_ms: duration of the dominant kernel alone (the first pass of a split launch; HIP events around it, msd_problem_first_pass_ms),
-    launch_ms: first pass + follow-up kernel.  What bounds the kernel is instruction issue of a lone wave per SIMD, so that is the roof
-    `bound` / `achieved` / `peak` / `frac` describe when the SQ counters of the running library are on file (profiles/hbm_traffic.json,
-    digest-checked); SURVEY 8(d)'s pricing against the HBM roof (streaming model S) is kept next to it in `hbm_model_S` -- and is what the
-    top-level fields fall back to when no counters are on file.
+    launch_ms: first pass + follow-up kernel.
+
+    The top-level fields always mean the same thing (round 5; rounds 3-4 switched them between two roofs depending on whether counters were on
+    file): the bench contract's pricing -- ALGORITHMIC bytes per launch (SURVEY 8(d)'s streaming model S: 904 B per stage-iteration x the
+    stage-iterations of the launch) over the dominant kernel's duration against the HBM peak.  The kernel does not generate that traffic (the
+    iterate is register/LDS resident); what limits it is instruction issue of a lone wave per SIMD, reported in `valu_issue` when the SQ
+    counters of the running library are on file (profiles/hbm_traffic.json, digest-checked).  `frac_useful` = SURVEY 8(d)'s flop model (400
+    flop per stage-iteration) against the FP64 vector peak: efficiency, where `valu_issue.frac` is utilisation.
     """
 
     kms = kernel_ms or launch_ms
@@ -350,27 +354,30 @@ def roofline_block(entry, key, B, N, nz, stage_iters, launch_ms, geo, kernel_ms=
     compulsory = float(B*(8*nz + 168))
     rec, note = hbm_traffic(entry, key)
     traffic = rec.get('bytes_per_launch') if rec else None
-    model_s = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
-               "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d streaming model) / duration of the dominant kernel.  The iterate is "
-                        "register/LDS resident: the kernel never generates that traffic -- the contract's pricing, not the limiter"}
-    out = dict(model_s)
+    useful = (400.0*stage_iters/(kms*1e-3)/1e12)/FP64_VALU_PEAK_TFLOPS
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
+           "model": "S = 904 B x N x sum(IP iterations) per launch (SURVEY 8d streaming model) / duration of the dominant kernel.  The iterate is "
+                    "register/LDS resident: the kernel never generates that traffic -- the contract's pricing, not the limiter (see limiter, valu_issue)",
+           "limiter": "valu-issue: one wave per SIMD (the register file allows no more) issuing FP64 VALU instructions with nothing to hide LDS/scratch latency behind",
+           "frac_useful": useful}
     issue = rec.get('issue') if rec else None
+    valu_issue = None
     if issue and issue.get('valu_instructions_per_launch'):
         valu = issue['valu_instructions_per_launch']*stage_iters/max(rec.get('stage_iterations_per_launch', stage_iters), 1.0)      # (scaled to this run's iteration count)
         ginst = valu/(kms*1e-3)/1e9
-        out = {"bound": "valu-issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst/VALU_ISSUE_PEAK_GINST,
-               "model": "VALU instructions of the dominant kernel (SQ_INSTS_VALU of the profiling pass on this library, scaled by the stage-iterations of this run) / its "
-                        "duration, against one double-rate wave64 instruction per 4 cycles on each of 1024 SIMDs at 2.4 GHz.  One wave per SIMD (the register "
-                        "file allows no more) with nothing to hide LDS/scratch latency behind: the rest of a wave's life is in `issue`"}
-    out.update({"traffic": traffic, "traffic_source": note, "hbm_model_S": model_s, "frac_model_S": model_s["frac"],
+        valu_issue = {"bound": "valu-issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst/VALU_ISSUE_PEAK_GINST,
+                      "model": "VALU instructions of the dominant kernel (SQ_INSTS_VALU of the profiling pass on this library, scaled by the stage-iterations of this run) / its "
+                               "duration, against one double-rate wave64 instruction per 4 cycles on each of 1024 SIMDs at 2.4 GHz: utilisation of the issue slots, every emitted "
+                               "instruction counted (frac_useful prices the algorithm's flops instead)",
+                      "valu_instructions_per_stage_iteration": issue.get('valu_instructions_per_launch', 0)/max(rec.get('stage_iterations_per_launch', stage_iters), 1.0)}
+    out.update({"traffic": traffic, "traffic_source": note, "valu_issue": valu_issue, "frac_model_S": out["frac"],
                 "frac_compulsory": compulsory/(kms*1e-3)/1e9/HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory,
                 "frac_measured": (traffic/(launch_ms*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
                 "kernel": "msd::solve_kernel<{},{}> (one workgroup of {} threads per scenario, {} shooting nodes per lane); split launch: first pass (fused iteration) + follow-up kernel".format(geo[0], geo[1], geo[0], geo[1]),
                 "kernel_ms": kms, "launch_ms": launch_ms, "stage_iterations_per_launch": stage_iters,
-                "issue": issue, "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                "fp64_valu_frac_model": (400.0*stage_iters/(kms*1e-3)/1e12)/FP64_VALU_PEAK_TFLOPS})
-    if issue:
-        out["valu_instructions_per_stage_iteration"] = issue.get('valu_instructions_per_launch', 0)/max(rec.get('stage_iterations_per_launch', stage_iters), 1.0)
+                "issue": issue, "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS, "fp64_valu_frac_model": useful})
+    if valu_issue:
+        out["valu_instructions_per_stage_iteration"] = valu_issue["valu_instructions_per_stage_iteration"]
     return out
 
 
@@ -421,22 +428,46 @@ def main():
     torch.cuda.set_device(local_rank)
     red_dev = 'cpu' if share else 'cuda'
 
+    backend = None      # what carries the barrier and the reductions between the ranks (the data path has no collective)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
+            backend = 'gloo (MSD_BENCH_SHARE_DEVICES=1: ranks share devices, RCCL refuses that)'
         else:
             try:
                 dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+                probe = torch.ones(1, dtype=torch.float64, device='cuda')
+                dist.all_reduce(probe)      # the communicator is created by the first collective: a failure shows here, not in the timed region
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce over RCCL saw {} ranks, expected {}".format(int(probe.item()), world))
+                backend = 'nccl (RCCL)'
             except Exception as exc:
-                # the data path has no collective: RCCL only carries the barrier and two reductions, gloo does the same job
-                print("bench.py: RCCL process group failed on rank {} ({}: {}); falling back to gloo for the barrier and the reductions"
-                      .format(rank, type(exc).__name__, exc), file=sys.stderr)
+                # Round 5: no silent fallback.  The data path has no collective -- gloo would carry the barrier and the two reductions just as well --
+                # but a line measured that way must say so, and only on request: MSD_BENCH_GLOO_FALLBACK=1
+                msg = "bench.py: RCCL process group failed on rank {} ({}: {})".format(rank, type(exc).__name__, exc)
+                if os.environ.get('MSD_BENCH_GLOO_FALLBACK') != '1':
+                    print(msg + "; set MSD_BENCH_GLOO_FALLBACK=1 to let gloo carry the barrier and the reductions instead", file=sys.stderr)
+                    return 3
+                print(msg + "; MSD_BENCH_GLOO_FALLBACK=1: falling back to gloo", file=sys.stderr)
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 dist.init_process_group('gloo', rank=rank, world_size=world)
                 red_dev = 'cpu'
+                backend = 'gloo (fallback: RCCL failed with {})'.format(type(exc).__name__)
+
+    def group_fields():
+        "process-group facts of a multi-rank line: backend, ranks seen by a reduction, the device of every rank"
+        if world == 1:
+            return {"process_group_backend": None, "world_size_seen": 1, "device_of_rank": [local_rank]}
+        seen = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        devs = torch.zeros(world, dtype=torch.int64, device=red_dev)
+        devs[rank] = local_rank
+        dist.all_reduce(devs, op=dist.ReduceOp.SUM)
+        return {"process_group_backend": backend, "world_size_seen": int(seen.item()), "device_of_rank": [int(v) for v in devs.tolist()]}
 
     def barrier(sync_only=False):
         torch.cuda.synchronize()
@@ -465,6 +496,7 @@ def main():
             good_all, failed_all = int(cnt[0].item()), int(cnt[1].item())
         else:
             good_all, failed_all = info['successful'], info['failed']
+        gf = group_fields()
         if rank == 0:
             from mseetc.ocp import casadiSolver
             probe = casadiSolver(train, track, wl.options(N), device=local_rank)
@@ -485,6 +517,7 @@ def main():
                            "parallelism": "scenarios sharded, no collective"},
                 "roofline": roofline_block(entry, 'c4', B*info['resolves_per_loop'], N, nz, info['stage_iterations_per_loop'], launch_ms, geo),
             }
+            line["config"].update(gf)
             line["roofline"]["launch_ms_note"] = "device time of one whole loop (events around its 50 re-solves: solver launches and bookkeeping kernels, shrinking horizons)"
             print(json.dumps(line), flush=True)
         if world > 1:
@@ -521,6 +554,7 @@ def main():
         by_rank = {"ip_iterations_mean": [float(v) for v in slot[0::2].tolist()], "first_running_time": [float(v) for v in slot[1::2].tolist()]}
     else:
         n_ok_all = n_ok
+    gf = group_fields()
 
     if rank == 0:
 
@@ -549,6 +583,7 @@ def main():
             "roofline": roofline_block(entry, key, B, N, solver.problem.nz, stage_iters, launch_ms, geo, kernel_ms=first_ms),
         }
         line["config"]["handed_to_follow_up_kernel_per_launch"] = listed
+        line["config"].update(gf)
         if by_rank is not None:
             line["config"]["by_rank"] = by_rank
 

@@ -244,7 +244,12 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds_bytes, stream, P, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, d_work);
     HIP_TRY(hipGetLastError());
     if (first_end) HIP_TRY(hipEventRecord(first_end, stream));
-    if (first_pass && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) {      /* (debugging aid: leave the list as the first pass wrote it) */
+#ifdef MSD_DEBUG_HOOKS      /* (diagnostic builds: MSD_DEBUG_NO_FOLLOW_UP=1 leaves the list as the first pass wrote it; the product library has no such switch) */
+    const bool skip_follow_up = getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1';
+#else
+    constexpr bool skip_follow_up = false;
+#endif
+    if (first_pass && !skip_follow_up) {
         /* the follow-up kernel: usually nothing to do (0 of the 1024 + 8192 benchmark scenarios of configs 1 and 2) -- a workgroup that finds
          * the list empty returns at once, the others take scenarios off it until it is empty */
         const int grid2 = std::min(nscen, pl.max_grid2);
@@ -384,6 +389,7 @@ int msd_problem_reconfigure(msd_handle h, const msd_problem_desc *d)
 int msd_problem_destroy(msd_handle h)
 {
     if (!h) return MSD_OK;
+    if (h->attached_loops > 0) return fail(MSD_E_INVALID, "a receding-horizon loop (msd_mpc_create) still runs on this handle: destroy the loop first");
     hipSetDevice(h->device);
     hipFree(h->d_prof); hipFree(h->d_loss); hipFree(h->d_work); hipFree(h->d_queue); hipFree(h->d_follow);
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess); hipFree(h->d_eval);
@@ -423,9 +429,13 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
         const size_t need = msd::FOLLOW_HDR + 2*(size_t)nscen;
         if (need > h->cap_follow) {
             HIP_TRY(hipStreamSynchronize(h->stream));      /* (a follow-up kernel in flight reads the old list) */
+            /* the telemetry behind the three list counters is documented as never reset: it moves to the new list */
+            int keep[msd::FOLLOW_HDR] = {0};
+            if (h->d_follow) HIP_TRY(hipMemcpy(keep, h->d_follow, sizeof(int)*msd::FOLLOW_HDR, hipMemcpyDeviceToHost));
+            keep[0] = keep[1] = keep[2] = 0;
             hipFree(h->d_follow); h->d_follow = nullptr; h->cap_follow = 0;
             HIP_TRY(hipMalloc((void **)&h->d_follow, sizeof(int)*need));
-            HIP_TRY(hipMemsetAsync(h->d_follow, 0, sizeof(int)*msd::FOLLOW_HDR, h->stream));      /* afterwards the follow-up kernel leaves the header zeroed */
+            HIP_TRY(hipMemcpy(h->d_follow, keep, sizeof(int)*msd::FOLLOW_HDR, hipMemcpyHostToDevice));      /* afterwards the follow-up kernel leaves the three counters zeroed */
             h->cap_follow = need;
         }
     }
@@ -465,7 +475,11 @@ int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per
 int msd_problem_follow_counts(msd_handle h, int *counts, int n)
 {
     if (!h || !counts || n < 1) return fail(MSD_E_INVALID, "bad argument");
-    if (n > 8 && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) n = 8;      /* (debugging aid: the list's entries behind the counters) */
+#ifdef MSD_DEBUG_HOOKS
+    if (n > 8 && !(getenv("MSD_DEBUG_NO_FOLLOW_UP") && *getenv("MSD_DEBUG_NO_FOLLOW_UP") == '1')) n = 8;      /* (diagnostic builds: the list's entries behind the counters) */
+#else
+    if (n > 8) n = 8;
+#endif
     if (n > (int)h->cap_follow - msd::FOLLOW_TOTAL && h->d_follow) n = (int)h->cap_follow - msd::FOLLOW_TOTAL;
     for (int k = 0; k < n; k++) counts[k] = 0;
     HIP_TRY(hipSetDevice(h->device));

@@ -106,5 +106,6 @@ struct msd_problem {
     bool time_first_pass = false;
     hipEvent_t fp_beg[FP_RING] = {}, fp_end[FP_RING] = {};
     long long fp_count = 0;
+    int attached_loops = 0;                             /* receding-horizon loops (msd_mpc_create) that run on this handle's stream: it cannot be destroyed while one exists */
 };
 

@@ -736,6 +736,79 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &
  * The last interval eliminates df through db_N = 0 (b_N is a parameter of the NLP).
  * Returns false when a pivot is not positive (wrong inertia of the KKT matrix).
  * ---------------------------------------------------------------------------------------- */
+/*
+ * The last interval on top of the terminal value function (only t_N is a free variable of the NLP; b_N is a parameter): its b row,
+ * Bb db + Bw (df + dp) + rb = 0, eliminates one of the two forces -- the one with the smaller curvature -- and the other one and the loss slack
+ * are ordinary pivots (s first: its reciprocal comes from the assembly, NaN when the pivot is not positive).  Round 5: rounds 1-4 always
+ * eliminated df.  With Fel on a bound its barrier curvature (1e11) then sat in every reduced entry and the value function of stage N-1 came out
+ * as a difference of two such numbers, P_bb = eb^2 (G_ff - G_ff^2/(G_ff + G_pp - 2 G_fp)), whose rounding error times Bw^2 decided the inertia of
+ * stage N-2 on degenerate problems (a zero-cost journey, random sweep seed 176: Restoration_Failed on the device, profiles/r04).  Eliminating the
+ * softer force keeps the stiff one as a pivot of its own: at most one bit is lost (the oracle does the same, ms_oracle.c: compute_direction).
+ * Out: value function of stage N-1 (Pn packed tt tb tq bb bq qq, pvn), the feedback in its uniform form K = (Kft Kfb Kfq | Kpt Kpb Kpq | kf kp),
+ * KS = feedback of the slack, LG = the eliminated force's row of the stage system over (dt, db, dq, df, dp, ds, 1): the multiplier of the b row
+ * is that row over Bw.  Returns false when the pivot of the kept force is not positive (wrong inertia).
+ */
+template <int DYN>
+__device__ __forceinline__ bool last_interval(const double *s, const double Ptt, const double pt, const bool pn, double (&Pn)[6], double (&pvn)[3],
+                                              double (&K)[8], double (&KS)[4], double (&LG)[7])
+{
+    const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+    const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
+                 Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
+    const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+    const double Prt = Ptt*rt + pt;
+    const double Mbt = Tb*Ptt, Mpt = Tw*Ptt;
+    const double Gtt = Htt + Ptt, Gtb = Mbt, Gtf = Mpt;
+    double Gtp = Mpt;
+    const double Gbb = Hbb + Tb*Mbt, Gbq = Hbq, Gbf = Hbf + Tb*Mpt;
+    double Gbp = Hbp + Tb*Mpt;
+    const double Gqq = Hqq, Gqf = Hqf;
+    const double Gff = Hff + Tw*Mpt;
+    double Gfp = Hfp + Tw*Mpt, Gpp = Hpp + Tw*Mpt;
+    const double gt = ht + Prt, gb = hb + Tb*Prt, gq = hq, gf = hf + Tw*Prt;
+    double gp = hp + Tw*Prt;
+    if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; }
+    const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0, Gps = DYN ? s[S_GPS] : 0.0;      /* (p-s coupling: integrated loss rows) */
+    const double eb = -Bb/Bw, e0 = -rb/Bw;
+    /* e: the force eliminated through the b row, d(e) = eb db - d(k) + e0; k: the force that is kept */
+    const bool sw = pn && Gpp < Gff;
+    const double Gte = sw ? Gtp : Gtf, Gtk = sw ? Gtf : Gtp, Gbe = sw ? Gbp : Gbf, Gbk = sw ? Gbf : Gbp, Gqe = sw ? 0.0 : Gqf, Gqk = sw ? Gqf : 0.0;
+    const double Gee = sw ? Gpp : Gff, Gkk = sw ? Gff : Gpp, Gek = Gfp, Ges = sw ? Gps : Gfs, Gks = sw ? Gfs : Gps, ge = sw ? gp : gf, gk = sw ? gf : gp;
+    LG[0] = Gte; LG[1] = Gbe; LG[2] = Gqe; LG[3] = sw ? Gfp : Gff; LG[4] = sw ? Gpp : Gfp; LG[5] = Ges; LG[6] = ge;
+    const double gee = ge + Gee*e0;
+    /* reduced blocks over (t, b, q | k, s) */
+    double Hkk2 = Gkk - 2*Gek + Gee, Hks2 = Gks - Ges;
+    double Hkt = Gtk - Gte, Hkb = Gbk + Gek*eb - Gbe - Gee*eb, Hkq = Gqk - Gqe;
+    const double Hsb = Ges*eb + Gbs;
+    double gk2 = gk + Gek*e0 - gee;
+    const double gs2 = gs + Ges*e0;
+    const double Xtt = Gtt, Xtb = Gtb + Gte*eb, Xbb = Gbb + 2*eb*Gbe + eb*eb*Gee, Xbq = Gbq + eb*Gqe, Xqq = Gqq;
+    const double xt = gt + Gte*e0, xb = gb + Gbe*e0 + eb*gee, xq = gq + Gqe*e0;
+    if (!pn) { Hkk2 = 1; Hks2 = 0; Hkt = 0; Hkb = 0; Hkq = 0; gk2 = 0; }
+    /* 2x2 pivots: s first, then k */
+    const double lks = Hks2*is, dk_ = Hkk2 - Hks2*lks;
+    const double ik = 1.0/dk_;
+    /* columns t, b, q and the vector: rhs = -(row k, row s) */
+    const double Kkt = -(Hkt)*ik, Kst = -(Hks2*Kkt)*is;
+    const double Kkb = -(Hkb - lks*Hsb)*ik, Ksb = -(Hsb + Hks2*Kkb)*is;
+    const double Kkq = -(Hkq)*ik, Ksq = -(Hks2*Kkq)*is;
+    const double kk = -(gk2 - lks*gs2)*ik, ks = -(gs2 + Hks2*kk)*is;
+    Pn[sy(0, 0)] = Xtt + Hkt*Kkt;
+    Pn[sy(0, 1)] = Xtb + Hkt*Kkb;
+    Pn[sy(0, 2)] = Hkt*Kkq;
+    Pn[sy(1, 1)] = Xbb + Hkb*Kkb + Hsb*Ksb;
+    Pn[sy(1, 2)] = Xbq + Hkb*Kkq + Hsb*Ksq;
+    Pn[sy(2, 2)] = Xqq + Hkq*Kkq;
+    pvn[0] = xt + Hkt*kk; pvn[1] = xb + Hkb*kk + Hsb*ks; pvn[2] = xq + Hkq*kk;
+    /* uniform feedback form: d(k) = Kk x + kk, d(e) = eb db - d(k) + e0 */
+    const double Ket = -Kkt, Keb = eb - Kkb, Keq = -Kkq, ke = e0 - kk;
+    K[0] = sw ? Kkt : Ket; K[1] = sw ? Kkb : Keb; K[2] = sw ? Kkq : Keq; K[6] = sw ? kk : ke;
+    K[3] = sw ? Ket : Kkt; K[4] = sw ? Keb : Kkb; K[5] = sw ? Keq : Kkq; K[7] = sw ? ke : kk;
+    if (!pn) { K[3] = 0; K[4] = 0; K[5] = 0; K[7] = 0; }
+    KS[0] = Kst; KS[1] = Ksb; KS[2] = Ksq; KS[3] = ks;
+    return dk_ > 0;
+}
+
 /* lg_out: when not null only the backward sweep runs and the seven numbers the forward sweep needs for the multiplier
  * of the last interval's eliminated row are written there */
 template <int DYN>
@@ -749,9 +822,22 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
     double LGtf = 0, LGbf = 0, LGqf = 0, LGff = 0, LGfp = 0, LGfs = 0, Lgf = 0;
 
     bool ok = true;
-    /* one backward stage; the last interval (LAST) is peeled off the loop so that the loop body is branch free */
-    auto backward = [&](const int i, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
+    /* the last interval (last_interval) is peeled off the loop so that the loop body is branch free */
+    {
+        double *s = S + (N - 1)*S_STRIDE;
+        s[S_PN + 0] = Ptt; s[S_PN + 1] = 0; s[S_PN + 2] = 0; s[S_PN + 3] = 0; s[S_PN + 4] = 0; s[S_PN + 5] = 0;      /* value function of stage N, for the multipliers */
+        s[S_PV + 0] = pt; s[S_PV + 1] = 0; s[S_PV + 2] = 0;
+        double Pn[6], pvn[3], K[8], KS[4], LG[7];
+        if (!last_interval<DYN>(s, Ptt, pt, pn, Pn, pvn, K, KS, LG)) ok = false;
+        LGtf = LG[0]; LGbf = LG[1]; LGqf = LG[2]; LGff = LG[3]; LGfp = LG[4]; LGfs = LG[5]; Lgf = LG[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) s[S_K + k] = K[k];
+        s[S_KV + 0] = K[6]; s[S_KV + 1] = K[7];
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[S_KS + k] = KS[k];
+        Ptt = Pn[0]; Ptb = Pn[1]; Ptq = Pn[2]; Pbb = Pn[3]; Pbq = Pn[4]; Pqq = Pn[5]; pt = pvn[0]; pb = pvn[1]; pq = pvn[2];
+    }
+    auto backward = [&](const int i) {
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
@@ -764,7 +850,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
         /* P r + p */
         const double Prt = Ptt*rt + Ptb*rb + pt, Prb = Ptb*rt + Pbb*rb + pb, Prq = Ptq*rt + Pbq*rb + pq;
         /* M_c = P F[:,c] for the columns b, p, f (column t is P[:,t]) */
-        const double Mbt = Tb*Ptt + Bb*Ptb, Mbb = Tb*Ptb + Bb*Pbb, Mbq = Tb*Ptq + Bb*Pbq;
+        const double Mbt = Tb*Ptt + Bb*Ptb, Mbb = Tb*Ptb + Bb*Pbb;
         const double Mpt = Tw*Ptt + Bw*Ptb, Mpb = Tw*Ptb + Bw*Pbb, Mpq = Tw*Ptq + Bw*Pbq;
         const double Mft = Mpt + Ptq, Mfb = Mpb + Pbq, Mfq = Mpq + Pqq;
         /* G = H + F^T P F, g = h + F^T (P r + p) */
@@ -779,43 +865,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
 
         double Kft, Kfb, Kfq, Kpt, Kpb, Kpq, kf, kp;
         double nPtt, nPtb, nPtq, nPbb, nPbq, nPqq, npt, npb, npq;
-
-        if (LAST) {
-            /* the last interval still carries its s row: b_N is a parameter, df = eb db - dp + e0 from the b row */
-            const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0;
-            const double eb = -Bb/Bw, e0 = -rb/Bw;
-            LGtf = Gtf; LGbf = Gbf; LGqf = Gqf; LGff = Gff; LGfp = Gfp; LGfs = Gfs; Lgf = gf;
-            const double gfe = gf + Gff*e0;
-            /* reduced blocks over (t, b, q | p, s) */
-            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = (DYN ? s[S_GPS] : 0.0) - Gfs;      /* (p-s coupling: integrated loss rows) */
-            double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
-            double Hsb = Gfs*eb + Gbs;
-            double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
-            double Xtt = Gtt, Xtb = Gtb + Gtf*eb, Xbb = Gbb + 2*eb*Gbf + eb*eb*Gff, Xbq = Gbq + eb*Gqf, Xqq = Gqq;
-            double xt = gt + Gtf*e0, xb = gb + Gbf*e0 + eb*gfe, xq = gq + Gqf*e0;
-            if (!pn) { Hpp2 = 1; Hps2 = 0; Hpt = 0; Hpb = 0; Hpq = 0; gp2 = 0; }
-            /* 2x2 pivots: s first (its reciprocal comes from assemble(), NaN when the pivot is not positive), then p */
-            const double lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
-            if (!(dp_ > 0)) ok = false;
-            const double ip = 1.0/dp_;
-            /* columns t, b, q and the vector: rhs = -(row p, row s) */
-            double Kp2t = -(Hpt)*ip, Ks2t = -(Hps2*Kp2t)*is;
-            double Kp2b = -(Hpb - lps*Hsb)*ip, Ks2b = -(Hsb + Hps2*Kp2b)*is;
-            double Kp2q = -(Hpq)*ip, Ks2q = -(Hps2*Kp2q)*is;
-            double kp2 = -(gp2 - lps*gs2)*ip, ks2 = -(gs2 + Hps2*kp2)*is;
-            /* value function of stage N-1 */
-            nPtt = Xtt + Hpt*Kp2t;
-            nPtb = Xtb + Hpt*Kp2b;
-            nPtq = Hpt*Kp2q;
-            nPbb = Xbb + Hpb*Kp2b + Hsb*Ks2b;
-            nPbq = Xbq + Hpb*Kp2q + Hsb*Ks2q;
-            nPqq = Xqq + Hpq*Kp2q;
-            npt = xt + Hpt*kp2; npb = xb + Hpb*kp2 + Hsb*ks2; npq = xq + Hpq*kp2;
-            /* uniform feedback form: df = eb db - dp + e0 */
-            Kpt = Kp2t; Kpb = Kp2b; Kpq = Kp2q; kp = kp2;
-            Kft = -Kp2t; Kfb = eb - Kp2b; Kfq = -Kp2q; kf = e0 - kp2;
-            s[S_KS + 0] = Ks2t; s[S_KS + 1] = Ks2b; s[S_KS + 2] = Ks2q; s[S_KS + 3] = ks2;
-        } else {
+        {
             /* s is already eliminated (assemble()): pivots of Guu in the order p, f */
             const double ip = 1.0/Gpp, lfp = Gfp*ip;
             const double df_ = Gff - Gfp*lfp;
@@ -838,8 +888,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
         s[S_KV + 0] = kf; s[S_KV + 1] = kp;
         Ptt = nPtt; Ptb = nPtb; Ptq = nPtq; Pbb = nPbb; Pbq = nPbq; Pqq = nPqq; pt = npt; pb = npb; pq = npq;
     };
-    backward(N - 1, std::true_type());
-    for (int i = N - 2; i >= 0; i--) backward(i, std::false_type());     /* no early exit: a wrong inertia is rare, the branch is not */
+    for (int i = N - 2; i >= 0; i--) backward(i);     /* no early exit: a wrong inertia is rare, the branch is not */
     if (!ok) return false;
     if (lg_out) {
         lg_out[0] = LGtf; lg_out[1] = LGbf; lg_out[2] = LGqf; lg_out[3] = LGff; lg_out[4] = LGfp; lg_out[5] = LGfs; lg_out[6] = Lgf;
@@ -899,10 +948,10 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         for (int b = 0; b < 3; b++) P[a][b] = 0;
     }
     P[0][0] = S[N*S_STRIDE + S_HTT]; pv[0] = S[N*S_STRIDE + S_HT];
-    bool ok = true;
+    bool ok = true, swapLast = false;
     auto backward = [&](const int i, auto last_tag) {
         constexpr bool last = decltype(last_tag)::value;
-        constexpr int nu = last ? 3 : 2;      /* controls to eliminate: (f, p), in the last interval (v, p, s) */
+        constexpr int nu = last ? 3 : 2;      /* controls to eliminate: (f, p), in the last interval (v, k, s) with k the force that is kept */
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Dt = Dtv[i], Db = Dbv[i];
@@ -965,7 +1014,16 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
             G[4][4] = 1; g[4] = 0;
         }
         if (last) {
-            /* df = eb db - dp + e0 - kap v */
+            /* d(e) = eb db - d(k) + e0 - kap v: the force with the smaller curvature is eliminated (last_interval); when that is Fpb the two forces
+             * swap their slots here, and back in the forward sweep (every index a compile-time constant) */
+            swapLast = pn && G[4][4] < G[3][3];
+            if (swapLast) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) { const double v = G[3][a]; G[3][a] = G[4][a]; G[4][a] = v; }
+#pragma unroll
+                for (int a = 0; a < 6; a++) { const double v = G[a][3]; G[a][3] = G[a][4]; G[a][4] = v; }
+                const double v = g[3]; g[3] = g[4]; g[4] = v;
+            }
             const double eb = -Bb/Bw, e0 = -rb/Bw, kap = sqrt(Db)/Bw;
             double T[6][6], GT[6][6], G2[6][6], gy[6], g2[6];
 #pragma unroll
@@ -1083,11 +1141,12 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         const double Dt = Dtv[i], Db = Dbv[i];
         const double u0 = s[S_K + 0]*x0 + s[S_K + 1]*x1 + s[S_K + 2]*x2 + s[S_KV + 0];
         const double u1 = pn ? s[S_K + 3]*x0 + s[S_K + 4]*x1 + s[S_K + 5]*x2 + s[S_KV + 1] : 0.0;
-        double df, dsl;
-        const double dp = u1;
+        double df, dsl, dp = u1;
         if (last) {
+            /* u0: v, u1: the force that was kept */
             dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
-            df = -Bb/Bw*x1 - dp - rb/Bw - sqrt(Db)/Bw*u0;
+            const double de = -Bb/Bw*x1 - u1 - rb/Bw - sqrt(Db)/Bw*u0;
+            df = swapLast ? u1 : de; dp = swapLast ? de : u1;
         } else {
             df = u0;
             dsl = -(s[S_GS] + s[S_GFS]*df)*s[S_IS];
@@ -1212,54 +1271,7 @@ struct ParallelRiccati {
         double Pn[6], pvn[3];          /* value function of stage N-1 */
         double LG[7];
         double lastK[8], lastKS[4];
-        {
-            const double *s = S + (N - 1)*S_STRIDE;
-            const double Ptt = S[N*S_STRIDE + S_HTT], pt = S[N*S_STRIDE + S_HT];
-            const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
-            const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
-                         Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
-            const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
-            const double Prt = Ptt*rt + pt;
-            const double Mbt = Tb*Ptt, Mpt = Tw*Ptt, Mft = Mpt;
-            double Gtt = Htt + Ptt, Gtb = Mbt, Gtf = Mft, Gtp = Mpt;
-            double Gbb = Hbb + Tb*Mbt, Gbq = Hbq, Gbf = Hbf + Tb*Mft, Gbp = Hbp + Tb*Mpt;
-            double Gqq = Hqq, Gqf = Hqf;
-            double Gff = Hff + Tw*Mft, Gfp = Hfp + Tw*Mpt;
-            double Gpp = Hpp + Tw*Mpt;
-            double gt = ht + Prt, gb = hb + Tb*Prt, gq = hq;
-            double gf = hf + Tw*Prt, gp = hp + Tw*Prt;
-            if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; gp = 0; }
-            const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0;
-            const double eb = -Bb/Bw, e0 = -rb/Bw;
-            LG[0] = Gtf; LG[1] = Gbf; LG[2] = Gqf; LG[3] = Gff; LG[4] = Gfp; LG[5] = Gfs; LG[6] = gf;
-            const double gfe = gf + Gff*e0;
-            double Hpp2 = Gpp - 2*Gfp + Gff, Hps2 = (DYN ? s[S_GPS] : 0.0) - Gfs;      /* (p-s coupling: integrated loss rows) */
-            double Hpt = Gtp - Gtf, Hpb = Gbp + Gfp*eb - Gbf - Gff*eb, Hpq = -Gqf;
-            double Hsb = Gfs*eb + Gbs;
-            double gp2 = gp + Gfp*e0 - gfe, gs2 = gs + Gfs*e0;
-            double Xtt = Gtt, Xtb = Gtb + Gtf*eb, Xbb = Gbb + 2*eb*Gbf + eb*eb*Gff, Xbq = Gbq + eb*Gqf, Xqq = Gqq;
-            double xt = gt + Gtf*e0, xb = gb + Gbf*e0 + eb*gfe, xq = gq + Gqf*e0;
-            if (!pn) { Hpp2 = 1; Hps2 = 0; Hpt = 0; Hpb = 0; Hpq = 0; gp2 = 0; }
-            const double lps = Hps2*is, dp_ = Hpp2 - Hps2*lps;
-            if (!(dp_ > 0)) ok = false;
-            const double ip = 1.0/dp_;
-            double Kp2t = -(Hpt)*ip, Ks2t = -(Hps2*Kp2t)*is;
-            double Kp2b = -(Hpb - lps*Hsb)*ip, Ks2b = -(Hsb + Hps2*Kp2b)*is;
-            double Kp2q = -(Hpq)*ip, Ks2q = -(Hps2*Kp2q)*is;
-            double kp2 = -(gp2 - lps*gs2)*ip, ks2 = -(gs2 + Hps2*kp2)*is;
-            Pn[sy(0, 0)] = Xtt + Hpt*Kp2t;
-            Pn[sy(0, 1)] = Xtb + Hpt*Kp2b;
-            Pn[sy(0, 2)] = Hpt*Kp2q;
-            Pn[sy(1, 1)] = Xbb + Hpb*Kp2b + Hsb*Ks2b;
-            Pn[sy(1, 2)] = Xbq + Hpb*Kp2q + Hsb*Ks2q;
-            Pn[sy(2, 2)] = Xqq + Hpq*Kp2q;
-            pvn[0] = xt + Hpt*kp2; pvn[1] = xb + Hpb*kp2 + Hsb*ks2; pvn[2] = xq + Hpq*kp2;
-            /* uniform feedback form: df = eb db - dp + e0 */
-            lastK[0] = -Kp2t; lastK[1] = eb - Kp2b; lastK[2] = -Kp2q; lastK[3] = Kp2t; lastK[4] = Kp2b; lastK[5] = Kp2q;
-            lastK[6] = e0 - kp2; lastK[7] = kp2;
-            if (!pn) { lastK[3] = 0; lastK[4] = 0; lastK[5] = 0; lastK[7] = 0; }
-            lastKS[0] = Ks2t; lastKS[1] = Ks2b; lastKS[2] = Ks2q; lastKS[3] = ks2;
-        }
+        if (!last_interval<DYN>(S + (N - 1)*S_STRIDE, S[N*S_STRIDE + S_HTT], S[N*S_STRIDE + S_HT], pn, Pn, pvn, lastK, lastKS, LG)) ok = false;
         __syncthreads();       /* every thread has read block N-1 before thread 0 overwrites it */
         if (c.tid == 0) {
             double *s = S + (N - 1)*S_STRIDE;
@@ -3824,8 +3836,11 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             if (guess) guess = nullptr; else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;
         }
         /* a solve that breaks down (not: runs out of iterations) is repeated from the other starting point */
+#ifndef MSD_MAX_ATTEMPTS
+#define MSD_MAX_ATTEMPTS 2          /* (1: diagnostic builds that look at the first attempt alone) */
+#endif
 #pragma unroll 1
-        for (int attempt = attempt0; attempt < 2; attempt++) {
+        for (int attempt = attempt0; attempt < MSD_MAX_ATTEMPTS; attempt++) {
             int iters = 0;
             int st = SolverT::STATUS_GENERAL;
             if constexpr (FASTK && PART != 2) {

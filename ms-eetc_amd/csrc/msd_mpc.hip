@@ -73,7 +73,10 @@ __global__ void mpc_relax(int B, int attempt, const double *stats, const double 
     bool again = false;
     if (attempt == 0) {
         if (flag[s] != 1) return;
-        const bool ok = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_STATUS] >= 0;
+        /* usable: the twin converged, or ended on a feasible point without converging -- the time of a feasible run bounds the minimum from above, so
+         * an arrival time moved there can be met (mseetc/ocp.py: minimumTime) */
+        const double viol = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_CONSTR_VIOL];
+        const bool ok = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_STATUS] >= 0 || (isfinite(viol) && viol <= 1e-6);
         const double tmin = z_tw[(size_t)nz_tw*s + nz_tw - 2] - tnow[s];
         if (ok && tmin > T[s] - tnow[s]) { tm[s] = tmin; flag[s] = 2; again = true; log[(size_t)MSD_MPC_COUNT*s + MSD_MPC_RELAXED] = 1.0; }
         else flag[s] = 0;
@@ -120,6 +123,8 @@ struct msd_mpc {
     double vmin = 1, vmax = 1, vN = 1, wmu = 0, wpush = 0, noise = 0, margin = 0;
     int warm = 0, relax = 0;
     double *d_prof = nullptr, *d_work = nullptr;
+    double *d_tables = nullptr;       /* the loop's own copies of the loss table and the collocation tables of its problems and of their twins: the handles may be
+                                       * reconfigured (which frees and regrows theirs) while the loop exists */
     int *d_ints = nullptr;            /* queue ring | follow | follow (twin) | list A | list B | flags */
     int *d_queue = nullptr, *d_follow = nullptr, *d_follow_tw = nullptr, *d_listA = nullptr, *d_listB = nullptr, *d_flag = nullptr;
     int queue_slot = 0;
@@ -137,8 +142,9 @@ extern "C" {
 int msd_mpc_destroy(msd_mpc_handle m)
 {
     if (!m) return MSD_OK;
-    if (m->h) hipSetDevice(m->h->device);
-    hipFree(m->d_prof); hipFree(m->d_work); hipFree(m->d_ints); hipFree(m->d_buf); hipFree(m->d_zlog);
+    if (m->h) { hipSetDevice(m->h->device); hipStreamSynchronize(m->h->stream); m->h->attached_loops--; }
+    if (m->twin) m->twin->attached_loops--;
+    hipFree(m->d_prof); hipFree(m->d_work); hipFree(m->d_tables); hipFree(m->d_ints); hipFree(m->d_buf); hipFree(m->d_zlog);
     if (m->e0) hipEventDestroy(m->e0);
     if (m->e1) hipEventDestroy(m->e1);
     delete m;
@@ -157,6 +163,8 @@ int msd_mpc_create(msd_handle h, msd_handle twin, const msd_mpc_plan *plan, msd_
     HIP_TRY(hipSetDevice(h->device));
     msd_mpc *m = new msd_mpc();
     m->h = h; m->twin = twin; m->K = plan->num_resolves; m->stride = plan->stride;
+    h->attached_loops++;      /* (the loop runs on the handle's stream: msd_problem_destroy refuses while a loop is attached) */
+    if (twin) twin->attached_loops++;
     m->vmin = plan->vmin; m->vmax = plan->vmax_train; m->vN = plan->terminal_velocity; m->warm = plan->warm_start; m->wmu = plan->warm_mu; m->wpush = plan->warm_push;
     m->noise = plan->noise; m->relax = plan->relax_infeasible; m->margin = plan->late_margin;
     m->pl.resize(m->K); m->tw.resize(twin ? m->K : 0);
@@ -167,13 +175,15 @@ int msd_mpc_create(msd_handle h, msd_handle twin, const msd_mpc_plan *plan, msd_
         const msd_problem_desc *d = plan->problems + k;
         rc = msd_host::check_desc(d);
         if (rc == MSD_OK && k > 0 && d->num_intervals != plan->problems[k - 1].num_intervals - m->stride) rc = fail(MSD_E_INVALID, "problem k + 1 must have `stride` intervals fewer than problem k");
-        if (rc == MSD_OK && (d->loss_kind == 2 || d->integrator != 0) && k > 0 && (d->loss_kind != plan->problems[0].loss_kind || d->integrator != plan->problems[0].integrator))
+        if (rc == MSD_OK && k > 0 && (d->loss_kind != plan->problems[0].loss_kind || d->integrator != plan->problems[0].integrator || d->loss_table_len != plan->problems[0].loss_table_len
+                                       || (d->integrator == MSD_INTEGRATOR_COLLOCATION && d->coll_degree != plan->problems[0].coll_degree)))
             rc = fail(MSD_E_INVALID, "the problems of a loop share their loss model and integrator");
         if (rc == MSD_OK) rc = msd_host::make_plan(h->device, d, &m->pl[k]);
         if (rc == MSD_OK && twin) {
             const msd_problem_desc *t = plan->twins + k;
             rc = msd_host::check_desc(t);
             if (rc == MSD_OK && t->num_intervals != d->num_intervals) rc = fail(MSD_E_INVALID, "a twin shares the grid of its problem");
+            if (rc == MSD_OK && k > 0 && (t->loss_kind != plan->twins[0].loss_kind || t->integrator != plan->twins[0].integrator)) rc = fail(MSD_E_INVALID, "the twins of a loop share their loss model and integrator");
             if (rc == MSD_OK) rc = msd_host::make_plan(h->device, t, &m->tw[k]);
         }
         if (rc != MSD_OK) break;
@@ -201,12 +211,33 @@ int msd_mpc_create(msd_handle h, msd_handle twin, const msd_mpc_plan *plan, msd_
             if (!p) continue;
             p->P.ds = m->d_prof + off; p->P.grad = p->P.ds + N; p->P.curv = p->P.grad + N; p->P.bmax = p->P.curv + N; p->P.pos = p->P.bmax + N + 1;
         }
-        /* loss table and collocation tables: the ones the handles were configured with (the problems of a loop share them) */
-        m->pl[k].P.loss = h->P.loss; m->pl[k].P.coll = h->P.coll;
-        if (twin) { m->tw[k].P.loss = twin->P.loss; m->tw[k].P.coll = twin->P.coll; }
         off += 5*(size_t)N + 2;
     }
     if (hipMemcpy(m->d_prof, stage.data(), sizeof(double)*prof, hipMemcpyHostToDevice) != hipSuccess) { msd_mpc_destroy(m); return fail(MSD_E_HIP, "profile upload failed"); }
+    {
+        /* loss table and collocation tables: the loop's own copies, from the first problem's (and the first twin's) description -- the problems of a
+         * loop share them (checked above).  Rounds 3-4 pointed at the handles' buffers, which msd_problem_reconfigure frees and regrows */
+        const msd_problem_desc *d0 = plan->problems, *t0 = twin ? plan->twins : nullptr;
+        auto loss_len = [](const msd_problem_desc *d) { return (d && d->loss_kind == 2) ? (size_t)d->loss_table_len : (size_t)0; };
+        auto coll_len = [](const msd_problem_desc *d) { return (d && d->integrator == MSD_INTEGRATOR_COLLOCATION) ? (size_t)(d->coll_degree + 1)*(d->coll_degree + 2) : (size_t)0; };
+        const size_t n[4] = {loss_len(d0), coll_len(d0), loss_len(t0), coll_len(t0)};
+        const double *src[4] = {d0->loss_table, d0->coll_tables, t0 ? t0->loss_table : nullptr, t0 ? t0->coll_tables : nullptr};
+        const size_t total = n[0] + n[1] + n[2] + n[3];
+        const double *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (total) {
+            if (hipMalloc((void **)&m->d_tables, sizeof(double)*total) != hipSuccess) { msd_mpc_destroy(m); return fail(MSD_E_HIP, "device allocation failed"); }
+            size_t o = 0;
+            for (int a = 0; a < 4; a++) {
+                if (!n[a]) continue;
+                if (hipMemcpy(m->d_tables + o, src[a], sizeof(double)*n[a], hipMemcpyHostToDevice) != hipSuccess) { msd_mpc_destroy(m); return fail(MSD_E_HIP, "table upload failed"); }
+                dev[a] = m->d_tables + o; o += n[a];
+            }
+        }
+        for (int k = 0; k < m->K; k++) {
+            m->pl[k].P.loss = dev[0]; m->pl[k].P.coll = dev[1];
+            if (twin) { m->tw[k].P.loss = dev[2]; m->tw[k].P.coll = dev[3]; }
+        }
+    }
     *out = m;
     return MSD_OK;
 }
@@ -292,19 +323,19 @@ int msd_mpc_run(msd_mpc_handle m, int nscen, const double *T, double initial_tim
         }
         ws.d_dual_out = m->warm ? m->d_dual[cur] : nullptr;
         rc = msd_host::launch_plan(pl, st, m->d_work, m->d_follow, queue(), B, m->d_scen, nullptr, m->d_z[cur], nullptr, m->d_st[cur], nullptr, 0, ws);
-        if (rc != MSD_OK) return rc;
+        if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }      /* (nothing of a loop that failed half-way stays queued on the handle's stream) */
         if (m->relax) {
             const msd_host::Plan &tw = m->tw[k];
             hipLaunchKernelGGL(mpc_collect, gb, tb, 0, st, B, m->d_st[cur], m->d_scen, 3*m->length[k]/m->vmax, m->d_flag, m->d_listA, m->d_scen_tw);
             rc = msd_host::launch_plan(tw, st, m->d_work, m->d_follow_tw, queue(), B, m->d_scen_tw, nullptr, m->d_ztw, nullptr, m->d_sttw, nullptr, 0, msd_host::WarmStart(), m->d_listA);
-            if (rc != MSD_OK) return rc;
+            if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }
             double margin = m->margin;
             for (int a = 0; a < 3; a++, margin *= 4) {
                 hipLaunchKernelGGL(mpc_relax, gb, tb, 0, st, B, a, m->d_st[cur], m->d_ztw, tw.nz, m->d_sttw, m->d_T, m->d_tnow, m->d_tm, m->d_flag, m->d_listB, m->d_scen, margin, logk);
                 msd_host::WarmStart cold;
                 cold.d_dual_out = ws.d_dual_out;
                 rc = msd_host::launch_plan(pl, st, m->d_work, m->d_follow, queue(), B, m->d_scen, nullptr, m->d_z[cur], nullptr, m->d_st[cur], nullptr, 0, cold, m->d_listB);
-                if (rc != MSD_OK) return rc;
+                if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }
             }
         }
         hipLaunchKernelGGL(mpc_log, gb, tb, 0, st, B, m->d_st[cur], m->d_T, logk);

@@ -216,7 +216,8 @@ class _ResultArrays():
     def __init__(self):
         self._cache = {}
 
-    def zeros(self, role, shape):
+    def empty(self, role, shape):
+        "An array of `shape` in page-locked memory, NOT initialised: every element is written by the device-to-host copy that follows."
         import sys
         count = int(np.prod(shape))
         if count == 0:
@@ -280,9 +281,9 @@ class DeviceProblem():
         L = lib()
         scen = np.ascontiguousarray(scen, dtype=np.float64).reshape(-1, SC_COUNT)
         B = scen.shape[0]
-        z = self._results.zeros('z', (B, self.nz))
-        st = self._results.zeros('st', (B, ST['COUNT']))
-        lam = self._results.zeros('lam', (B, self.rowsPerInterval*self.N)) if want_multipliers else None
+        z = self._results.empty('z', (B, self.nz))
+        st = self._results.empty('st', (B, ST['COUNT']))
+        lam = self._results.empty('lam', (B, self.rowsPerInterval*self.N)) if want_multipliers else None
         ms = ctypes.c_float(0)
         hist = None
 

@@ -192,7 +192,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
     position = 0.0
     current = copy.deepcopy(track)
     previous = None
-    onDevice = False      # the handle's last launch solved the whole batch (its solutions are what a shifted warm start reads)
+    batchOnDevice = False      # the handle's last launch solved the whole batch (its solutions are what a shifted warm start reads)
     last = None
     log = []
 
@@ -242,14 +242,14 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
             common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 
             posNew = position + solver.points.index.values
-            tail = (warmStart and previous is not None and onDevice and hasattr(solver, 'adoptDevice') and solverFactory is None and
+            tail = (warmStart and previous is not None and batchOnDevice and hasattr(solver, 'adoptDevice') and solverFactory is None and
                     len(previous[1]) - len(posNew) == stride and np.allclose(posNew, previous[1][stride:], rtol=0, atol=1e-6))
 
             if tail:
                 # the new grid is the tail of the old one and the previous solutions are still on the device (same handle): the re-solve
                 # warm-starts from them there -- no upload, and scenarios without a usable guess start cold inside the same launch
                 res = solver.solveBatch(T, shift=stride, warmMu=dualMu, warmPush=warmPush, classifyFailures=False, **common)
-                onDevice = True
+                batchOnDevice = True
             elif warmStart and previous is not None:
                 zPrev, posPrev, okPrev = previous
                 guess = transferSolution(zPrev, posPrev, position + solver.points.index.values, solver.withPnBrake)
@@ -262,10 +262,10 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
                     res = solver.solveBatch(T, guess=guess, warmMu=warmMu, warmPush=warmPush, classifyFailures=False, **common)
                 else:
                     res = solver.solveBatch(T, classifyFailures=False, **common)
-                onDevice = True
+                batchOnDevice = True
             else:
                 res = solver.solveBatch(T, classifyFailures=False, **common)
-                onDevice = True
+                batchOnDevice = True
 
             relaxed = np.zeros(B, dtype=bool)
             kernel_extra = 0.0
@@ -291,7 +291,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
                         if not still.any():
                             break
                         idx, tm, margin = idx[still], tm[still], 4*margin
-                    onDevice = False      # the handle's last launch held these scenarios only: the next re-solve takes its guess from the host copy
+                    batchOnDevice = False      # the handle's last launch held these scenarios only: the next re-solve takes its guess from the host copy
 
             previous = (res['z'], position + solver.points.index.values, res['status'] >= 0)
 

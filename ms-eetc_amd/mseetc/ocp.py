@@ -371,7 +371,13 @@ class casadiSolver():
             ov[:, _device.OV['OBJ_DEN']] = twin._desc.obj_den
 
         out = twin.problem.solve_batch(loose, overrides=ov)
-        ok = out['stats'][:, _device.ST['STATUS']] >= 0
+        st = out['stats']
+        # usable: the twin converged -- or it ended on a feasible point without converging (its primal point settles long before its multipliers
+        # do where both brakes share an active acceleration bound: DESIGN.md section 8).  The time of a feasible run bounds the minimum from above:
+        # an arrival time moved there can be met, which is all the callers need (shrinkingHorizon; _classify_failures only calls a running time
+        # infeasible when the twin converged)
+        ok = (st[:, _device.ST['STATUS']] >= 0) | (np.isfinite(st[:, _device.ST['CONSTR_VIOL']]) & (st[:, _device.ST['CONSTR_VIOL']] <= 1e-6))
+        self._twinConverged = st[:, _device.ST['STATUS']] >= 0
 
         return out['z'][:, -2] - sub[:, 0], ok
 
@@ -395,7 +401,7 @@ class casadiSolver():
 
         sub = scen[failed]
         tmin, ok = self.minimumTime(sub, None if overrides is None else overrides[failed])
-        short = ok & (tmin > (sub[:, 1] - sub[:, 0])*(1 + 1e-8))
+        short = ok & self._twinConverged & (tmin > (sub[:, 1] - sub[:, 0])*(1 + 1e-8))      # (a verdict of infeasibility needs the minimum itself, not an upper bound of it)
         st[failed[short], ST['STATUS']] = _device.STATUS_INFEASIBLE
 
     def unpack(self, z):

@@ -633,7 +633,7 @@ typedef struct {
     double H[6][6], h[6], E[6][3];         /* condensed stage system, cross term y_i^T E x_{i+1} */
     double F[3][6], r[3];
     double K[3][3], k[3], Pn[3][3], pn[3]; /* feedback, and the (P,p) of stage i+1 used at i */
-    double ef[6], e0;                       /* terminal elimination: df = ef . y~ + e0 (last interval only) */
+    double ef[6], e0; int je;               /* terminal elimination: d(control je) = ef . y~ + e0 (last interval only); je = 3 (Fel) or 4 (Fpb) */
     double M[2][2], Dt, Db;                 /* restoration: (P2 + D^-1)^-1 on the relaxed rows (t, b), their D = n/zn + p/zp (unscaled rows) */
     double Ghat[6][6], ghat[6];             /* G, g before elimination (for multiplier recovery) */
 } StageKkt;
@@ -1147,22 +1147,29 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
         memcpy(Kk->Ghat, G, sizeof G); memcpy(Kk->ghat, g, sizeof g);
 
         if (i == N - 1) {
-            /* b_N fixed: the b-row of the dynamics is an equality in (x, u); eliminate df through it.  Restoration: the row is relaxed,
-             * F_b y + r_b = -D_b lam_b+ with the penalty D_b lam_b+^2 / 2; in terms of v = sqrt(D_b) lam_b+ (slot of df, unit curvature)
-             * the system stays well conditioned as D_b -> 0 */
+            /* b_N fixed: the b-row of the dynamics is an equality in (x, u), Bb db + Bw (df + dp) + rb = 0: one of the two forces is eliminated
+             * through it -- the one with the smaller curvature.  (Round 5.  Rounds 1-4 always eliminated df: with Fel on a bound its barrier
+             * curvature Sigma_f ~ 1e11 then sits in every reduced entry and the value function of stage N-1 comes out as a difference of two such
+             * numbers -- P_bb = eb^2 (G_ff - G_ff^2/(G_ff + G_pp - 2 G_fp)) -- whose rounding error, times Bw^2, decided the inertia of
+             * stage N-2 on degenerate problems: random sweep seed 176, profiles/r04.  Eliminating the softer force leaves the stiff one as an
+             * ordinary pivot: at most one bit is lost.)  Restoration: the row is relaxed, F_b y + r_b = -D_b lam_b+ with the penalty
+             * D_b lam_b+^2 / 2; in terms of v = sqrt(D_b) lam_b+ (slot of the eliminated force, unit curvature) the system stays well
+             * conditioned as D_b -> 0 */
             double Bw = Kk->F[1][3];
+            const int je = (P->withPn && G[4][4] < G[3][3]) ? 4 : 3, jk = 7 - je;
+            Kk->je = je;
             double T[6][6]; memset(T, 0, sizeof T);
             for (int a = 0; a < 6; a++) T[a][a] = 1;
-            T[3][3] = R ? -sqrt(Kk->Db)/Bw : 0;
-            T[3][1] = -Kk->F[1][1]/Bw; T[3][4] = -Kk->F[1][4]/Bw;
+            T[je][je] = R ? -sqrt(Kk->Db)/Bw : 0;
+            T[je][1] = -Kk->F[1][1]/Bw; T[je][jk] = -Kk->F[1][jk]/Bw;
             double y0f = -Kk->r[1]/Bw;
-            memset(Kk->ef, 0, sizeof Kk->ef); Kk->ef[1] = T[3][1]; Kk->ef[4] = T[3][4]; Kk->e0 = y0f;
-            /* G~ = T^T G T, g~ = T^T (G y0 + g); column/row 3 of T is zero -> df decoupled, make it an identity pivot */
+            memset(Kk->ef, 0, sizeof Kk->ef); Kk->ef[1] = T[je][1]; Kk->ef[jk] = T[je][jk]; Kk->e0 = y0f;
+            /* G~ = T^T G T, g~ = T^T (G y0 + g); column/row je of T is zero -> that force decoupled, make it an identity pivot */
             double GT[6][6], G2[6][6], gy[6], g2[6];
-            for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += G[a][m]*T[m][c]; GT[a][c] = s; } gy[a] = g[a] + G[a][3]*y0f; }
+            for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += G[a][m]*T[m][c]; GT[a][c] = s; } gy[a] = g[a] + G[a][je]*y0f; }
             for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) { double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*GT[m][c]; G2[a][c] = s; } double s = 0; for (int m = 0; m < 6; m++) s += T[m][a]*gy[m]; g2[a] = s; }
-            if (R) G2[3][3] += 1;
-            else { for (int a = 0; a < 6; a++) G2[3][a] = G2[a][3] = 0; G2[3][3] = 1; g2[3] = 0; }
+            if (R) G2[je][je] += 1;
+            else { for (int a = 0; a < 6; a++) G2[je][a] = G2[a][je] = 0; G2[je][je] = 1; g2[je] = 0; }
             memcpy(G, G2, sizeof G); memcpy(g, g2, sizeof g);
         }
 
@@ -1190,8 +1197,9 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
         double du[3], y[6];
         for (int a = 0; a < 3; a++) { double s = Kk->k[a]; for (int c = 0; c < 3; c++) s += Kk->K[a][c]*dxs[c]; du[a] = s; }
         for (int a = 0; a < 3; a++) { y[a] = dxs[a]; y[3 + a] = du[a]; }
-        const double v_last = y[3];
-        if (i == N - 1) { double s = Kk->e0; for (int a = 0; a < 6; a++) if (a != 3) s += Kk->ef[a]*y[a]; y[3] = s; if (R) y[3] -= sqrt(Kk->Db)/Kk->F[1][3]*v_last; }
+        const int je = (i == N - 1) ? Kk->je : 3;
+        const double v_last = y[je];
+        if (i == N - 1) { double s = Kk->e0; for (int a = 0; a < 6; a++) if (a != je) s += Kk->ef[a]*y[a]; y[je] = s; if (R) y[je] -= sqrt(Kk->Db)/Kk->F[1][3]*v_last; }
         if (!P->withPn) y[4] = 0;
         double xn[3];
         for (int a = 0; a < 3; a++) { double s = Kk->r[a]; for (int c = 0; c < 6; c++) s += Kk->F[a][c]*y[c]; xn[a] = s; }
@@ -1216,8 +1224,8 @@ static int compute_direction(Ws *W, double mu, double dw, const double (*res_c)[
         double lp[3];
         for (int a = 0; a < 3; a++) { double s = Kk->pn[a]; for (int c = 0; c < 3; c++) s += Kk->Pn[a][c]*xn[c]; for (int c = 0; c < 6; c++) s += Kk->E[c][a]*y[c]; lp[a] = -s; }
         if (i == N - 1 && !R) {
-            /* multiplier of the eliminated row from stationarity wrt df: (G y + g)_f - lam_b * Bw = 0 */
-            double s = Kk->ghat[3]; for (int c = 0; c < 6; c++) s += Kk->Ghat[3][c]*y[c];
+            /* multiplier of the eliminated row from stationarity wrt the eliminated force: (G y + g)_e - lam_b * Bw = 0 */
+            double s = Kk->ghat[je]; for (int c = 0; c < 6; c++) s += Kk->Ghat[je][c]*y[c];
             lp[1] = s/Kk->F[1][3];
         }
         if (R) { lp[0] = lam_r[0]; lp[1] = lam_r[1]; }
@@ -2313,7 +2321,7 @@ static int solve_core(const int *ip, const double *dp, const double *ds, const d
         if (!accepted) {
             /* the step became too small: feasibility restoration (IpBacktrackingLineSearch: goto_resto).  Not from an almost feasible
              * point (resto_failure_feasibility_threshold = 100 tol); restated for the static loss rows, like the kernels (msd_resto.hpp) */
-            if (!g_resto || P->lossKind == 2 || P->intLosses || R.primal <= 1e2*P->tol) { status = OR_STATUS_LINESEARCH; break; }
+            if (!g_resto || R.primal <= 1e2*P->tol) { status = OR_STATUS_LINESEARCH; break; }
             if (W->nfilt < 512) { W->filt_theta[W->nfilt] = (1 - G_THETA)*theta; W->filt_phi[W->nfilt] = phi - G_PHI*theta; W->nfilt++; }
             int nit = 0;
             const int rr = restoration(W, mu, theta, phi, iter, &nit, hist, hist_cap, dbg);

@@ -52,7 +52,9 @@ def lib():
 
         so = HERE / 'libms_oracle.so'
 
-        if not so.exists():
+        if os.environ.get('MS_ORACLE_LIB'):      # an instrumented build of the same sources (debugging sessions)
+            so = Path(os.environ['MS_ORACLE_LIB'])
+        elif not so.exists():
             build()
 
         _lib = ctypes.CDLL(str(so))

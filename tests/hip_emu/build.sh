@@ -3,8 +3,8 @@
 # (optionally with sanitizers: SAN=1; output: OUT=<path>, default libmsd_emu.so here)
 set -e
 cd "$(dirname "$0")"
-FLAGS="-O1 -g"
-[ -n "$SAN" ] && FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
+FLAGS="-O1 -g $EXTRA"
+[ -n "$SAN" ] && FLAGS="-O1 -g $EXTRA -fsanitize=address,undefined -fno-omit-frame-pointer"
 OUT=${OUT:-libmsd_emu.so}
 OBJ=${OBJDIR:-obj${SAN:+_san}}
 mkdir -p "$OBJ"

@@ -83,6 +83,16 @@ def test_two_ranks_on_the_gpu_box():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['scenarios'] == 2048 and line['config']['converged'] == 2048
     assert line['value'] > 1e5 and 'alt' not in line and 'cpu_baseline' not in line
+    # the line says what carried the barrier and the reductions, how many ranks a reduction saw and which device every rank drove
+    cfg = line['config']
+    assert cfg['process_group_backend'].startswith('gloo (MSD_BENCH_SHARE_DEVICES=1') and cfg['world_size_seen'] == 2 and cfg['device_of_rank'] == [0, 0]
+    assert line['roofline']['bound'] == 'hbm' and 0 < line['roofline']['frac_useful'] < 1
+    # without the sharing switch two ranks on one device cannot form an RCCL group: the run fails loudly instead of falling back to gloo on its own
+    env2 = {k: v for k, v in os.environ.items() if k not in ('MSD_BENCH_SHARE_DEVICES', 'MSD_BENCH_GLOO_FALLBACK')}
+    import torch
+    if torch.cuda.device_count() == 1:
+        out2 = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-build'], env=env2, capture_output=True, text=True, timeout=600)
+        assert out2.returncode != 0 and not [l for l in out2.stdout.splitlines() if l.startswith('{')]
 
 
 @pytest.mark.gpu
@@ -129,10 +139,11 @@ def test_roofline_block_fields():
         def hip_digest():
             return 'no such digest'
     r = bench.roofline_block(E, 'c1', 1024, 100, 502, 100*1024*20.6, 1.15, (64, 2))
-    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_model_S', 'frac_compulsory', 'frac_measured', 'hbm_model_S', 'launch_ms', 'kernel_ms'):
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_model_S', 'frac_compulsory', 'frac_measured', 'frac_useful', 'valu_issue', 'limiter', 'launch_ms', 'kernel_ms'):
         assert key in r
-    # without counters of the running library on file the top-level fields are SURVEY 8(d)'s pricing against the HBM roof
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    # the top-level fields are always SURVEY 8(d)'s pricing against the HBM roof (the issue roof sits in `valu_issue` when counters are on file)
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['valu_issue'] is None
+    assert abs(r['frac_useful'] - 400*100*1024*20.6/1.15e-3/1e12/78.6) < 1e-12
     assert abs(r['achieved'] - 904*100*1024*20.6/1.15e-3/1e9) < 1e-6*r['achieved'] and abs(r['frac'] - r['achieved']/8000.0) < 1e-12
     assert r['traffic'] is None and r['frac_measured'] is None
     assert abs(r['compulsory_bytes_per_launch'] - 1024*(8*502 + 168)) < 1e-9

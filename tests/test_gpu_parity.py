@@ -311,6 +311,40 @@ def test_randomized_problems_vs_oracle(seed, tmp_path):
     s.close(); fast.close()
 
 
+@pytest.mark.parametrize('seed,factor', [(176, 2.0), (22, 3.0), (35, 3.0)])
+def test_degenerate_zero_cost_journeys_vs_oracle(seed, factor, tmp_path):
+    """
+    Random problems of the round-4 sweeps on which device and oracle parted (profiles/r04/random_sweep_150_450.txt, random_sweep_loose_2.5_3.txt): loose
+    schedules on downhill tracks -- a zero-cost optimum, a singular reduced Hessian, Newton steps of norm 200 along the flat directions.  Seed 176
+    (N = 154, pneumatic brake only, twice the minimum running time) ended with Restoration_Failed on the device from both starting points; seeds 22 and
+    35 (three times the minimum) ended 1.7e-6 from the oracle's objective.  Cause (round 5): the last interval always eliminated Fel through its
+    b row; with Fel on a bound its barrier curvature of 1e11 went through every reduced entry, the value function of stage N-1 lost all its digits and
+    the inertia of stage N-2 was decided by rounding (last_interval in msd_kernel.hpp; compute_direction in the oracle).  Both now eliminate the force
+    with the smaller curvature.  From both starting points: a solution (the reference surfaces anything else as df = None, ocp.py:359-370), the oracle's
+    objective and -- from the same starting point -- the oracle's iterates.
+    """
+    from oracle import oracle
+    train, track, N, rng = _random_problem(seed, tmp_path)
+    v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
+    po = cases.oracle_problem(train, track, N, energyOptimal=False, losses='none')
+    reft = oracle.solve(po, po.scenario(3*track.length/train.velocityMax, 0.0, vN, v0), start='profile')
+    assert reft['stats']['STATUS'] == 0
+    T = factor*float(reft['z'][-2])
+    pe = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(pe, pe.scenario(T, 0.0, vN, v0), start='profile')
+    assert ref['stats']['STATUS'] == 0
+    scale = max(1.0, abs(ref['stats']['OBJ']))      # (kWh; the journeys cost nothing)
+    for start in ('profile', 'reference'):
+        s = _solver(train, track, N, start=start)
+        res = s.solveBatch([T], initialVelocity=v0, terminalVelocity=vN)
+        s.close()
+        assert res['status'][0] == 0, (seed, start, res['status'], res['iterations'])
+        assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-7*scale, (seed, start, res['cost'][0], ref['stats']['OBJ'])
+        if start == 'profile':
+            assert abs(int(res['iterations'][0]) - int(ref['stats']['ITERS'])) <= 2, (seed, res['iterations'][0], ref['stats']['ITERS'])
+            assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1.0, np.abs(ref['z']))) <= 1e-5
+
+
 def test_velocity_clipping_like_the_reference():
     # initial/terminal speeds are clipped to [vmin, local speed limit] (ocp.py:343-344)
     train, track = cases.train_default(), cases.track_00(crop=20000)

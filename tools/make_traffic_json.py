@@ -30,7 +30,7 @@ def mean_counter(d, counter, which='launch'):
     for f in glob.glob(os.path.join(out, d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'solve_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
-                (follow if part_of(r['Kernel_Name']) == 2 and True else first).append(float(r['Counter_Value']))
+                (follow if part_of(r['Kernel_Name']) == 2 else first).append(float(r['Counter_Value']))
     if not first and follow:      # a launch that is the follow-up kernel's alone
         first, follow = follow, []
     if not first:
