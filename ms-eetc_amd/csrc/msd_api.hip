@@ -172,13 +172,15 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
         pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles(N, 128, wide, geo.xch, geo.red);
     }
     size_t work2 = 0;
-    if (!geo.fn2 && !geo.stream && !dyn && !intloss && (gen || geo.NT == 320)) {
-        /* static loss rows, collocation / adaptive shooting or the five-wave geometry: these kernels are first-pass kernels without the restoration
-         * phase; a scenario whose line search breaks down is followed up by the streamed kernel of the family, which has it (msd_kernel.hpp:
-         * FAMILY_HAS_RESTO).  The follow-up restarts the scenario, so the two geometries need not agree */
-        const msd::Geometry g2 = gen ? msd::pick_stream_geometry_general(N) : msd::pick_stream_geometry_static(N);
-        if (!g2.fn) return fail(MSD_E_UNSUPPORTED, "no follow-up kernel for numIntervals = " + std::to_string(N));
-        geo.fn2 = g2.fn; pl.NT2 = g2.NT; pl.SPT2 = g2.SPT;
+    if (!geo.fn2 && !geo.stream) {
+        /* an LDS-resident kernel without a follow-up kernel of its own geometry (every family but the two with the structure of the reference's rolling
+         * stock compiled in): a first-pass kernel -- the general iteration without the restoration phase and the watchdog procedure; a scenario that needs
+         * either is followed up by the streamed kernel of the family (msd_kernel.hpp: FAMILY_HAS_RESTO, WD_HANDOVER).  The follow-up restarts the
+         * scenario, so the two geometries need not agree */
+        const msd::Geometry g2 = (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N)
+                                 : intloss ? msd::pick_stream_geometry_intloss(N) : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
+        if (!g2.fn2) return fail(MSD_E_UNSUPPORTED, "no follow-up kernel for numIntervals = " + std::to_string(N));
+        geo.fn2 = g2.fn2; pl.NT2 = g2.NT; pl.SPT2 = g2.SPT;
         pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles_stream();
         work2 = msd::stream_doubles(N, g2.NT*g2.SPT, wide);
     }
@@ -211,10 +213,9 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     const bool split = pl.kernel2 != nullptr;
     const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
     const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);
-    if (d_list) {
-        /* the scenarios of a list, by the kernel that holds everything (an idle workgroup returns at once).  (A first-pass kernel takes an input list
-         * too -- DevProb::list next to DevProb::follow -- but sending the receding-horizon loop's few re-solves through first pass + follow-up kernel
-         * buys nothing: 184 k successful re-solves/s on config 4 either way) */
+    if (d_list && !first_pass) {
+        /* the scenarios of a list by one kernel: the follow-up kernel of a fused family whose start needs the least-squares estimate and has no first pass
+         * for it, or a kernel that holds everything (an idle workgroup returns at once) */
         const msd::KernelFn fn = split ? pl.kernel2 : pl.kernel;
         const int cap = split ? pl.max_grid2 : pl.max_grid;
         P.list = d_list;
@@ -222,6 +223,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         HIP_TRY(hipGetLastError());
         return MSD_OK;
     }
+    P.list = d_list;      /* (not null: the first pass solves the scenarios of this list only -- the re-solves of msd_mpc.hip -- and hands over through `follow` as usual) */
     /* split solves (msd::Geometry::fn2): first pass + follow-up kernel behind it on the stream, the list of unfinished scenarios between them.
      * The first pass is the kernel without the least-squares multiplier estimate when every scenario can start without it (profile start,
      * primal-dual warm start), the one with it otherwise (the reference's starting point, a primal-only warm start) */
@@ -234,8 +236,8 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
         if (!d_follow) return fail(MSD_E_INVALID, "split solve without its list");
         P.follow = d_follow;
     }
-    if (nscen > grid) {
-        /* more scenarios than resident workgroups: dynamic distribution through a counter */
+    if (nscen > grid && !d_list) {
+        /* more scenarios than resident workgroups: dynamic distribution through a counter (a list has its own) */
         if (!d_queue) return fail(MSD_E_INVALID, "launch without its scenario counter");
         P.queue = d_queue;
         HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), stream));

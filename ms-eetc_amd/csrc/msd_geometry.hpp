@@ -40,42 +40,50 @@ Geometry pick_stream_geometry_intloss(int N);
 Geometry pick_geometry_general_full(int N);  /* the same two families with the structure of the reference's rolling stock compiled in (msd_kernels_full2.hip) */
 Geometry pick_geometry_intloss_full(int N);
 
+/* LDS-resident kernels without the structure of the NLP compiled in: first-pass kernels (PART = 1: the general iteration without the cold paths); the
+ * streamed kernel of the family follows up (msd_api.hip: make_plan) */
 template <int DYN> inline Geometry pick_geometry_t(int N)
 {
     const int nodes = N + 1;
 #ifdef MSD_ONLY_192X2              /* debugging builds */
-    return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN>} : Geometry{0, 0, nullptr};
+    return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN, false, false, 0, 1>} : Geometry{0, 0, nullptr};
 #endif
-    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, DYN>};
-    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, DYN>};     /* one wave per scenario, one wave per SIMD */
-    if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, DYN>};
+    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, DYN, false, false, 0, 1>};
+    if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, DYN, false, false, 0, 1>};     /* one wave per scenario, one wave per SIMD */
+    if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, DYN, false, false, 0, 1>};
 #ifdef MSD_MINIMAL_GEOMETRIES      /* tuning builds (tools/build_variant.py) */
     return {0, 0, nullptr};
 #endif
-    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, DYN>};
-    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, DYN>};
+    if (nodes <= 384) return {192, 2, solve_kernel<192, 2, 1, DYN, false, false, 0, 1>};
+    if (nodes <= 512) return {256, 2, solve_kernel<256, 2, 1, DYN, false, false, 0, 1>};
     /* N = 512 ... 575 with static loss rows: three waves with three nodes per lane and the whole register file of a SIMD each -- the stage blocks and
      * six exchange arrays of 576 slots still fit the LDS of a compute unit.  (Round 3 ran these horizons on five waves of two nodes per lane with
      * half a register file each: 2 253 spilled registers, 25 ms per 1024 solves at N = 560 against 6.2 ms at N = 511.) */
-    if (DYN == LOSS_STATIC && nodes <= 576) return {192, 3, solve_kernel<192, 3, 1, DYN>};
-    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN, false, false, 0, DYN == LOSS_STATIC ? 1 : 0>};      /* (static loss rows: a first-pass kernel, the streamed one follows up -- the restoration phase lives there) */
+    if (DYN == LOSS_STATIC && nodes <= 576) return {192, 3, solve_kernel<192, 3, 1, DYN, false, false, 0, 1>};
+    if (nodes <= 640) return {320, 2, solve_kernel<320, 2, 2, DYN, false, false, 0, 1>};
     return {0, 0, nullptr};
 }
 
 /* horizons whose stage blocks do not fit the LDS of a compute unit: node fields, stage blocks and exchange arrays live in device memory, a
  * lane's nodes are worked off one after the other.  512 threads (two waves per SIMD, 256 registers each) with the stage-parallel KKT solve
  * and as few nodes per lane as the horizon allows (N = 1000: two; 38 -> 11 ms per solve against round 2's 1024 x 5 with serial sweeps).
- * The instantiations are spread over two translation units (msd_kernels_stream.hip, msd_kernels_stream2.hip) */
-template <bool DYN> inline Geometry pick_stream_geometry_short_t(int N)      /* N <= 2047 */
+ * A streamed solve is a split launch too (round 5): `fn` = the first pass (PART = 1), `fn2` = the follow-up kernel of the same geometry with the
+ * restoration phase and the watchdog procedure (PART = 2), which also follows up the LDS-resident first-pass kernels of its family.
+ * The instantiations are spread over translation units (msd_kernels_stream*.hip) */
+template <int DYN, bool GEN, int SPT> inline Geometry stream_geometry_t()
 {
-    if (N + 1 <= 1024) return {512, 2, solve_kernel<512, 2, 2, DYN, true>, true};
-    if (N + 1 <= 2048) return {512, 4, solve_kernel<512, 4, 2, DYN, true>, true};
+    return {512, SPT, solve_kernel<512, SPT, 2, DYN, true, GEN, 0, 1>, true, XCH_GENERAL, RED_DOUBLES, solve_kernel<512, SPT, 2, DYN, true, GEN, 0, 2>};
+}
+template <int DYN> inline Geometry pick_stream_geometry_short_t(int N)      /* N <= 2047 */
+{
+    if (N + 1 <= 1024) return stream_geometry_t<DYN, false, 2>();
+    if (N + 1 <= 2048) return stream_geometry_t<DYN, false, 4>();
     return {0, 0, nullptr};
 }
-template <bool DYN> inline Geometry pick_stream_geometry_long_t(int N)       /* N <= 5119 */
+template <int DYN> inline Geometry pick_stream_geometry_long_t(int N)       /* N <= 5119 */
 {
-    if (N + 1 <= 3072) return {512, 6, solve_kernel<512, 6, 2, DYN, true>, true};
-    if (N + 1 <= 5120) return {512, 10, solve_kernel<512, 10, 2, DYN, true>, true};
+    if (N + 1 <= 3072) return stream_geometry_t<DYN, false, 6>();
+    if (N + 1 <= 5120) return stream_geometry_t<DYN, false, 10>();
     return {0, 0, nullptr};
 }
 Geometry pick_stream_geometry_static_long(int N);

@@ -580,7 +580,10 @@ constexpr int W_SC = 72, W_RN = 74, W_RP = 81, W_RZN = 88, W_RZP = 95, W_RDN = 1
 /* behind that: the reference point of the watchdog procedure -- a copy of the iterate's fields W_X ... W_ZUS in the same order (Solver::wd_restore) */
 constexpr int W_WD = 175, W_WD_FIELDS = 37;
 static_assert(W_DSG == W_WD_FIELDS, "the iterate proper: the fields in front of the slack steps");
-constexpr int W_FIELDS = W_WD + W_WD_FIELDS;
+/* behind that: what assemble(MODE_RESTO) hands to riccati_resto next to the stage blocks when the loss rows depend on the running time (integrateLosses):
+ * curvature and gradient of the rows' share in d = t_{i+1} - t_i -- W_dd, W_bd, W_fd, W_pd, W_sd, h_d */
+constexpr int W_RX = W_WD + W_WD_FIELDS, W_RX_FIELDS = 6;
+constexpr int W_FIELDS = W_RX + W_RX_FIELDS;
 __host__ __device__ constexpr size_t work_doubles(int node_slots) { return (size_t)W_FIELDS*node_slots; }
 /* work area of a workgroup of the streamed (long-horizon) kernel: node fields (the same fields as above), stage blocks, six exchange arrays */
 __host__ __device__ constexpr size_t stream_doubles(int N, int node_slots, bool dyn)
@@ -771,7 +774,10 @@ __device__ __forceinline__ bool last_interval(const double *s, const double Ptt,
     const double Gfs = s[S_GFS], is = s[S_IS], gs = s[S_GS], Gbs = DYN ? s[S_GBS] : 0.0, Gps = DYN ? s[S_GPS] : 0.0;      /* (p-s coupling: integrated loss rows) */
     const double eb = -Bb/Bw, e0 = -rb/Bw;
     /* e: the force eliminated through the b row, d(e) = eb db - d(k) + e0; k: the force that is kept */
-    const bool sw = pn && Gpp < Gff;
+#ifndef MSD_LAST_SWAP
+#define MSD_LAST_SWAP 1      /* 0: always eliminate Fel (rounds 1-4; A/B builds) */
+#endif
+    const bool sw = MSD_LAST_SWAP && pn && Gpp < Gff;
     const double Gte = sw ? Gtp : Gtf, Gtk = sw ? Gtf : Gtp, Gbe = sw ? Gbp : Gbf, Gbk = sw ? Gbf : Gbp, Gqe = sw ? 0.0 : Gqf, Gqk = sw ? Gqf : 0.0;
     const double Gee = sw ? Gpp : Gff, Gkk = sw ? Gff : Gpp, Gek = Gfp, Ges = sw ? Gps : Gfs, Gks = sw ? Gfs : Gps, ge = sw ? gp : gf, gk = sw ? gf : gp;
     LG[0] = Gte; LG[1] = Gbe; LG[2] = Gqe; LG[3] = sw ? Gfp : Gff; LG[4] = sw ? Gpp : Gfp; LG[5] = Ges; LG[6] = ge;
@@ -922,24 +928,24 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
 }
 
 /* ------------------------------------------------------------------------------------------
- * Serial sweeps of the restoration problem's Newton system (cold path, one lane; msd_resto.hpp assembles the blocks).  The two
- * dynamics rows of an interval are relaxed there: x+ = F y + r + D lam+ on (t, b), with D = n/z_n + p/z_p > 0 of the row (unscaled).  The
- * value function of stage i+1 enters stage i through  P~ = P - P[:,tb] M P[tb,:],  M = (P2 + D^-1)^-1 = D^1/2 (I + D^1/2 P2 D^1/2)^-1 D^1/2,
- * and the forward sweep takes lam+ = -(I + P2 D)^-1 (P a + p) from the relaxed rows themselves (a = F y + r), so that their linearisation
- * holds to rounding.  b_N stays a parameter: in the last interval df is eliminated through  F_b y + r_b = -sqrt(D_b) v  with
- * v = sqrt(D_b) lam_b+ of unit curvature in the slot of df -- the hard elimination of riccati_solve in the limit D_b -> 0.
- * Leaves (dt, db, df, dp, ds) and the new multipliers (lt, lb) of every interval in its block.  Static loss rows only.
+ * Serial sweeps of the restoration problem's Newton system (cold path, one lane; assemble(MODE_RESTO) leaves the unreduced blocks: the slack
+ * variable is a control of its own here).  The two dynamics rows of an interval are relaxed there: x+ = F y + r + D lam+ on (t, b), with
+ * D = n/z_n + p/z_p > 0 of the row (unscaled).  With the cross terms y_i^T E x_{i+1} of the loss rows that reach into the next node (dynamic loss
+ * table: (b_i, s_i) with b_{i+1}; integrated loss rows: (t_i, b_i, f_i, p_i, s_i) with t_{i+1} through the running time) the stage system is
+ *     G = H + F^T P F + E F2 + (E F2)^T - Q^T M Q,   Q = (P F)[tb,:] + E^T,   M = (P2 + D^-1)^-1 = D^1/2 (I + D^1/2 P2 D^1/2)^-1 D^1/2,
+ * and the forward sweep takes lam+ = -(I + P2 D)^-1 (P a + p + E^T y) from the relaxed rows themselves (a = F y + r), so that their linearisation
+ * holds to rounding -- the oracle's compute_direction, restated on the kernel's blocks.  b_N stays a parameter: in the last interval one force is
+ * eliminated through  F_b y + r_b = -sqrt(D_b) v  with v = sqrt(D_b) lam_b+ of unit curvature in its slot -- the hard elimination of last_interval in
+ * the limit D_b -> 0.  Leaves (dt, db, df, dp, ds) and the new multipliers (lt, lb) of every interval in its block.
+ * X: the integrated loss rows' share in the running time (fields W_RX of the work area, stride NS).
  * ---------------------------------------------------------------------------------------- */
 template <int DYN>
-__device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S, const double *Dtv, const double *Dbv, double *tmp)
+__device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S, const double *Dtv, const double *Dbv, const double *X, const int NS)
 {
-    static_assert(DYN == LOSS_STATIC, "restoration phase: static loss rows");
     constexpr int S_STRIDE = stage_stride(DYN);
-    /* Round 3 kept every array of the sweeps in `tmp` (work area, run-time indices): the stack of this cold function sized the scratch memory of
+    /* Round 3 kept every array of the sweeps in the work area (run-time indices): the stack of this cold function sized the scratch memory of
      * every launch of the kernel it was compiled into.  Since round 4 it only lives in follow-up kernels (solve_kernel: PART = 2), so the
-     * arrays are locals with compile-time indices -- registers -- and the last interval is peeled off the stage loop: a stage costs a few
-     * hundred instructions instead of a few hundred round trips to device memory (8 ms -> 0.1 ms per sweep at N = 100) */
-    (void)tmp;
+     * arrays are locals with compile-time indices -- registers -- and the last interval is peeled off the stage loop */
     double P[3][3], pv[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -949,13 +955,25 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
     }
     P[0][0] = S[N*S_STRIDE + S_HTT]; pv[0] = S[N*S_STRIDE + S_HT];
     bool ok = true, swapLast = false;
+    /* cross terms of stage i: E[a][m], a over (t b q f p s), m over (t+, b+) */
+    auto cross = [&](const int i, const bool last, const double *s, double (&E)[6][2], double (&H)[6][6]) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) E[a][0] = E[a][1] = 0;
+        if (DYN == LOSS_TABLE && !last) { E[1][1] = s[S_EB]; E[5][1] = s[S_ES]; }
+        if (DYN == LOSS_INTEGRATED) {
+            const double Wdd = X[0*NS + i], Wbd = X[1*NS + i], Wfd = X[2*NS + i], Wpd = X[3*NS + i], Wsd = X[4*NS + i];
+            /* d = t+ - t: entries at t are minus, at t+ plus the running time's (H_tt already carries W_dd, the next node's too: assemble) */
+            H[0][1] = H[1][0] = -Wbd; H[0][3] = H[3][0] = -Wfd; H[0][4] = H[4][0] = -Wpd; H[0][5] = H[5][0] = -Wsd;
+            E[0][0] = -Wdd; E[1][0] = Wbd; E[3][0] = Wfd; E[4][0] = Wpd; E[5][0] = Wsd;
+        }
+    };
     auto backward = [&](const int i, auto last_tag) {
         constexpr bool last = decltype(last_tag)::value;
-        constexpr int nu = last ? 3 : 2;      /* controls to eliminate: (f, p), in the last interval (v, k, s) with k the force that is kept */
+        constexpr int nu = 3;      /* controls to eliminate: (f, p, s), in the last interval (v, k, s) with k the force that is kept */
         double *s = S + i*S_STRIDE;
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
         const double Dt = Dtv[i], Db = Dbv[i];
-        double H[6][6], G[6][6], h[6], g[6], Pt[3][3], pt[3], PF[3][6], Pr[3], F[3][6], r[3], L[3][3], K[3][4];
+        double H[6][6], G[6][6], h[6], g[6], PF[3][6], Pr[3], F[3][6], r[3], L[3][3], K[3][4], E[6][2], Q[2][6];
 #pragma unroll
         for (int a = 0; a < 6; a++) {
             h[a] = 0;
@@ -965,8 +983,9 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         H[0][0] = s[S_HTT]; H[1][1] = s[S_HBB]; H[1][2] = H[2][1] = s[S_HBQ]; H[1][3] = H[3][1] = s[S_HBF]; H[1][4] = H[4][1] = s[S_HBP];
         H[2][2] = s[S_HQQ]; H[2][3] = H[3][2] = s[S_HQF]; H[3][3] = s[S_HFF]; H[3][4] = H[4][3] = s[S_HFP]; H[4][4] = s[S_HPP];
         h[0] = s[S_HT]; h[1] = s[S_HB]; h[2] = s[S_HQ]; h[3] = s[S_HF]; h[4] = s[S_HP];
-        if (last) { H[3][5] = H[5][3] = s[S_GFS]; H[5][5] = 1.0/s[S_IS]; h[5] = s[S_GS]; }      /* the last interval keeps its s row */
-        else H[5][5] = 1.0;
+        H[3][5] = H[5][3] = s[S_GFS]; H[5][5] = 1.0/s[S_IS]; h[5] = s[S_GS];      /* the slack variable's row, unreduced (1/NaN when its pivot is not positive: the Cholesky below fails) */
+        if (DYN) { H[1][5] = H[5][1] = s[S_GBS]; H[4][5] = H[5][4] = s[S_GPS]; }
+        cross(i, last, s, E, H);
         /* value function of stage i+1 as it is, for the forward sweep */
         s[S_PN + 0] = P[0][0]; s[S_PN + 1] = P[0][1]; s[S_PN + 2] = P[0][2]; s[S_PN + 3] = P[1][1]; s[S_PN + 4] = P[1][2]; s[S_PN + 5] = P[2][2];
         s[S_PV + 0] = pv[0]; s[S_PV + 1] = pv[1]; s[S_PV + 2] = pv[2];
@@ -983,30 +1002,39 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
             M00 = st*(mc/det)*st; M01 = -st*(mb/det)*sb; M11 = sb*(ma/det)*sb;
         }
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double q0 = P[a][0]*M00 + P[a][1]*M01, q1 = P[a][0]*M01 + P[a][1]*M11;
-#pragma unroll
-            for (int b = 0; b < 3; b++) Pt[a][b] = P[a][b] - (q0*P[0][b] + q1*P[1][b]);
-            pt[a] = pv[a] - (q0*pv[0] + q1*pv[1]);
-        }
-#pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int b = 0; b < 6; b++) F[a][b] = 0;
         F[0][0] = 1; F[0][1] = Tb; F[0][3] = Tw; F[0][4] = pn ? Tw : 0.0; F[1][1] = Bb; F[1][3] = Bw; F[1][4] = pn ? Bw : 0.0; F[2][3] = 1;
         r[0] = rt; r[1] = last ? 0.0 : rb; r[2] = 0;
-        /* G = H + F^T P~ F, g = h + F^T (P~ r + p~) */
+        if (last) {
+#pragma unroll
+            for (int b = 0; b < 6; b++) F[1][b] = 0;      /* db_N = 0: the b row is the equality handled below, not a transition */
+        }
+        /* G = H + F^T P F + E F2 + (E F2)^T, g = h + F^T (P r + p) + E r2 */
 #pragma unroll
         for (int a = 0; a < 3; a++) {
 #pragma unroll
-            for (int b = 0; b < 6; b++) PF[a][b] = Pt[a][0]*F[0][b] + Pt[a][1]*F[1][b] + Pt[a][2]*F[2][b];
-            Pr[a] = pt[a] + Pt[a][0]*r[0] + Pt[a][1]*r[1] + Pt[a][2]*r[2];
+            for (int b = 0; b < 6; b++) PF[a][b] = P[a][0]*F[0][b] + P[a][1]*F[1][b] + P[a][2]*F[2][b];
+            Pr[a] = pv[a] + P[a][0]*r[0] + P[a][1]*r[1] + P[a][2]*r[2];
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
 #pragma unroll
-            for (int b = 0; b < 6; b++) G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b];
-            g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2];
+            for (int b = 0; b < 6; b++)
+                G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b]
+                          + (DYN ? E[a][0]*F[0][b] + E[a][1]*F[1][b] + F[0][a]*E[b][0] + F[1][a]*E[b][1] : 0.0);
+            g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2] + (DYN ? E[a][0]*r[0] + E[a][1]*r[1] : 0.0);
+        }
+        /* - Q^T M Q on the relaxed rows */
+#pragma unroll
+        for (int b = 0; b < 6; b++) { Q[0][b] = PF[0][b] + (DYN ? E[b][0] : 0.0); Q[1][b] = PF[1][b] + (DYN ? E[b][1] : 0.0); }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double q0 = M00*Q[0][a] + M01*Q[1][a], q1 = M01*Q[0][a] + M11*Q[1][a];
+#pragma unroll
+            for (int b = 0; b < 6; b++) G[a][b] -= q0*Q[0][b] + q1*Q[1][b];
+            g[a] -= q0*Pr[0] + q1*Pr[1];
         }
         if (!pn) {
 #pragma unroll
@@ -1102,7 +1130,7 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
                 x[a] = v/L[a][a];
             }
 #pragma unroll
-            for (int a = 0; a < 3; a++) K[a][c] = a < nu ? x[a] : 0.0;
+            for (int a = 0; a < 3; a++) K[a][c] = x[a];
         }
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -1125,7 +1153,7 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         if (!pn) { K[1][0] = K[1][1] = K[1][2] = K[1][3] = 0; }
         s[S_K + 0] = K[0][0]; s[S_K + 1] = K[0][1]; s[S_K + 2] = K[0][2]; s[S_K + 3] = K[1][0]; s[S_K + 4] = K[1][1]; s[S_K + 5] = K[1][2];
         s[S_KV + 0] = K[0][3]; s[S_KV + 1] = K[1][3];
-        if (last) { s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3]; }
+        s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3];      /* (over the slack row's inputs, which are used up) */
     };
     backward(N - 1, std::true_type());
 #pragma unroll 1
@@ -1141,20 +1169,20 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         const double Dt = Dtv[i], Db = Dbv[i];
         const double u0 = s[S_K + 0]*x0 + s[S_K + 1]*x1 + s[S_K + 2]*x2 + s[S_KV + 0];
         const double u1 = pn ? s[S_K + 3]*x0 + s[S_K + 4]*x1 + s[S_K + 5]*x2 + s[S_KV + 1] : 0.0;
-        double df, dsl, dp = u1;
+        const double dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
+        double df = u0, dp = u1;
         if (last) {
             /* u0: v, u1: the force that was kept */
-            dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
             const double de = -Bb/Bw*x1 - u1 - rb/Bw - sqrt(Db)/Bw*u0;
             df = swapLast ? u1 : de; dp = swapLast ? de : u1;
-        } else {
-            df = u0;
-            dsl = -(s[S_GS] + s[S_GFS]*df)*s[S_IS];
         }
         const double dw = df + dp;
         const double at = x0 + Tb*x1 + Tw*dw + rt, ab = last ? 0.0 : Bb*x1 + Bw*dw + rb;
         const double Ptt = s[S_PN + 0], Ptb = s[S_PN + 1], Ptq = s[S_PN + 2], Pbb = s[S_PN + 3], Pbq = s[S_PN + 4];
-        const double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
+        double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
+        /* + E^T y */
+        if (DYN == LOSS_TABLE && !last) g1 += s[S_EB]*x1 + s[S_ES]*dsl;
+        if (DYN == LOSS_INTEGRATED) g0 += -X[0*NS + i]*x0 + X[1*NS + i]*x1 + X[2*NS + i]*df + X[3*NS + i]*dp + X[4*NS + i]*dsl;
         double lt, lb, nt, nb;
         if (last) { lt = -g0/(1 + Ptt*Dt); lb = u0/sqrt(Db); nt = at + Dt*lt; nb = 0; }
         else {
@@ -1991,6 +2019,7 @@ struct Solver {
      */
     __device__ __forceinline__ void assemble(const int mode, double mu_, double dw, const double eta = 0.0)
     {
+        constexpr bool UNFOLD = DYN == LOSS_INTEGRATED;      /* (see below: MODE_RESTO keeps the running time of the integrated loss rows unfolded) */
         Ev e[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++) load_ev(j, e[j]);
@@ -2003,11 +2032,16 @@ struct Solver {
             double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
             double nHbb = 0, nHbq = 0, nhb = 0;
             double Hbs = 0, Hps = 0, Eb = 0, Es = 0;     /* only the dynamic / integrated loss rows fill these */
+            /* MODE_RESTO with integrated loss rows: the rows' share in the running time d = t_{i+1} - t_i stays unfolded (the time row is relaxed there, so
+             * d no longer obeys its linearisation): curvature W_xd over x = (b, f, p, s), W_dd, gradient h_d -- riccati_resto turns them into entries of
+             * (t_i, t_{i+1}) */
+            const bool unfold = UNFOLD && mode == MODE_RESTO;
+            double Wdd = 0, Wbd = 0, Wfd = 0, Wpd = 0, Wsd = 0, hd = 0;
             if (nd.ival()) {
                 const double f = nd.x[VF];
                 double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
                 row_grads(j, e[j], gb, gf, gp, gs, gb1, gd);
-                fold_running_time(e[j], gb, gf, gp, gd);
+                if (!unfold) fold_running_time(e[j], gb, gf, gp, gd);
                 const double rt = (mode == MODE_NEWTON) ? -resc[j][0] : 0.0;
                 double of, op, os, oq, off, opp;
                 obj_grads(j, q, of, op, os, oq, off, opp);
@@ -2031,7 +2065,8 @@ struct Solver {
                          * dd = tb db + tw (df + dp) + rt (quadratic form; the part linear in rt goes to the gradient) */
                         const LossHess L = loss_hess(f, b, e[j]);
                         const double W = nd.nu[RLTR]*U.rs[RLTR]*(-P.ct) + nd.nu[RLRG]*U.rs[RLRG]*P.cr;
-                        const double tb = e[j].tb, tw = e[j].tw;
+                        const double tb = unfold ? 0.0 : e[j].tb, tw = unfold ? 0.0 : e[j].tw;
+                        if (unfold) { Wbd += W*L.bd; Wfd += W*L.fd; Wdd += W*L.dd; if (withPn()) Wpd += W*L.pd; }
                         Hbb += W*(L.bb + 2*tb*L.bd + tb*tb*L.dd);
                         Hbf += W*(L.bf + tb*L.fd + tw*L.bd + tb*tw*L.dd);
                         Hff += W*(L.ff + 2*tw*L.fd + tw*tw*L.dd);
@@ -2068,6 +2103,7 @@ struct Solver {
                         coef = St*resd[j][r] + gphi*St/Sg; Sg = St;
                     }
                     else { Sg = 1.0; coef = -nd.zLs[r] + nd.zUs[r]; }
+                    if (unfold) { hd += coef*gd[r]; Wbd += Sg*gb[r]*gd[r]; Wfd += Sg*gf[r]*gd[r]; Wpd += Sg*gp[r]*gd[r]; Wsd += Sg*gs[r]*gd[r]; Wdd += Sg*gd[r]*gd[r]; }
                     hb += coef*gb[r]; hf += coef*gf[r]; hp += coef*gp[r]; hs += coef*gs[r]; nhb += coef*gb1[r];
                     Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
                     Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
@@ -2075,6 +2111,7 @@ struct Solver {
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
                     if (DYN) { Hbs += Sg*gb[r]*gs[r]; Hps += Sg*gp[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
+                if (unfold) { Htt += Wdd; ht -= hd; }      /* (d = t_{i+1} - t_i: the entries at t_i; those at t_{i+1} go to the next node below) */
             } else if (nd.i == P.N && !energyOpt() && mode != MODE_RESTO) ht = U.sf/P.objDen;
             /* bounds of the node's own variables + regularisation */
             if (nd.node()) {
@@ -2106,14 +2143,16 @@ struct Solver {
                     const double Bb = e[j].Bb, Bw = e[j].Bw, rb = (mode == MODE_NEWTON) ? -resc[j][1] : 0.0;
                     const bool last = nd.i == P.N - 1;
                     double Gbs = Hbs, Gfs = Hfs, Gps = Hps, gsv = hs;
-                    if (DYN && !last) {
+                    /* (MODE_RESTO: the dynamics rows are relaxed, nothing folds through them, and the slack variable stays a control of its own: riccati_resto
+                     *  works on the unreduced blocks, with the couplings Eb, Es of (b_i, s_i) with b_{i+1} as cross terms) */
+                    if (DYN && !last && mode != MODE_RESTO) {
                         Hbb += 2*Eb*Bb; Hbf += Eb*Bw; hb += Eb*rb;
                         if (withPn()) Hbp += Eb*Bw;
                         Gbs += Es*Bb; Gfs += Es*Bw; gsv += Es*rb;
                         if (withPn()) Gps += Es*Bw;
                     }
                     const double is = (Hss > 0) ? 1.0/Hss : NAN;
-                    if (!last) {
+                    if (!last && mode != MODE_RESTO) {
                         const double wf = Gfs*is;
                         Hff -= Gfs*wf; hf -= wf*gsv;
                         if (DYN) {
@@ -2131,6 +2170,11 @@ struct Solver {
             }
             /* the end-of-interval power row lives in the next stage's (b, q) block */
             c.o1[nd.i] = nHbb; c.o2[nd.i] = nHbq; c.o3[nd.i] = nhb;
+            if constexpr (UNFOLD && STREAM) {
+                if (unfold) {
+                    wf(W_RX + 0, nd.i) = Wdd; wf(W_RX + 1, nd.i) = Wbd; wf(W_RX + 2, nd.i) = Wfd; wf(W_RX + 3, nd.i) = Wpd; wf(W_RX + 4, nd.i) = Wsd; wf(W_RX + 5, nd.i) = hd;
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -2140,6 +2184,9 @@ struct Solver {
             if (nd.node() && nd.i > 0) {
                 double *s = c.S + nd.i*S_STRIDE;
                 s[S_HBB] += c.o1[nd.i - 1]; s[S_HBQ] += c.o2[nd.i - 1]; s[S_HB] += c.o3[nd.i - 1];
+                if constexpr (UNFOLD && STREAM) {
+                    if (mode == MODE_RESTO) { s[S_HTT] += wf(W_RX + 0, nd.i - 1); s[S_HT] += wf(W_RX + 5, nd.i - 1); }      /* the entries at t_{i+1} of the interval before */
+                }
             }
         }
         __syncthreads();
@@ -3001,10 +3048,13 @@ struct Solver {
 #define MSD_RESTO 1      /* 0: kernels without the restoration phase (A/B builds) */
 #endif
     static constexpr bool FIRST = PART == 1 || PART == 3;
-    /* static loss rows: the kernels of up to four waves whose horizon fits the LDS hold the phase themselves (in their follow-up kernels), so do the
-     * streamed kernels (N <= 5119); the other families with static loss rows -- collocation / adaptive shooting, 320 x 2 -- are compiled as first-pass
-     * kernels (PART = 1) and followed up by the streamed kernel of their family (msd_api.hip: make_plan).  Not: the dynamic and the integrated loss rows */
-    static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && DYN == LOSS_STATIC && (STREAM || FIRST || (!GEN && NT <= 256));
+    /* Every family has the phase (round 5: also the dynamic loss table and integrateLosses -- assemble(MODE_RESTO) leaves their couplings with b_{i+1} resp.
+     * the running time unfolded and riccati_resto carries them as cross terms, like the oracle's compute_direction).  Where it lives: in the follow-up
+     * kernels.  The kernels with the structure of the reference's rolling stock compiled in have LDS-resident follow-up kernels of their own; every other
+     * LDS-resident kernel is a first-pass kernel (PART = 1) followed up by the streamed kernel of its family, and a streamed solve is a first-pass kernel
+     * plus a follow-up kernel of the same geometry too (msd_api.hip: make_plan) -- the cold paths cost the streamed kernels a quarter of their speed when
+     * they sat in the same code object (round 4) */
+    static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && (STREAM || FIRST || PART == 2 || (DYN == LOSS_STATIC && !GEN && NT <= 256));
     static constexpr bool HAS_RESTO = FAMILY_HAS_RESTO && !FIRST;      /* (a first-pass kernel leaves the phase to its follow-up kernel) */
     static constexpr int STATUS_RESTO = -101;
 
@@ -3021,7 +3071,7 @@ struct Solver {
      * integrators) the register allocation of their loop fell apart: 591 -> 3 172 spilled registers on the 64 x 2 kernel of the dynamic loss model, 295 k
      * -> 163 k solves/s (profiles/r04).  A first-pass kernel counts the shortened iterations and hands the scenario over when the procedure is due; a
      * complete LDS-resident kernel without a follow-up kernel (PART = 0: those families) only counts -- no watchdog procedure there */
-    static constexpr bool WD_FULL = MSD_WATCHDOG && (PART == 2 || STREAM);
+    static constexpr bool WD_FULL = MSD_WATCHDOG && (PART == 2 || (STREAM && PART == 0));
     static constexpr bool WD_HANDOVER = MSD_WATCHDOG && !WD_FULL && (PART == 1 || PART == 3);
     static constexpr bool RESUMABLE = (FAMILY_HAS_RESTO && !(PART == 1 || PART == 3)) || WD_FULL;      /* the general iteration can be entered again (`resume`) */
     /* StopWatchDog, the part outside the iteration (solve_kernel calls it between two entries of run): the watchdog's copy back to the iterate's fields in

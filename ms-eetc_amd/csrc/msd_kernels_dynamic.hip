@@ -7,5 +7,5 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_geometry_dynamic(int N) { return pick_geometry_t<true>(N); }
+Geometry pick_geometry_dynamic(int N) { return pick_geometry_t<LOSS_TABLE>(N); }
 }

@@ -33,9 +33,9 @@ Geometry pick_geometry_intloss_full(int N)
 {
     const int nodes = N + 1;
     if (no_full()) return {0, 0, nullptr};
-    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_INTEGRATED, false, false, true>};
-    if (nodes <= 128 && two_nodes_per_lane()) return {64, 2, solve_kernel<64, 2, 1, LOSS_INTEGRATED, false, false, true>};
-    if (nodes <= 128) return {128, 1, solve_kernel<128, 1, 1, LOSS_INTEGRATED, false, false, true>};
+    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_INTEGRATED, false, false, FULL_BOTH, 1>};
+    if (nodes <= 128 && two_nodes_per_lane()) return {64, 2, solve_kernel<64, 2, 1, LOSS_INTEGRATED, false, false, FULL_BOTH, 1>};
+    if (nodes <= 128) return {128, 1, solve_kernel<128, 1, 1, LOSS_INTEGRATED, false, false, FULL_BOTH, 1>};
     return {0, 0, nullptr};
 }
 

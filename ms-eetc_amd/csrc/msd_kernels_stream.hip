@@ -9,7 +9,7 @@
 namespace msd {
 Geometry pick_stream_geometry_static(int N)
 {
-    const Geometry g = pick_stream_geometry_short_t<false>(N);
+    const Geometry g = pick_stream_geometry_short_t<LOSS_STATIC>(N);
     return g.fn ? g : pick_stream_geometry_static_long(N);
 }
 }

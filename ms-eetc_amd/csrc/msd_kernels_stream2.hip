@@ -7,5 +7,5 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_stream_geometry_static_long(int N) { return pick_stream_geometry_long_t<false>(N); }
+Geometry pick_stream_geometry_static_long(int N) { return pick_stream_geometry_long_t<LOSS_STATIC>(N); }
 }

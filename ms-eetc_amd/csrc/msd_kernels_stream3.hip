@@ -8,7 +8,7 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_stream_geometry_dynamic(int N) { return N + 1 <= 1024 ? Geometry{512, 2, solve_kernel<512, 2, 2, LOSS_TABLE, true>, true} : Geometry{0, 0, nullptr}; }
-Geometry pick_stream_geometry_general(int N) { return N + 1 <= 1024 ? Geometry{512, 2, solve_kernel<512, 2, 2, LOSS_STATIC, true, true>, true} : Geometry{0, 0, nullptr}; }
-Geometry pick_stream_geometry_intloss(int N) { return N + 1 <= 1024 ? Geometry{512, 2, solve_kernel<512, 2, 2, LOSS_INTEGRATED, true>, true} : Geometry{0, 0, nullptr}; }
+Geometry pick_stream_geometry_dynamic(int N) { return N + 1 <= 1024 ? stream_geometry_t<LOSS_TABLE, false, 2>() : Geometry{0, 0, nullptr}; }
+Geometry pick_stream_geometry_general(int N) { return N + 1 <= 1024 ? stream_geometry_t<LOSS_STATIC, true, 2>() : Geometry{0, 0, nullptr}; }
+Geometry pick_stream_geometry_intloss(int N) { return N + 1 <= 1024 ? stream_geometry_t<LOSS_INTEGRATED, false, 2>() : Geometry{0, 0, nullptr}; }
 }

@@ -6,6 +6,6 @@
 #include "msd_geometry.hpp"
 
 namespace msd {
-Geometry pick_stream_geometry_general_dynamic(int N) { return N + 1 <= 1024 ? Geometry{512, 2, solve_kernel<512, 2, 2, LOSS_TABLE, true, true>, true} : Geometry{0, 0, nullptr}; }
-Geometry pick_stream_geometry_general_intloss(int N) { return N + 1 <= 1024 ? Geometry{512, 2, solve_kernel<512, 2, 2, LOSS_INTEGRATED, true, true>, true} : Geometry{0, 0, nullptr}; }
+Geometry pick_stream_geometry_general_dynamic(int N) { return N + 1 <= 1024 ? stream_geometry_t<LOSS_TABLE, true, 2>() : Geometry{0, 0, nullptr}; }
+Geometry pick_stream_geometry_general_intloss(int N) { return N + 1 <= 1024 ? stream_geometry_t<LOSS_INTEGRATED, true, 2>() : Geometry{0, 0, nullptr}; }
 }

@@ -14,8 +14,8 @@
  * in a function of its own (resto_entry, noinline) between two calls of the general iteration: the caller parks the register-resident
  * iterate in the work area, this code works on it there, the general iteration picks it up again (Solver::run, `resume`).  (n, p, z_n, z_p),
  * their steps, the reference point, the original bound multipliers and the filter of the restoration problem are further fields of the work
- * area (W_R*).  The Newton system: assemble(MODE_RESTO) + riccati_resto (serial sweeps on one lane).  Static loss rows, horizons that fit
- * the LDS; no second-order correction inside.
+ * area (W_R*).  The Newton system: assemble(MODE_RESTO) + riccati_resto (serial sweeps on one lane; every loss model: the couplings of the dynamic loss
+ * table with b_{i+1} and of the integrated loss rows with the running time enter as cross terms).  No second-order correction inside.
  */
 static constexpr double RESTO_RHO = 1000.0;            /* resto_penalty_parameter */
 static constexpr double RESTO_KAPPA = 0.9;             /* required_infeasibility_reduction */
@@ -185,7 +185,7 @@ __device__ __forceinline__ int restoration(const double *scen, double *hist, int
         bool ok;
         for (bool first = true;; first = false) {
             assemble(MODE_RESTO, mu, dw, eta);
-            if (c.tid == 0) c.misc[0] = riccati_resto<DYN>(N, withPn(), c.S, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS, work + (size_t)W_RTMP*NS) ? 1.0 : 0.0;
+            if (c.tid == 0) c.misc[0] = riccati_resto<DYN>(N, withPn(), c.S, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS, work + (size_t)W_RX*NS, NS) ? 1.0 : 0.0;
             __syncthreads();
             ok = uni(c.misc[0]) != 0.0;
             __syncthreads();
@@ -230,6 +230,7 @@ __device__ __forceinline__ int restoration(const double *scen, double *hist, int
                 }
                 if (!nd.ival()) continue;
                 const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
+                const double dd_ = (DYN == LOSS_INTEGRATED) ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time (integrated loss rows) */
                 double gb[NR], gf[NR], gp_[NR], gs[NR], gb1[NR], gdd[NR];
                 Ev ej; load_ev1(j, ej);
                 row_grads(j, ej, gb, gf, gp_, gs, gb1, gdd);
@@ -239,7 +240,7 @@ __device__ __forceinline__ int restoration(const double *scen, double *hist, int
                 for (int r = 0; r < NR; r++) {
                     dy[2 + r] = 0;
                     if (!rowOn(r)) continue;
-                    const double lin = resd[j][r] + gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp_[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1;
+                    const double lin = resd[j][r] + gb[r]*d.dx[VB] + gf[r]*d.dx[VF] + gp_[r]*d.dx[VP] + gs[r]*d.dx[VS] + gb1[r]*db1 + gdd[r]*dd_;
                     double Sg, gphi; row_terms(j, r, mu, Sg, gphi);
                     const double Sw = Sg + dw, St = 1.0/(rs_D(nd.i, 2 + r) + 1.0/Sw), nup = St*lin + gphi*St/Sw;
                     const double ds_ = (nup - gphi)/Sw;

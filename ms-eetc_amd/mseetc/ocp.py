@@ -79,7 +79,8 @@ class casadiSolver():
         from a speed profile built on the device from the limits, the running time and the end speeds -- same optimum,
         about half the interior-point iterations; a scenario that breaks down from it is repeated from the reference's point.
         `restoration` (default True, IPOPT's behaviour): a solve whose filter line search breaks down enters the feasibility restoration
-        phase on the device (static loss models, 'RK' shooting, N <= 511); False: it ends there ('Restoration_Failed') after the restart from the other
+        phase on the device (every loss model, shooting integrator and horizon: in the follow-up kernels, csrc/msd_resto.hpp); False: it ends there
+        ('Restoration_Failed') after the restart from the other
         starting point -- what a loop that handles failed scenarios itself wants (mseetc/mpc.py), since a hopeless scenario can spend
         hundreds of iterations in restoration and a launch lasts as long as its slowest scenario.
         """

@@ -49,3 +49,15 @@ bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_stream(const EmuArgs &a);
 #define EMU_CALL(...) run_blocks<__VA_ARGS__>(a.P, a.nscen, a.scen, a.ovr, a.z, a.lam, a.stats, a.hist, a.cap)
+
+/* a split solve of a family without LDS-resident follow-up kernels, like msd_api.hip: launch_plan does it: the first pass (PART = 1: the general iteration
+ * without the cold paths) + the streamed follow-up kernel of the family -- restoration phase, watchdog procedure, second attempt -- over the list the first
+ * pass left (a stand-in geometry the emulation can afford: 128 x 5) */
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL> void run_first_and_follow(EmuArgs a)
+{
+    std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
+    a.P.follow = follow.data();
+    EMU_CALL(NT, SPT, DYN, STREAM, GEN, FULL, 1);
+    a.P.list = follow.data(); a.P.follow = nullptr;
+    EMU_CALL(128, 5, DYN, true, GEN, 0, 2);
+}

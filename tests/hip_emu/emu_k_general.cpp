@@ -3,14 +3,7 @@
 
 /* like msd_api.hip launches this family: a first-pass kernel (general iteration without the restoration phase), then the streamed kernel of the
  * family -- which has the phase -- over the list the first pass left (a stand-in geometry the emulation can afford: 128 x 5) */
-template <int NT, int SPT> static void run_split(EmuArgs a)
-{
-    std::vector<int> follow(msd::FOLLOW_HDR + 2*(size_t)a.nscen, 0);
-    a.P.follow = follow.data();
-    EMU_CALL(NT, SPT, 0, false, true, 0, 1);
-    a.P.list = follow.data(); a.P.follow = nullptr;
-    EMU_CALL(128, 5, 0, true, true);
-}
+template <int NT, int SPT> static void run_split(EmuArgs a) { run_first_and_follow<NT, SPT, 0, false, true, 0>(a); }
 
 bool emu_run_general(int NT, int SPT, const EmuArgs &a)
 {
@@ -22,6 +15,6 @@ bool emu_run_general(int NT, int SPT, const EmuArgs &a)
 /* the same integrators with integrateLosses (loss rows from the integrated loss distance, msd_lossint.hpp) */
 bool emu_run_general_intloss(int NT, int SPT, const EmuArgs &a)
 {
-    if (NT == 64 && SPT == 1) { EMU_CALL(64, 1, 2, false, true); return true; }
+    if (NT == 64 && SPT == 1) { run_first_and_follow<64, 1, 2, false, true, 0>(a); return true; }
     return false;
 }

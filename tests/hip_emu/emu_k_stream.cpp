@@ -1,4 +1,4 @@
-/* TEST-ONLY: host emulation, the long-horizon kernel at a thread count the emulation can afford (see emu_common.h) */
+/* TEST-ONLY: host emulation, streamed kernels (see emu_common.h) */
 #include "emu_common.h"
 
-bool emu_run_stream(const EmuArgs &a) { EMU_CALL(128, 5, false, true); return true; }
+bool emu_run_stream(const EmuArgs &a) { run_first_and_follow<128, 5, 0, true, false, 0>(a); return true; }

@@ -93,43 +93,81 @@ def test_emulated_restoration_phase_follows_the_oracle():
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
 
 
-@pytest.mark.parametrize('family', ['streamed', 'collocation'])
+def _family_case(family, N, maxit, crop=12000):
+    "(train, track, solver options, oracle problem, solve keywords) of the kernel families outside the LDS-resident Runge-Kutta kernels"
+    from oracle import oracle
+    from mseetc.track import computeDiscretizationPoints
+    train, track, kw = cases.train_default(), cases.track_00(crop) if crop else cases.track_00(), {}
+    if family in ('streamed', 'RK'):
+        opts = dict(numIntervals=N, maxIterations=maxit, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        prob = cases.oracle_problem(train, track, N, maxIterations=maxit)
+    elif family in ('collocation', 'IRK'):
+        opts = dict(numIntervals=N, maxIterations=maxit, integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))
+        prob = cases.oracle_problem(train, track, N, numSteps=1, numApproxSteps=0, maxIterations=maxit,
+                                    integration=dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10))
+    elif family == 'CVODES':
+        opts = dict(numIntervals=N, maxIterations=maxit, integrationMethod='CVODES', integrationOptions=dict())
+        prob = cases.oracle_problem(train, track, N, numSteps=1, numApproxSteps=0, maxIterations=maxit, integration=dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6))
+    elif family == 'integrateLosses':
+        opts = dict(numIntervals=N, maxIterations=maxit, integrateLosses=True, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        prob = cases.oracle_problem(train, track, N, maxIterations=maxit, integration=dict(integrateLosses=True))
+    else:
+        # the dynamic loss model on the configuration of simulations/figure5.py (8.5 km, v0 = 1 m/s, vN = 100 km/h, forceMinPn = 0)
+        from mseetc.train import Train
+        from mseetc.efficiency import totalLossesFunction
+        assert family == 'dynamic'
+        train = Train(config={'id': 'NL_Intercity_VIRM6'})
+        train.forceMinPn = 0
+        train.powerLosses = totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+        track = cases.track_00(8500)
+        oracle.set_loss_table(train.powerLosses.parameters(train.mass*train.rho))
+        opts = dict(numIntervals=N, maxIterations=maxit, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        prob = oracle.pack_problem(train, computeDiscretizationPoints(track, N), dict(numIntervals=N, maxIterations=maxit, energyOptimal=True, minimumVelocity=1,
+                                                                                     numSteps=1, numApproxSteps=1), 2, 0.0, 0.0, track.length)
+        kw = dict(terminalVelocity=100/3.6, initialVelocity=1)
+    return train, track, opts, prob, kw
+
+
+@pytest.mark.parametrize('family', ['streamed', 'collocation', 'dynamic', 'integrateLosses'])
 def test_emulated_restoration_phase_in_the_other_kernel_families(family, monkeypatch):
     """
-    Round 4: the phase outside the LDS-resident Runge-Kutta kernels.  `streamed`: the long-horizon kernel (node fields and stage blocks in device
-    memory) holds the phase itself -- same history as the oracle, row by row.  `collocation`: the kernels of the other shooting integrators are
-    first-pass kernels; the scenario whose line search breaks down is listed and solved again, with the phase, by the streamed kernel of the family
-    (msd_api.hip: make_plan; the emulation launches the two like the host code does).
+    The phase outside the LDS-resident Runge-Kutta kernels.  `streamed`: the long-horizon kernels (node fields and stage blocks in device memory): a first
+    pass + the follow-up kernel of the same geometry, which holds the phase -- same history as the oracle, row by row.  `collocation`, `dynamic` (loss
+    table of efficiency.py), `integrateLosses` (ocp.py:231-241): LDS-resident first-pass kernels; the scenario whose line search breaks down is listed and
+    solved again, with the phase, by the streamed follow-up kernel of the family (msd_api.hip: make_plan; the emulation launches the two like the host code
+    does).  Round 5 for the last two: their loss rows reach into the next node (b_{i+1}, resp. t_{i+1} through the running time), which the Newton system
+    of the restoration problem carries as cross terms (riccati_resto; the oracle's compute_direction, whose Newton residuals ORACLE_DEBUG=2 prints).
+    An infeasible running time: both sides go through restoration phases and end at the iteration limit of the second attempt.
     """
     from test_kernel_emulation import load_emulation
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
     from oracle import oracle
     emu = load_emulation()
-    N, crop, T, cap = 30, 12000, 300.0, 64
-    train, track = cases.train_default(), cases.track_00(crop)
+    N, cap = 30, 64
+    T = 200.0 if family == 'dynamic' else 300.0
     if family == 'streamed':
         monkeypatch.setenv('EMU_GEOMETRY', 'stream')
-        opts = dict(numIntervals=N, maxIterations=60, integrationOptions=dict(numSteps=1, numApproxSteps=1))
-        prob = cases.oracle_problem(train, track, N, maxIterations=60)
-    else:
-        opts = dict(numIntervals=N, maxIterations=60, integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))
-        prob = cases.oracle_problem(train, track, N, numSteps=1, numApproxSteps=0, maxIterations=60,
-                                    integration=dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10))
+    train, track, opts, prob, kw = _family_case(family, N, 60)
     solver = casadiSolver(train, track, opts, startingPoint='reference')
-    scen = solver._scenarios(T, 0, 1, 1)
+    scen = solver._scenarios(T, 0, kw.get('terminalVelocity', 1), kw.get('initialVelocity', 1))
     nz = (4 + int(solver.withPnBrake))*N + 2
     z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((cap, 8))
     d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), cap) == 0
-    ref = oracle.solve(prob, prob.scenario(T), start='reference', history=True)
+    ref = oracle.solve(prob, prob.scenario(T, **kw), start='reference', history=True)
     assert int(st[0, ST['STATUS']]) == int(ref['stats']['STATUS']) == -1
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 120
     assert int(st[0, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
     h = ref['hist']
-    for i in range(60 if family == 'streamed' else 36):      # (collocation: the Newton iteration inside the integrator lets the two drift apart by 1e-4 after forty iterations)
-        assert np.allclose(hist[i, 1:5], h[i, 1:5], rtol=1e-4, atol=1e-9), (i, hist[i], h[i])
-    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < (1e-4 if family == 'streamed' else 1e-2)
+    # (collocation: the Newton iteration inside the integrator -- OptionsIRK.maxIter steps, no convergence test, like casadi.simpleIRK -- lets the two drift
+    #  apart: 1.2e-4 in the dual infeasibility of the restoration iterates from row 24 on, 1e-4 in everything after forty iterations)
+    #  integrateLosses: the loss integrals come from an adaptive integrator (CVODES' tolerances, msd_lossint.hpp); the two implementations agree to 1e-10 up
+    #  to the breakdown at row 20 -- dual infeasibility 3e9 -- and to 1e-5 ... 1e-4 on the restoration iterates behind it, which start from that point)
+    for i in range(36 if family == 'collocation' else 60):
+        rtol = 3e-4 if family == 'collocation' else (1e-3 if i > 25 else 1e-4) if family == 'integrateLosses' else 1e-4
+        assert np.allclose(hist[i, 1:5], h[i, 1:5], rtol=rtol, atol=1e-9), (i, hist[i], h[i])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < (1e-2 if family == 'collocation' else 1e-4)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -221,33 +259,27 @@ def test_gpu_restoration_on_every_geometry(N, variant):
 
 
 @gpu
-@pytest.mark.parametrize('family,N,T', [('CVODES', 100, 14000.0), ('CVODES', 100, 20000.0), ('IRK', 300, 9000.0), ('RK', 600, 9000.0), ('RK', 700, 9000.0), ('RK', 1200, 20000.0)])
+@pytest.mark.parametrize('family,N,T', [('CVODES', 100, 14000.0), ('CVODES', 100, 20000.0), ('IRK', 300, 9000.0), ('RK', 600, 9000.0), ('RK', 700, 9000.0), ('RK', 1200, 20000.0),
+                                        ('integrateLosses', 100, 14000.0), ('dynamic', 100, 1500.0)])
 def test_gpu_restoration_in_the_other_kernel_families(family, N, T):
     """
-    Round 4: the restoration phase for every kernel family with static loss rows.  Adaptive ('CVODES') and collocation ('IRK') shooting: first-pass
-    kernels + the streamed kernel of the family behind them; 600 intervals: the five-wave kernel + the streamed one; 700 and 1200 intervals: the streamed
-    kernels themselves.  A loose schedule from the reference's starting point goes through restoration phases in the oracle and on the device
-    and reaches the oracle's optimum.  (Not: the dynamic loss model and integrateLosses -- their loss rows couple neighbouring stages, the
-    restoration problem's Newton system is not restated for them, neither in the oracle nor here.)
+    The restoration phase for every kernel family.  Adaptive ('CVODES') and collocation ('IRK') shooting: first-pass kernels + the streamed follow-up kernel
+    of the family; 600 intervals: the five-wave kernel + the streamed one; 700 and 1200 intervals: the streamed kernels themselves (first pass + follow-up
+    kernel of the same geometry).  Round 5: integrateLosses (ocp.py:231-241) and the dynamic loss model (efficiency.py; figure-5 configuration) -- first-pass
+    kernels + the streamed follow-up kernel of their family, the loss rows' couplings with the next node as cross terms of the restoration problem's Newton
+    system.  A loose schedule from the reference's starting point goes through restoration phases in the oracle and on the device and reaches the oracle's
+    optimum (dynamic loss table: to 1e-4 -- the table's kinks leave the two solvers on iterates 1e-5 apart in cost).
     """
     from mseetc.ocp import casadiSolver
     from mseetc._device import ST
     from oracle import oracle
-    train, track = cases.train_default(), cases.track_00()
-    if family == 'RK':
-        opts, integ, kw = dict(numIntervals=N, maxIterations=800, integrationOptions=RK11), None, {}
-    elif family == 'IRK':
-        opts = dict(numIntervals=N, maxIterations=800, integrationMethod='IRK', integrationOptions=dict(order=2, numSteps=1, numApproxSteps=0))
-        integ, kw = dict(integrationMethod='IRK', order=2, collMethod='radau', maxIter=10), dict(numSteps=1, numApproxSteps=0)
-    else:
-        opts = dict(numIntervals=N, maxIterations=800, integrationMethod='CVODES', integrationOptions=dict())
-        integ, kw = dict(integrationMethod='CVODES', absTol=1e-8, relTol=1e-6), dict(numSteps=1, numApproxSteps=0)
+    train, track, opts, prob, kw = _family_case(family, N, 800, crop=None)
     s = casadiSolver(train, track, opts, startingPoint='reference')
-    res = s.solveBatch([T])
+    res = s.solveBatch([T], **kw)
     s.close()
-    prob = cases.oracle_problem(train, track, N, maxIterations=800, integration=integ, **kw)
-    ref = oracle.solve(prob, prob.scenario(T), start='reference')
+    ref = oracle.solve(prob, prob.scenario(T, **kw), start='reference')
     assert res['status'][0] == int(ref['stats']['STATUS']) == 0
     assert int(ref['stats']['N_RESTO']) >= 1 and int(res['stats'][0, ST['N_RESTO']]) >= 1
-    assert abs(res['cost'][0] - ref['stats']['OBJ']) <= 1e-7*abs(ref['stats']['OBJ'])
-    assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4
+    assert abs(res['cost'][0] - ref['stats']['OBJ']) <= (1e-4 if family == 'dynamic' else 1e-7)*abs(ref['stats']['OBJ'])
+    if family != 'dynamic':
+        assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-4

@@ -55,18 +55,19 @@ def test_oracle_watchdog_with_a_lowered_trigger(N, crop, T, trigger, expect):
 
 def test_oracle_watchdog_takes_trial_points_without_the_filters_consent(tmp_path):
     """
-    The part of the procedure the ordinary problems never reach: four times the minimum running time on a random track (a zero-cost journey: the
-    energy optimum is degenerate, the iteration crawls with shortened steps).  The procedure starts at IPOPT's own trigger, takes two trial points
-    the filter would not accept and ends with one it accepts against the stored reference: 111 instead of 167 iterations to the same optimum.
+    The part of the procedure the ordinary problems never reach: three times the minimum running time on a random track (a zero-cost journey: the
+    energy optimum is degenerate, the iteration crawls with shortened steps).  The procedure starts at IPOPT's own trigger, takes a trial point
+    the filter would not accept and ends with one it accepts against the stored reference: 79 instead of 139 iterations to the same optimum.
+    (Round 5: seed 86 -- rounds 3-4 used seed 92, whose path to the optimum changed with the last interval's elimination: ms_oracle.c, compute_direction.)
     """
     from oracle import oracle
     from test_gpu_parity import _random_problem      # (the generator only: no GPU call)
-    train, track, N, rng = _random_problem(92, tmp_path)
+    train, track, N, rng = _random_problem(86, tmp_path)
     v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
     pt = cases.oracle_problem(train, track, N, energyOptimal=False)
     rt = oracle.solve(pt, pt.scenario(3*track.length/train.velocityMax, 0.0, vN, v0), start='profile')
     assert rt['stats']['STATUS'] == 0
-    T = 4.0*float(rt['z'][-2])
+    T = 3.0*float(rt['z'][-2])
     res = {}
     for trig in (0, -1):
         pe = cases.oracle_problem(train, track, N, watchdogTrigger=trig)
@@ -106,6 +107,49 @@ def test_emulated_kernel_follows_the_oracle_through_the_watchdog(N, crop, T, tri
     assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
     assert int(st[0, ST['N_BACKTRACK']]) == int(ref['stats']['N_BACKTRACK'])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-7
+
+
+def _wd_family_case(family, trigger):
+    "(train, track, N, T, solver options, oracle problem, solve keywords): a solve of the family on which the oracle's watchdog starts with the lowered trigger"
+    from oracle.oracle import IP
+    import test_restoration
+    if family == 'time-optimal':      # the general static family (no structure compiled in): the time-optimal twin of the config-1 problem
+        N, T = 30, 3000.0
+        train, track, kw = cases.train_default(), cases.track_00(12000), {}
+        opts = dict(numIntervals=N, maxIterations=300, energyOptimal=False, integrationOptions=dict(numSteps=1, numApproxSteps=1))
+        prob = cases.oracle_problem(train, track, N, energyOptimal=False, losses='none', maxIterations=300, watchdogTrigger=trigger)
+    else:
+        N, T = (60, 310.0) if family == 'dynamic' else (30, 3000.0)
+        train, track, opts, prob, kw = test_restoration._family_case(family, N, 300)
+        prob.ip[IP['WATCHDOG_TRIGGER']] = trigger
+    return train, track, N, T, opts, prob, kw
+
+
+@pytest.mark.parametrize('family,trigger', [('time-optimal', 1), ('dynamic', 1), ('integrateLosses', 1), ('integrateLosses', 2)])
+def test_emulated_watchdog_in_the_other_kernel_families(family, trigger):
+    """
+    Round 5: IPOPT's watchdog procedure for every kernel family.  The LDS-resident kernels without the structure of the NLP compiled in -- the general
+    static family (here: a time-optimal problem), the dynamic loss table, integrateLosses -- are first-pass kernels: they count the shortened iterations and
+    hand the scenario to the streamed follow-up kernel of their family when the procedure is due (rounds 1-4: they only counted).  Kernel code on host
+    threads against the oracle: same number of procedures, same iteration count, same point.
+    """
+    from test_kernel_emulation import load_emulation
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    emu = load_emulation()
+    train, track, N, T, opts, prob, kw = _wd_family_case(family, trigger)
+    solver = casadiSolver(train, track, opts, startingPoint='profile', watchdogTrigger=trigger)
+    scen = solver._scenarios(T, 0, kw.get('terminalVelocity', 1), kw.get('initialVelocity', 1))
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    ref = oracle.solve(prob, prob.scenario(T, **kw), start='profile')
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert int(st[0, ST['N_WATCHDOG']]) == int(ref['stats']['N_WATCHDOG']) >= 1
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -164,3 +208,23 @@ def test_gpu_watchdog_starts_at_ipopts_trigger_on_loose_schedules_of_long_horizo
     assert st[:, oracle.ST['N_RESTO']].sum() >= 1 and res['stats'][:, ST['N_RESTO']].sum() >= 1
     assert np.max(np.abs(res['cost'] - st[:, oracle.ST['OBJ']])/np.abs(st[:, oracle.ST['OBJ']])) <= 1e-7
     assert np.max(np.abs(res['z'] - z)/np.maximum(1, np.abs(z))) < 1e-4
+
+
+@gpu
+@pytest.mark.parametrize('family,trigger', [('time-optimal', 1), ('dynamic', 1), ('integrateLosses', 1), ('integrateLosses', 2)])
+def test_gpu_watchdog_in_the_other_kernel_families(family, trigger):
+    "The same on the device: first-pass kernel (hand-over, reason 6) + streamed follow-up kernel of the family, against the oracle."
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    train, track, N, T, opts, prob, kw = _wd_family_case(family, trigger)
+    s = casadiSolver(train, track, opts, startingPoint='profile', watchdogTrigger=trigger)
+    res = s.solveBatch([T], **kw)
+    total, why = s.problem.follow_counts()
+    s.close()
+    ref = oracle.solve(prob, prob.scenario(T, **kw), start='profile')
+    assert res['status'][0] == int(ref['stats']['STATUS']) == 0
+    assert int(res['stats'][0, ST['N_WATCHDOG']]) == int(ref['stats']['N_WATCHDOG']) >= 1 and why[6] >= 1
+    assert abs(int(res['iterations'][0]) - int(ref['stats']['ITERS'])) <= 1
+    assert abs(res['stats'][0, ST['OBJ']] - ref['stats']['OBJ']) <= 1e-8*max(1.0, abs(ref['stats']['OBJ']))      # (the NLP's objective; `cost` is seconds for a time-optimal problem)
+    assert np.max(np.abs(res['z'][0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-5
