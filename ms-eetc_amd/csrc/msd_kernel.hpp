@@ -155,6 +155,14 @@ constexpr int CONST_DOUBLES = 96, UNI_OFF = 48;    /* LDS copies of the problem 
 constexpr int S_TB = 0, S_TW = 1, S_BB = 2, S_BW = 3, S_RT = 4, S_RB = 5;
 constexpr int S_HTT = 6, S_HBB = 7, S_HBQ = 8, S_HBF = 9, S_HBP = 10, S_HQQ = 11, S_HQF = 12, S_HFF = 13, S_HFP = 14, S_HPP = 15,
               S_HT = 18, S_HB = 19, S_HQ = 20, S_HF = 21, S_HP = 22;
+/* The two forces' own curvatures, Hff - Hfp and Hpp - Hfp, accumulated on their own (round 5).  Where both brakes are free and the acceleration
+ * row is active, its barrier term Sigma g g^T (1e12 at convergence) sits in Hff, Hfp and Hpp alike and the curvature of the split between the two
+ * forces -- 1e-4 in a time-optimal problem -- is lost in Hff - Hfp^2/Hpp: the second pivot of the control block came out as rounding noise of
+ * either sign, the inertia correction escalated (467 regularisations and the iteration limit on a re-solve of config 4 whose oracle solve takes 26
+ * iterations).  With a = S_OA, b = S_OB and G = H + F^T P F:  Gff - Gfp = a + (Tw Ptq + Bw Pbq) + Pqq,  Gpp - Gfp = b - (Tw Ptq + Bw Pbq),  and the
+ * pivot is  (Gff - Gfp) + (Gfp/Gpp)(Gpp - Gfp)  -- no difference of large numbers.  Written by assemble() / fused_pass; the sweeps read them before
+ * they stash the value function over them (S_PN) */
+constexpr int S_OA = 16, S_OB = 17;
 /* s-elimination data: ds = -(GS + GBS db + GFS df + GPS dp) IS; the last interval keeps its (unreduced) s row here and the
  * backward sweep leaves the feedback of s in 23..26 */
 constexpr int S_GFS = 23, S_IS = 24, S_GS = 25, S_GBS = 26 /* dynamic only */, S_GPS = 27 /* dynamic only */;
@@ -777,16 +785,18 @@ __device__ __forceinline__ bool last_interval(const double *s, const double Ptt,
 #ifndef MSD_LAST_SWAP
 #define MSD_LAST_SWAP 1      /* 0: always eliminate Fel (rounds 1-4; A/B builds) */
 #endif
-    const bool sw = MSD_LAST_SWAP && pn && Gpp < Gff;
+    const double oa = pn ? s[S_OA] : 0.0, ob = pn ? s[S_OB] : 0.0;      /* Gff - Gfp, Gpp - Gfp (the value function of stage N has no q entries) */
+    const bool sw = MSD_LAST_SWAP && pn && ob < oa;
     const double Gte = sw ? Gtp : Gtf, Gtk = sw ? Gtf : Gtp, Gbe = sw ? Gbp : Gbf, Gbk = sw ? Gbf : Gbp, Gqe = sw ? 0.0 : Gqf, Gqk = sw ? Gqf : 0.0;
     const double Gee = sw ? Gpp : Gff, Gkk = sw ? Gff : Gpp, Gek = Gfp, Ges = sw ? Gps : Gfs, Gks = sw ? Gfs : Gps, ge = sw ? gp : gf, gk = sw ? gf : gp;
     LG[0] = Gte; LG[1] = Gbe; LG[2] = Gqe; LG[3] = sw ? Gfp : Gff; LG[4] = sw ? Gpp : Gfp; LG[5] = Ges; LG[6] = ge;
     const double gee = ge + Gee*e0;
     /* reduced blocks over (t, b, q | k, s) */
-    double Hkk2 = Gkk - 2*Gek + Gee, Hks2 = Gks - Ges;
-    double Hkt = Gtk - Gte, Hkb = Gbk + Gek*eb - Gbe - Gee*eb, Hkq = Gqk - Gqe;
+    const double oe = sw ? ob : oa;      /* Gee - Gek */
+    double Hkk2 = oa + ob, Hks2 = Gks - Ges;
+    double Hkt = Gtk - Gte, Hkb = (Gbk - Gbe) - oe*eb, Hkq = Gqk - Gqe;
     const double Hsb = Ges*eb + Gbs;
-    double gk2 = gk + Gek*e0 - gee;
+    double gk2 = (gk - ge) - oe*e0;
     const double gs2 = gs + Ges*e0;
     const double Xtt = Gtt, Xtb = Gtb + Gte*eb, Xbb = Gbb + 2*eb*Gbe + eb*eb*Gee, Xbq = Gbq + eb*Gqe, Xqq = Gqq;
     const double xt = gt + Gte*e0, xb = gb + Gbe*e0 + eb*gee, xq = gq + Gqe*e0;
@@ -831,10 +841,10 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
     /* the last interval (last_interval) is peeled off the loop so that the loop body is branch free */
     {
         double *s = S + (N - 1)*S_STRIDE;
-        s[S_PN + 0] = Ptt; s[S_PN + 1] = 0; s[S_PN + 2] = 0; s[S_PN + 3] = 0; s[S_PN + 4] = 0; s[S_PN + 5] = 0;      /* value function of stage N, for the multipliers */
-        s[S_PV + 0] = pt; s[S_PV + 1] = 0; s[S_PV + 2] = 0;
         double Pn[6], pvn[3], K[8], KS[4], LG[7];
         if (!last_interval<DYN>(s, Ptt, pt, pn, Pn, pvn, K, KS, LG)) ok = false;
+        s[S_PN + 0] = Ptt; s[S_PN + 1] = 0; s[S_PN + 2] = 0; s[S_PN + 3] = 0; s[S_PN + 4] = 0; s[S_PN + 5] = 0;      /* value function of stage N, for the multipliers */
+        s[S_PV + 0] = pt; s[S_PV + 1] = 0; s[S_PV + 2] = 0;
         LGtf = LG[0]; LGbf = LG[1]; LGqf = LG[2]; LGff = LG[3]; LGfp = LG[4]; LGfs = LG[5]; Lgf = LG[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) s[S_K + k] = K[k];
@@ -849,6 +859,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
                      Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
         const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+        const double oa = s[S_OA], ob = s[S_OB];
         /* stash the value function of stage i+1 for the multipliers */
         s[S_PN + 0] = Ptt; s[S_PN + 1] = Ptb; s[S_PN + 2] = Ptq; s[S_PN + 3] = Pbb; s[S_PN + 4] = Pbq; s[S_PN + 5] = Pqq;
         s[S_PV + 0] = pt; s[S_PV + 1] = pb; s[S_PV + 2] = pq;
@@ -874,7 +885,7 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
         {
             /* s is already eliminated (assemble()): pivots of Guu in the order p, f */
             const double ip = 1.0/Gpp, lfp = Gfp*ip;
-            const double df_ = Gff - Gfp*lfp;
+            const double df_ = pn ? (oa + Mpq + Pqq) + lfp*(ob - Mpq) : Gff;      /* = Gff - Gfp^2/Gpp, from the own curvatures (S_OA) */
             if (!(Gpp > 0) || !(df_ > 0)) ok = false;
             const double iff = 1.0/df_;
             Kft = -(Gtf - lfp*Gtp)*iff; Kpt = -(Gtp + Gfp*Kft)*ip;
@@ -1268,10 +1279,14 @@ struct ParallelRiccati {
         const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW];
         const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
                      Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
-        double rff, rfp, rpp, det;
-        if (pn) { det = Hff*Hpp - Hfp*Hfp; const double id = 1.0/det; rff = Hpp*id; rfp = -Hfp*id; rpp = Hff*id; }
-        else { det = Hff; rff = 1.0/Hff; rfp = 0; rpp = 0; }
-        const double sf = rff + rfp, sp = rfp + rpp, sw = sf + sp;
+        double rff, rfp, rpp, det, sf, sp, sw;
+        if (pn) {
+            /* determinant and row sums of the inverse from the forces' own curvatures (S_OA, S_OB): no difference of large numbers */
+            const double oa = s[S_OA], ob = s[S_OB];
+            det = Hfp*(oa + ob) + oa*ob;
+            const double id = 1.0/det;
+            rff = Hpp*id; rfp = -Hfp*id; rpp = Hff*id; sf = ob*id; sp = oa*id; sw = (oa + ob)*id;
+        } else { det = Hff; rff = 1.0/Hff; rfp = 0; rpp = 0; sf = rff; sp = 0; sw = rff; }
         e.C[sy(0, 0)] = Tw*Tw*sw; e.C[sy(0, 1)] = Tw*Bw*sw; e.C[sy(1, 1)] = Bw*Bw*sw;
         e.C[sy(0, 2)] = Tw*sf; e.C[sy(1, 2)] = Bw*sf; e.C[sy(2, 2)] = rff;
         const double ub = sf*Hbf + sp*Hbp, uq = sf*Hqf, vb = rff*Hbf + rfp*Hbp;
@@ -1398,6 +1413,7 @@ struct ParallelRiccati {
                 const double Htt = s[S_HTT], Hbb = s[S_HBB], Hbq = s[S_HBQ], Hbf = s[S_HBF], Hbp = s[S_HBP], Hqq = s[S_HQQ], Hqf = s[S_HQF],
                              Hff = s[S_HFF], Hfp = s[S_HFP], Hpp = s[S_HPP];
                 const double ht = s[S_HT], hb = s[S_HB], hq = s[S_HQ], hf = s[S_HF], hp = s[S_HP];
+                const double oa = s[S_OA], ob = s[S_OB];
                 s[S_PN + 0] = Ptt; s[S_PN + 1] = Ptb; s[S_PN + 2] = Ptq; s[S_PN + 3] = Pbb; s[S_PN + 4] = Pbq; s[S_PN + 5] = Pqq;
                 const double Mbt = Tb*Ptt + Bb*Ptb, Mbb = Tb*Ptb + Bb*Pbb;
                 const double Mpt = Tw*Ptt + Bw*Ptb, Mpb = Tw*Ptb + Bw*Pbb, Mpq = Tw*Ptq + Bw*Pbq;
@@ -1409,7 +1425,7 @@ struct ParallelRiccati {
                 double Gpp = Hpp + Tw*Mpt + Bw*Mpb;
                 if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; }
                 const double ip = 1.0/Gpp, lfp = Gfp*ip;
-                const double df_ = Gff - Gfp*lfp;
+                const double df_ = pn ? (oa + Mpq + Pqq) + lfp*(ob - Mpq) : Gff;      /* = Gff - Gfp^2/Gpp, from the own curvatures (S_OA) */
                 if (!(Gpp > 0) || !(df_ > 0)) ok = false;
                 const double iff = 1.0/df_;
                 double Kft = -(Gtf - lfp*Gtp)*iff, Kpt = -(Gtp + Gfp*Kft)*ip;
@@ -2032,6 +2048,7 @@ struct Solver {
             double ht = 0, hb = 0, hq = 0, hf = 0, hp = 0, hs = 0;
             double nHbb = 0, nHbq = 0, nhb = 0;
             double Hbs = 0, Hps = 0, Eb = 0, Es = 0;     /* only the dynamic / integrated loss rows fill these */
+            double oa = 0, ob = 0;                       /* Hff - Hfp, Hpp - Hfp accumulated on their own (S_OA, S_OB) */
             /* MODE_RESTO with integrated loss rows: the rows' share in the running time d = t_{i+1} - t_i stays unfolded (the time row is relaxed there, so
              * d no longer obeys its linearisation): curvature W_xd over x = (b, f, p, s), W_dd, gradient h_d -- riccati_resto turns them into entries of
              * (t_i, t_{i+1}) */
@@ -2048,13 +2065,13 @@ struct Solver {
                 if (mode == MODE_RESTO) { of = op = os = oq = off = opp = 0; }      /* the restoration problem has no objective but the proximity term */
                 hf = of; hp = op; hs = os; hq = oq;
                 if (mode != MODE_LSQ) {
-                    Hff = off; Hpp = opp;
+                    Hff = off; Hpp = opp; oa = off; ob = opp;
                     if (energyOpt() && nd.i > 0) { Hqq = off; Hqf = -off; }
                     /* - lam_t hess(tau) - lam_b hess(b+) */
                     const double hbb = -(nd.lam[0]*e[j].tbb + nd.lam[1]*e[j].Bbb), hbw = -(nd.lam[0]*e[j].tbw + nd.lam[1]*e[j].Bbw),
                                  hww = -(nd.lam[0]*e[j].tww + nd.lam[1]*e[j].Bww);
                     Hbb += hbb; Hbf += hbw; Hff += hww;
-                    if (withPn()) { Hbp += hbw; Hfp += hww; Hpp += hww; }
+                    if (withPn()) { Hbp += hbw; Hfp += hww; Hpp += hww; } else oa += hww;
                     /* nu * hess(row) */
                     const double b = nd.x[VB];
                     if (rowOn(RPW0)) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
@@ -2070,6 +2087,8 @@ struct Solver {
                         Hbb += W*(L.bb + 2*tb*L.bd + tb*tb*L.dd);
                         Hbf += W*(L.bf + tb*L.fd + tw*L.bd + tb*tw*L.dd);
                         Hff += W*(L.ff + 2*tw*L.fd + tw*tw*L.dd);
+                        if (withPn()) { oa += W*((L.ff - L.fp) + tw*(L.fd - L.pd)); ob += W*((L.pp - L.fp) + tw*(L.pd - L.fd)); }
+                        else oa += W*(L.ff + 2*tw*L.fd + tw*tw*L.dd);
                         hb += W*rt*(L.bd + L.dd*tb); hf += W*rt*(L.fd + L.dd*tw);
                         if (withPn()) {
                             Hbp += W*(L.bp + tb*L.pd + tw*L.bd + tb*tw*L.dd);
@@ -2086,7 +2105,7 @@ struct Solver {
                             const int r = (k == 0) ? RLTR : RLRG;
                             const double w = -nd.nu[r]*U.rs[r];
                             const double gv = e[j].lg[k][1], gff = e[j].lg[k][2], gfv = e[j].lg[k][3], gvv = e[j].lg[k][4];
-                            Hff += w*gff; Hbf += w*gfv*vb; nHbq += w*gfv*vb1;
+                            Hff += w*gff; oa += w*gff; Hbf += w*gfv*vb; nHbq += w*gfv*vb1;
                             Hbb += w*(gvv*vb*vb + gv*vbb); nHbb += w*(gvv*vb1*vb1 + gv*vb1b1); Eb += w*gvv*vb*vb1;
                         }
                     }
@@ -2108,6 +2127,7 @@ struct Solver {
                     Hbb += Sg*gb[r]*gb[r]; Hbf += Sg*gb[r]*gf[r]; Hbp += Sg*gb[r]*gp[r];
                     Hff += Sg*gf[r]*gf[r]; Hfp += Sg*gf[r]*gp[r]; Hfs += Sg*gf[r]*gs[r];
                     Hpp += Sg*gp[r]*gp[r]; Hss += Sg*gs[r]*gs[r];
+                    oa += Sg*gf[r]*(gf[r] - gp[r]); ob += Sg*gp[r]*(gp[r] - gf[r]);      /* (the acceleration row: gf = gp, nothing of it in either) */
                     nHbq += Sg*gf[r]*gb1[r]; nHbb += Sg*gb1[r]*gb1[r];
                     if (DYN) { Hbs += Sg*gb[r]*gs[r]; Hps += Sg*gp[r]*gs[r]; Eb += Sg*gb[r]*gb1[r]; Es += Sg*gs[r]*gb1[r]; }
                 }
@@ -2129,6 +2149,7 @@ struct Solver {
                     else { Sv[k] = 1.0; gv[k] = -nd.zL[k] + nd.zU[k]; }
                 }
                 Htt += Sv[VT]; ht += gv[VT]; Hbb += Sv[VB]; hb += gv[VB]; Hff += Sv[VF]; hf += gv[VF]; Hpp += Sv[VP]; hp += gv[VP]; Hss += Sv[VS]; hs += gv[VS];
+                oa += Sv[VF]; ob += Sv[VP];
                 double *s = c.S + nd.i*S_STRIDE;
                 if (nd.ival()) {
                     s[S_TB] = e[j].tb; s[S_TW] = e[j].tw; s[S_BB] = e[j].Bb; s[S_BW] = e[j].Bw;
@@ -2155,6 +2176,7 @@ struct Solver {
                     if (!last && mode != MODE_RESTO) {
                         const double wf = Gfs*is;
                         Hff -= Gfs*wf; hf -= wf*gsv;
+                        oa -= (Gfs - Gps)*wf; ob -= Gps*(Gps - Gfs)*is;
                         if (DYN) {
                             const double wb = Gbs*is, wp = Gps*is;
                             Hbb -= Gbs*wb; Hbf -= Gfs*wb; Hbp -= Gps*wb; Hfp -= Gps*wf; Hpp -= Gps*wp;
@@ -2165,7 +2187,7 @@ struct Solver {
                     if (DYN) { s[S_GBS] = Gbs; s[S_GPS] = Gps; s[S_EB] = last ? 0.0 : Eb; s[S_ES] = last ? 0.0 : Es; }
                 }
                 s[S_HTT] = Htt; s[S_HBB] = Hbb; s[S_HBQ] = Hbq; s[S_HBF] = Hbf; s[S_HBP] = Hbp; s[S_HQQ] = Hqq; s[S_HQF] = Hqf;
-                s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HPP] = Hpp;
+                s[S_HFF] = Hff; s[S_HFP] = Hfp; s[S_HPP] = Hpp; s[S_OA] = oa; s[S_OB] = ob;
                 s[S_HT] = ht; s[S_HB] = hb; s[S_HQ] = hq; s[S_HF] = hf; s[S_HP] = hp;
             }
             /* the end-of-interval power row lives in the next stage's (b, q) block */
@@ -2616,7 +2638,7 @@ struct Solver {
             double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
             double a0[HV] = {0, 0, 0, 0, 0, 0}, a1[HV] = {0, 0, 0, 0, 0, 0};      /* t b q f p s */
             double nHbb = 0, nHbq = 0, nhb0 = 0, nhb1 = 0, out_q = 0, out_t1 = 0, out_b1 = 0, prod = 1.0;
-            double tb = 0, tw = 0, Bb = 0, Bw = 0, rt = 0, rb = 0;
+            double tb = 0, tw = 0, Bb = 0, Bw = 0, rt = 0, rb = 0, oa = 0;
 #pragma unroll
             for (int k = 0; k < NV; k++) gl[j][k] = 0;
 #pragma unroll
@@ -2702,6 +2724,8 @@ struct Solver {
                 Hbb += Sg[RPW0]*g.g0b*g.g0b + Sg[RACC]*g.g2b*g.g2b;
                 Hbf += Sg[RPW0]*g.g0b*g.g0f + Sg[RACC]*g.g2b*g.g2f;
                 if (withPn()) Hbp += Sg[RACC]*g.g2b*g.g2f;
+                /* own curvature of Fel (S_OA): everything in Hff that is not in Hfp as well -- with both brakes: all but the dynamics' and the acceleration row's */
+                oa = off + (Sg[RPW0]*g.g0f*g.g0f + Sg[RPW1]*g.g1f*g.g1f + Sg[RLTR]*g.g3f*g.g3f + Sg[RLRG]*g.g4f*g.g4f);
                 Hff += Sg[RPW0]*g.g0f*g.g0f + Sg[RPW1]*g.g1f*g.g1f + Sg[RACC]*g.g2f*g.g2f + Sg[RLTR]*g.g3f*g.g3f + Sg[RLRG]*g.g4f*g.g4f;
                 if (withPn()) { Hfp += Sg[RACC]*g.g2f*g.g2f; Hpp += Sg[RACC]*g.g2f*g.g2f; }
                 Hfs += Sg[RLTR]*g.g3f*g.g3s + Sg[RLRG]*g.g4f*g.g4s;
@@ -2740,11 +2764,13 @@ struct Solver {
                     /* the slack variable is eliminated here (pivot Hss), except in the last interval (assemble) */
                     const bool last = i == N - 1;
                     const double is = (Hss > 0) ? 1.0/Hss : NAN;
+                    oa += Sv[VF];
                     if (!last) {
                         const double wf = Hfs*is;
-                        Hff -= Hfs*wf; a0[3] -= wf*a0[5]; a1[3] -= wf*a1[5];
+                        Hff -= Hfs*wf; a0[3] -= wf*a0[5]; a1[3] -= wf*a1[5]; oa -= Hfs*wf;
                     }
                     sB[S_GFS] = Hfs; sB[S_IS] = is;
+                    if (withPn()) { sB[S_OA] = oa; sB[S_OB] = Sv[VP]; }      /* (own curvature of Fpb: its bounds) */
                 }
                 sB[S_HTT] = Htt; sB[S_HBF] = Hbf; sB[S_HBP] = Hbp; sB[S_HQQ] = Hqq; sB[S_HQF] = Hqf; sB[S_HFF] = Hff; sB[S_HFP] = Hfp; sB[S_HPP] = Hpp;
             }
@@ -3380,7 +3406,10 @@ struct Solver {
             const double E0 = total_err(E, 0.0);
             const double dual_u = E.dual/U.sf, compl_u = compl_err(E, 0.0)/U.sf;
             if (E0 <= P.tol && dual_u <= 1.0 && E.primal_u <= 1e-4 && compl_u <= 1e-4) { status = MSD_STATUS_SOLVED; break; }
-            if (E0 <= ACC_TOL && dual_u <= 1e10 && E.primal_u <= 1e-2 && compl_u <= 1e-2) { if (++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
+            /* (acc_now: the current point meets the acceptable tolerances -- where the line search then finds no step the solve ends with
+             *  Solved_To_Acceptable_Level, IPOPT's "Restoration phase called at acceptable point", instead of breaking down: below) */
+            const bool acc_now = E0 <= ACC_TOL && dual_u <= 1e10 && E.primal_u <= 1e-2 && compl_u <= 1e-2;
+            if (acc_now) { if (++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
             else acc_count = 0;
             if (iter >= P.maxIter) { status = MSD_STATUS_MAXITER; break; }
             if (!isfinite(E0)) { status = MSD_STATUS_NUMERIC; break; }
@@ -3443,6 +3472,7 @@ struct Solver {
                     if (alpha < amin) break;
                 }
                 if (general) { status = STATUS_GENERAL; why_general = 3; break; }
+                if (!accepted && acc_now) { status = MSD_STATUS_ACCEPTABLE; break; }      /* (no step from an acceptable point: IPOPT's ACCEPTABLE_POINT_REACHED) */
                 if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; why_general = 4; break; }      /* (the general iteration has the restoration phase) */
                 alpha_pr = alpha;
                 if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;      /* (shortened iterations: what starts the watchdog) */
@@ -3657,6 +3687,7 @@ struct Solver {
                 __syncthreads();
                 status = STATUS_WDSTOP; break;
             }
+            if (!accepted && acc_now) { status = MSD_STATUS_ACCEPTABLE; break; }      /* (no step from an acceptable point: IPOPT's ACCEPTABLE_POINT_REACHED; the oracle has the comment) */
             if (!accepted) {
                 /* the step became too small: feasibility restoration (IpBacktrackingLineSearch), unless the point is almost feasible
                  * (resto_failure_feasibility_threshold = 100 tol).  The current point enters the filter; the iterate and the scalars

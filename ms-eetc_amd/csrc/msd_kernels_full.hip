@@ -17,8 +17,13 @@ Geometry pick_geometry_full(int N)
     const int nodes = N + 1;
     const char *nf = getenv("MSD_NO_FULL");      /* MSD_NO_FULL=1: the general kernels (A/B runs) */
     if (nf && *nf == '1') return {0, 0, nullptr};
+#ifndef MSD_HOT_ONLY_64X2
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, 0, follow_kernel_full(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>};
+#endif
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, 0, follow_kernel_full(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>};     /* the benchmark geometry */
+#ifdef MSD_HOT_ONLY_64X2      /* tuning builds of the benchmark geometry alone (tools/build_hot.py: a fifth of the unit's compile time) */
+    return {0, 0, nullptr};
+#endif
     if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, RED_DOUBLES, follow_kernel_full(128, 2), solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>};
     /* longer horizons while the five additional exchange arrays still fit the LDS of a compute unit next to the stage blocks */
     const auto fits = [&](int ns) { return sizeof(double)*(size_t)lds_doubles(N, ns, false, XCH_FAST, RED_DOUBLES) <= 160*1024; };
