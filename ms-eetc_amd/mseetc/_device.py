@@ -210,8 +210,12 @@ class _ResultArrays():
     """
     Result arrays of the host-buffer entry points in page-locked memory: a device-to-host copy into them runs at the link's rate without
     staging or page faults.  A buffer is handed out again once no array or view of its previous use is alive (reference count of the
-    ctypes object every such array has as its base); otherwise a new one is allocated.
+    ctypes object every such array has as its base).  Up to POOL buffers per role are kept, so that a caller who still holds the results of
+    the previous call -- `r = solve_batch(...)` in a loop -- alternates between two buffers instead of page-locking a new one per call
+    (hipHostMalloc of the 34 MB of an 8192-scenario batch costs more than the copy it speeds up).
     """
+
+    POOL = 3
 
     def __init__(self):
         self._cache = {}
@@ -222,14 +226,20 @@ class _ResultArrays():
         count = int(np.prod(shape))
         if count == 0:
             return np.zeros(shape)
-        ent = self._cache.get(role)
-        if ent is not None and len(ent) == count and sys.getrefcount(ent) == 3:      # (the cache, `ent` and getrefcount's own argument: no array or view of the last use is alive)
-            carr = ent
-        else:
+        pool = self._cache.setdefault(role, [])
+        pool[:] = [e for e in pool if len(e) == count]      # (another batch size: the old buffers go)
+        carr = None
+        for k in range(len(pool)):
+            if sys.getrefcount(pool[k]) == 2:      # (the pool and getrefcount's own argument: no array or view of an earlier use is alive)
+                carr = pool[k]
+                break
+        if carr is None:
             buf = _Pinned(8*count)
             carr = (ctypes.c_double*count).from_address(buf.ptr.value)
             carr._owner = buf
-            self._cache[role] = carr
+            if len(pool) >= self.POOL:
+                pool.pop(0)      # (still referenced by the caller's arrays: freed when those go)
+            pool.append(carr)
         return np.frombuffer(carr, dtype=np.float64, count=count).reshape(shape)      # (every element is written by the copy that follows)
 
 
