@@ -161,7 +161,11 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     pl.max_grid = per_cu*cus;
     pl.max_grid2 = 0;
     pl.NT2 = geo.NT; pl.SPT2 = geo.SPT; pl.lds_bytes2 = lds;
+#ifdef MSD_FOLLOW_64X1
+    if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST && full) {      /* (diagnostic build: the one-brake family keeps its 64 x 1 follow-up kernel) */
+#else
     if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST) {
+#endif
         /* horizons of up to 63 intervals: the first pass runs one node per lane, the follow-up kernel is the two-nodes-per-lane one (its second node
          * slots stay idle).  The follow-up kernel restarts a scenario from its starting point, so nothing ties its geometry to the first pass's; and
          * the 64 x 1 instantiation of the one-brake follow-up kernel faults on the device (round 4: `solve_kernel<64, 1, 1, 0, false, false, 2, 2>`
@@ -452,6 +456,12 @@ static int launch(msd_handle h, int nscen, const double *d_scen, const double *d
         e0 = h->fp_beg[k]; e1 = h->fp_end[k];
         h->fp_count++;
     }
+#ifdef MSD_DEBUG_HOOKS      /* (diagnostic builds: the device buffers of a launch, to place the address of a memory fault) */
+    if (getenv("MSD_DEBUG_PTRS"))
+        fprintf(stderr, "[msd] launch nscen %d  work %p (+%zu B)  follow %p  queue %p  prof %p  scen %p  z %p  lam %p  stats %p  hist %p  NT %d SPT %d NT2 %d SPT2 %d lds %zu lds2 %zu grid caps %d %d %d\n",
+                nscen, (void *)h->d_work, sizeof(double)*h->cap_work, (void *)h->d_follow, (void *)queue, (void *)h->d_prof, (const void *)d_scen, (void *)d_z, (void *)d_lam, (void *)d_stats, (void *)d_hist,
+                h->NT, h->SPT, h->NT2, h->SPT2, h->lds_bytes, h->lds_bytes2, h->max_grid, h->max_grid_lsq, h->max_grid2);
+#endif
     return msd_host::launch_plan(plan_of(h), h->stream, h->d_work, h->d_follow, queue, nscen, d_scen, d_ovr, d_z, d_lam, d_stats, d_hist, hist_cap, ws, nullptr, e0, e1);
 }
 
