@@ -47,8 +47,8 @@ extern "C" {
  * Starting point of a solve.  REFERENCE: the reference's cold start (ocp.py:325-339: Fel 0.5, Fpb -0.1, s 1, t linear,
  * v 60 km/h).  PROFILE: a speed profile built from the limits, the running time and the end speeds with dynamically
  * consistent forces and zero constraint multipliers (msd_kernel.hpp: profile_start); it reaches the same optimum in about half the
- * iterations.  A scenario whose line search breaks down enters the feasibility restoration phase like in IPOPT (msd_resto.hpp; kernels
- * with static loss rows and Runge-Kutta shooting, N <= 511, unless no_restoration is set); one that still ends with a breakdown (any
+ * iterations.  A scenario whose line search breaks down enters the feasibility restoration phase like in IPOPT (msd_resto.hpp: every loss
+ * model, shooting integrator and horizon, in the follow-up kernel of the launch; unless no_restoration is set); one that still ends with a breakdown (any
  * failure but MSD_STATUS_INFEASIBLE and the iteration limit -- that one too when a restoration phase came before it) is solved again
  * from the other starting point inside the same launch.
  */
@@ -189,13 +189,14 @@ int msd_solve_batch_device_ex(msd_handle h, int nscen, const double *d_scen, con
 int msd_problem_geometry(msd_handle h, int *threads_per_scenario, int *nodes_per_thread);
 
 /*
- * Split solves (round 4).  The kernels of the benchmark family solve a batch in two launches on the handle's stream: a first pass that holds the
- * fused interior-point iteration alone, and a follow-up kernel (general iteration, restoration phase, second attempt) for the scenarios
- * the first pass hands over through a list in device memory -- in the reference all of that is inside the one call of IPOPT (ocp.py:359).
+ * Split solves.  Every family solves a batch in two launches on the handle's stream: a first pass (the kernels with the structure of the reference's
+ * rolling stock compiled in: the fused interior-point iteration alone; the others: the general iteration without its cold paths), and a follow-up
+ * kernel (general iteration, restoration phase, watchdog procedure, second attempt) for the scenarios the first pass hands over through a list in
+ * device memory -- in the reference all of that is inside the one call of IPOPT (ocp.py:359).
  * Telemetry, never reset: counts[0] scenarios handed over since the handle was created, counts[1 + why] by reason (0 no fused start for the
  * scenario, 1 wrong inertia or scan breakdown, 2 tiny step, 3 rejected first trial point with a second-order correction due, 4 line search
  * broke down, 5 breakdown that asks for the second attempt, 6 ten shortened iterations in a row: the watchdog procedure is due).  Waits for the
- * handle's stream.  n <= 8 entries are written (zeros for a handle whose kernels are not split).
+ * handle's stream.  n <= 8 entries are written.
  */
 int msd_problem_follow_counts(msd_handle h, int *counts, int n);
 
