@@ -603,6 +603,50 @@ def main():
     return 0
 
 
+def two_streams(device, k):
+    """
+    What the tail of a 1024-scenario launch costs (never the headline): config 1 on two handles -- two streams -- whose launches alternate without waiting
+    for each other, so that the workgroups of the next launch fill the SIMDs the previous one has left while its slowest scenarios finish (a launch of 1024
+    scenarios on 1024 SIMDs lasts 27-28 iterations, the scenarios take 20.6 on average).  Each handle solves its own batch (seed + 0 / + 1), resident in HBM.
+    """
+
+    import numpy as np
+    from mseetc._device import ST
+
+    B = PER_GPU_BATCH['c1']
+    sides = []
+    for r in range(2):
+        solver, scen, ov, text = build_workload('c1', B, 0, r, 'profile', device, 'rk')
+        pr = solver.problem
+        d_scen, d_z, d_st = pr.alloc(scen.nbytes), pr.alloc(8*pr.nz*B), pr.alloc(8*ST['COUNT']*B)
+        pr.to_device(d_scen, scen)
+        sides.append((solver, pr, d_scen, d_z, d_st))
+    for _ in range(2):
+        for solver, pr, d_scen, d_z, d_st in sides:
+            pr.solve_batch_device(B, d_scen, d_z, None, d_st)
+    for _, pr, *_r in sides:
+        pr.synchronize()
+    launches = 4*k
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        for solver, pr, d_scen, d_z, d_st in sides:
+            pr.solve_batch_device(B, d_scen, d_z, None, d_st)
+    for _, pr, *_r in sides:
+        pr.synchronize()
+    dt = time.perf_counter() - t0
+    ok = 0
+    for solver, pr, d_scen, d_z, d_st in sides:
+        st = np.zeros((B, ST['COUNT']))
+        pr.to_host(st, d_st)
+        ok += int(np.sum(st[:, ST['STATUS']] >= 0))
+        for d in (d_scen, d_z, d_st):
+            pr.free(d)
+        solver.close()
+    return {"solves_per_s": 2*B*launches/dt, "ms_per_pair_of_launches": 1e3*dt/launches, "launches_per_stream": launches, "converged": ok, "scenarios": 2*B,
+            "workload": "config 1 on two handles / two streams, launches of 1024 scenarios alternating without waiting for each other (wall clock over both streams): "
+                        "what the tail of a 1024-scenario launch costs; never the headline"}
+
+
 def alt_workloads(args, device):
     "The other workloads of SURVEY 8(d) at their per-GPU sizes, ten timed launches each after two warm-ups (N = 1 runs only)."
 
@@ -622,6 +666,7 @@ def alt_workloads(args, device):
         solver.close()
 
     one("reference_start", 'c1', PER_GPU_BATCH['c1'], start='reference', note=", cold start of ocp.py:325-339")
+    alt["c1_two_streams"] = two_streams(device, k)
     one("c1_batch8192", 'c1', 8192)
     one("c2", 'c2', PER_GPU_BATCH['c2'])
     one("c3", 'c3', PER_GPU_BATCH['c3'])
