@@ -26,6 +26,13 @@ int msd_problem_first_pass_ms(msd_handle h, float *mean_ms, int *launches);
 int msd_host_alloc(unsigned long long bytes, void **ptr);
 int msd_host_free(void *ptr);
 
+/*
+ * Test hook: the reciprocal and the square root / reciprocal square root of the fused interior-point iteration (csrc/msd_fastmath.hpp: v_rcp_f64 /
+ * v_rsq_f64 refined without the compiler's range scaling) evaluated on n operands, so that the GPU tests can bound their error against the IEEE
+ * operations (tests/test_gpu_parity.py::test_fast_reciprocal_and_square_root: <= 1 ulp on normal operands).  Errors: msd_interval_last_error().
+ */
+int msd_fastmath_probe(int device, int n, const double *x, double *rcp_out, double *sqrt_out, double *rsqrt_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,7 +298,7 @@ __device__ inline T irk_b(const DevProb &P, T b0, T w, double G, double ds, doub
  * control on the values; the derivatives are those of the accepted steps (the discrete map), carried in jet arithmetic.
  */
 template <class T>
-__device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds, T &tau, T &bplus)
+__device__ inline void dopri_tb_plain(const DevProb &P, T b0, T w, double G, double ds, T &tau, T &bplus)
 {
     constexpr double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
                      a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
@@ -307,7 +307,7 @@ __device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds
                      e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
     T yt = jconst(T(), 0.0), yb = b0;
     T kt[7], kb[7];
-    auto rhs = [&](const T &bj, T &ot, T &ob) { ot = xrecip(xsqrt(bj))*ds; ob = ode_b(P, bj, w, G, ds); };
+    auto rhs = [&](const T &bj, T &ot, T &ob) { ot = xrsqrt<MSD_FAST_MATH != 0>(bj)*ds; ob = ode_b<T, MSD_FAST_MATH != 0>(P, bj, w, G, ds); };      /* (msd_fastmath.hpp) */
     double sig = 0, h = 1.0;      /* the whole interval first (1.9 instead of 3.4 sets of stages per interval on the benchmark grid: a rejected first step lands on the right size) */
     rhs(yb, kt[0], kb[0]);
     for (int step = 0; step < 100000 && sig < 1.0; step++) {
@@ -333,7 +333,7 @@ __device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds
             sig += h;
             yt = nt; yb = nb; kt[0] = kt[6]; kb[0] = kb[6];     /* first same as last */
         }
-        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow_m02(err) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
         if (h < 1e-14) break;      /* the step control has collapsed (the state left the model's domain) */
     }
@@ -343,12 +343,85 @@ __device__ inline void dopri_tb(const DevProb &P, T b0, T w, double G, double ds
     tau = yt; bplus = yb;
 }
 
+/*
+ * The same with the values going first (round 5): the step-size controller sees values only, so a set of stages is first run in value arithmetic --
+ * a fifth of what it costs in jets -- and only an accepted step is run again with the jets (1.9 sets of stages per interval were jets before, one
+ * of them a rejected first step); the stage after an accepted step ("first same as last") is evaluated as a jet only when another step follows.
+ * The accepted steps, and with them the discrete map and its derivatives, are what dopri_tb_plain computes.
+ */
+#ifndef MSD_DOPRI_VALUES_FIRST
+#define MSD_DOPRI_VALUES_FIRST 1
+#endif
+__device__ inline void dopri_tb_jet(const DevProb &P, Jet b0, Jet w, double G, double ds, Jet &tau, Jet &bplus)
+{
+    constexpr double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                     a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                     a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                     b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                     e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+    constexpr bool FM = MSD_FAST_MATH != 0;
+    const double wv = w.v;
+    auto rhsv = [&](const double bj, double &ot, double &ob) { ot = xrsqrt<FM>(bj)*ds; ob = ode_b<double, FM>(P, bj, wv, G, ds); };
+    auto rhsj = [&](const Jet &bj, Jet &ot, Jet &ob) { ot = xrsqrt<FM>(bj)*ds; ob = ode_b<Jet, FM>(P, bj, w, G, ds); };
+    Jet yt = jconst(Jet(), 0.0), yb = b0;
+    Jet kt[6], kb[6];
+    double sig = 0, h = 1.0;
+    rhsj(yb, kt[0], kb[0]);
+    for (int step = 0; step < 100000 && sig < 1.0; step++) {
+        if (sig + h > 1.0) h = 1.0 - sig;
+        /* the step in values: error estimate, acceptance */
+        double vt[7], vb[7], sv;
+        const double ytv = yt.v, ybv = yb.v;
+        vt[0] = kt[0].v; vb[0] = kb[0].v;
+        sv = ybv + vb[0]*(h*a21); rhsv(sv, vt[1], vb[1]);
+        sv = (ybv + vb[0]*(h*a31)) + vb[1]*(h*a32); rhsv(sv, vt[2], vb[2]);
+        sv = ((ybv + vb[0]*(h*a41)) + vb[1]*(h*a42)) + vb[2]*(h*a43); rhsv(sv, vt[3], vb[3]);
+        sv = (((ybv + vb[0]*(h*a51)) + vb[1]*(h*a52)) + vb[2]*(h*a53)) + vb[3]*(h*a54); rhsv(sv, vt[4], vb[4]);
+        sv = ((((ybv + vb[0]*(h*a61)) + vb[1]*(h*a62)) + vb[2]*(h*a63)) + vb[3]*(h*a64)) + vb[4]*(h*a65); rhsv(sv, vt[5], vb[5]);
+        const double ntv = ((((ytv + vt[0]*(h*b1)) + vt[2]*(h*b3)) + vt[3]*(h*b4)) + vt[4]*(h*b5)) + vt[5]*(h*b6);
+        const double nbv = ((((ybv + vb[0]*(h*b1)) + vb[2]*(h*b3)) + vb[3]*(h*b4)) + vb[4]*(h*b5)) + vb[5]*(h*b6);
+        const bool finite = isfinite(ntv) && isfinite(nbv) && nbv > 0;
+        double err = 0;
+        if (finite) {
+            rhsv(nbv, vt[6], vb[6]);
+            const double sct = P.intAtol + P.intRtol*fmax(fabs(ytv), fabs(ntv)), scb = P.intAtol + P.intRtol*fmax(fabs(ybv), fabs(nbv));
+            const double et = h*(e1*vt[0] + e3*vt[2] + e4*vt[3] + e5*vt[4] + e6*vt[5] + e7*vt[6]);
+            const double eb = h*(e1*vb[0] + e3*vb[2] + e4*vb[3] + e5*vb[4] + e6*vb[5] + e7*vb[6]);
+            err = fmax(fabs(et/sct), fabs(eb/scb));
+        }
+        if (finite && err <= 1.0) {
+            /* accepted: the same stages as jets */
+            Jet s;
+            s = yb + kb[0]*(h*a21); rhsj(s, kt[1], kb[1]);
+            s = (yb + kb[0]*(h*a31)) + kb[1]*(h*a32); rhsj(s, kt[2], kb[2]);
+            s = ((yb + kb[0]*(h*a41)) + kb[1]*(h*a42)) + kb[2]*(h*a43); rhsj(s, kt[3], kb[3]);
+            s = (((yb + kb[0]*(h*a51)) + kb[1]*(h*a52)) + kb[2]*(h*a53)) + kb[3]*(h*a54); rhsj(s, kt[4], kb[4]);
+            s = ((((yb + kb[0]*(h*a61)) + kb[1]*(h*a62)) + kb[2]*(h*a63)) + kb[3]*(h*a64)) + kb[4]*(h*a65); rhsj(s, kt[5], kb[5]);
+            yt = ((((yt + kt[0]*(h*b1)) + kt[2]*(h*b3)) + kt[3]*(h*b4)) + kt[4]*(h*b5)) + kt[5]*(h*b6);
+            yb = ((((yb + kb[0]*(h*b1)) + kb[2]*(h*b3)) + kb[3]*(h*b4)) + kb[4]*(h*b5)) + kb[5]*(h*b6);
+            sig += h;
+            if (sig < 1.0) rhsj(yb, kt[0], kb[0]);     /* first same as last */
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow_m02(err) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-14) break;      /* the step control has collapsed (the state left the model's domain) */
+    }
+    if (!(sig >= 1.0)) { yt = jconst(Jet(), NAN); yb = jconst(Jet(), NAN); }
+    tau = yt; bplus = yb;
+}
+
+__device__ inline void dopri_tb(const DevProb &P, double b0, double w, double G, double ds, double &tau, double &bplus) { dopri_tb_plain<double>(P, b0, w, G, ds, tau, bplus); }
+__device__ inline void dopri_tb(const DevProb &P, Jet b0, Jet w, double G, double ds, Jet &tau, Jet &bplus)
+{
+    if (MSD_DOPRI_VALUES_FIRST) dopri_tb_jet(P, b0, w, G, ds, tau, bplus); else dopri_tb_plain<Jet>(P, b0, w, G, ds, tau, bplus);
+}
+
 /* one shooting interval with the integrator the problem names (P.integ: MSD_INTEGRATOR_ADAPTIVE or MSD_INTEGRATOR_COLLOCATION) */
 template <class T>
 __device__ inline void interval_map_general(const DevProb &P, double b0, double w0, double G, double ds, T &tau, T &bplus)
 {
     const T b = make_var(T(), b0, 0), w = make_var(T(), w0, 1);
-    if (P.integ == MSD_INTEGRATOR_ADAPTIVE) { dopri_tb<T>(P, b, w, G, ds, tau, bplus); return; }     /* train.py:314: time integrated along */
+    if (P.integ == MSD_INTEGRATOR_ADAPTIVE) { dopri_tb(P, b, w, G, ds, tau, bplus); return; }     /* train.py:314: time integrated along */
     if (P.numApprox == 0) {
         T t = jconst(T(), 0.0);
         bplus = irk_b<T>(P, b, w, G, ds, 1.0, &t);

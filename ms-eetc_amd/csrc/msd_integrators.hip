@@ -21,6 +21,8 @@
 #include <string>
 
 #include "../../include/mseetc_hip.h"
+#include "../../include/mseetc_aux.h"
+#include "msd_fastmath.hpp"
 
 namespace {
 
@@ -294,6 +296,17 @@ __global__ void colloc_kernel(IvTrain T, Colloc K, int n, const double *t0, cons
     if (status) status[k] = st;
 }
 
+/* the fused iteration's reciprocal and square root on a list of operands (msd_fastmath_probe: the GPU tests bound their error in ulps) */
+__global__ void fastmath_kernel(int n, const double *x, double *rc, double *sq, double *rs)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double r;
+    rc[k] = msd::frcp(x[k]);
+    sq[k] = msd::fsqrt2(x[k], r);
+    rs[k] = r;
+}
+
 thread_local std::string g_iv_err;
 int iv_fail(int code, const std::string &m) { g_iv_err = m; return code; }
 
@@ -358,6 +371,23 @@ int msd_interval_integrate(int device, int n, const double *train5, int method, 
 #undef IV_TRY
     cleanup();
     return MSD_OK;
+}
+
+int msd_fastmath_probe(int device, int n, const double *x, double *rcp_out, double *sqrt_out, double *rsqrt_out)
+{
+    if (n < 1 || !x || !rcp_out || !sqrt_out || !rsqrt_out) return iv_fail(MSD_E_INVALID, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return iv_fail(MSD_E_NODEVICE, "no such device");
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(double)*4*(size_t)n) != hipSuccess) return iv_fail(MSD_E_HIP, "hipMalloc");
+    hipError_t e = hipMemcpy(d, x, sizeof(double)*n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fastmath_kernel, dim3((n + 255)/256), dim3(256), 0, 0, n, d, d + n, d + 2*(size_t)n, d + 3*(size_t)n);
+        e = hipGetLastError();
+    }
+    double *out[3] = {rcp_out, sqrt_out, rsqrt_out};
+    for (int a = 0; a < 3 && e == hipSuccess; a++) e = hipMemcpy(out[a], d + (size_t)(a + 1)*n, sizeof(double)*n, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? MSD_OK : iv_fail(MSD_E_HIP, hipGetErrorString(e));
 }
 
 }  // extern "C"

@@ -39,6 +39,7 @@
 #include <math.h>
 
 #include "../../include/mseetc_hip.h"
+#include "msd_fastmath.hpp"
 #include "msd_scan.hpp"
 
 /* build-time tuning switches (defaults = what measured fastest on MI355X) */
@@ -205,28 +206,43 @@ __device__ __forceinline__ Jet chain(Jet a, double F, double f1, double f2)
 {
     return {F, f1*a.g0, f1*a.g1, f1*a.h00 + f2*a.g0*a.g0, f1*a.h01 + f2*a.g0*a.g1, f1*a.h11 + f2*a.g1*a.g1};
 }
-/* sqrt as a jet: the value is the IEEE square root -- the same number the value-only evaluation of a trial point computes (xsqrt(double)), so
- * that the residual a Newton step is built on and the constraint violation the line search measures at the same point agree to the last bit --
- * and the two derivative factors 1/(2 sqrt(v)) = r/2, -1/(4 v sqrt(v)) = -r^3/4 come from one reciprocal square root (they only shape the
- * Newton direction) */
+/* sqrt as a jet: the value is the same number the value-only evaluation of a trial point computes (xsqrt(double)), so that the residual a Newton
+ * step is built on and the constraint violation the line search measures at the same point agree to the last bit -- and the two derivative
+ * factors 1/(2 sqrt(v)) = r/2, -1/(4 v sqrt(v)) = -r^3/4 come from one reciprocal square root (accurate to an ulp: they scale the Jacobian the
+ * dual residual is formed with) */
 #ifdef MSD_HOST_EMULATION
 __device__ __forceinline__ double rsqrt_(double v) { return 1.0/sqrt(v); }
 #else
 __device__ __forceinline__ double rsqrt_(double v) { return rsqrt(v); }
 #endif
-__device__ __forceinline__ Jet xsqrt(Jet a) { const double r = rsqrt_(a.v), f1 = 0.5*r; return chain(a, sqrt(a.v), f1, -0.5*f1*(r*r)); }
-__device__ __forceinline__ Jet xrecip(Jet a) { double r = 1.0/a.v; return chain(a, r, -r*r, 2*r*r*r); }
-__device__ __forceinline__ double xsqrt(double a) { return sqrt(a); }
-__device__ __forceinline__ double xrecip(double a) { return 1.0/a; }
+template <bool FM = false> __device__ __forceinline__ Jet xsqrt(Jet a)
+{
+    if constexpr (FM) { double r; const double s = fsqrt2(a.v, r), f1 = 0.5*r; return chain(a, s, f1, -0.5*f1*(r*r)); }
+    else { const double r = rsqrt_(a.v), f1 = 0.5*r; return chain(a, sqrt(a.v), f1, -0.5*f1*(r*r)); }
+}
+template <bool FM = false> __device__ __forceinline__ Jet xrecip(Jet a) { const double r = FM ? frcp(a.v) : 1.0/a.v; return chain(a, r, -r*r, 2*r*r*r); }
+template <bool FM = false> __device__ __forceinline__ double xsqrt(double a) { return FM ? fsqrt(a) : sqrt(a); }
+template <bool FM = false> __device__ __forceinline__ double xrecip(double a) { return FM ? frcp(a) : 1.0/a; }
+/* 1/sqrt: the integrand of the time equation (shooting integrators of msd_integ.hpp).  FM: from the square root's own refinement */
+template <bool FM = false> __device__ __forceinline__ double xrsqrt(double a)
+{
+    if constexpr (FM) { double r; fsqrt2(a, r); return r; }
+    else return 1.0/sqrt(a);
+}
+template <bool FM = false> __device__ __forceinline__ Jet xrsqrt(Jet a)
+{
+    if constexpr (FM) { const double r = xrsqrt<true>(a.v), r2 = r*r, f1 = -0.5*r*r2; return chain(a, r, f1, -1.5*f1*r2); }
+    else return xrecip(xsqrt(a));
+}
 __device__ __forceinline__ Jet make_var(Jet, double v, int k) { return {v, k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, 0, 0, 0}; }
 __device__ __forceinline__ double make_var(double, double v, int) { return v; }
 __device__ __forceinline__ Jet make_zero(Jet) { return {0, 0, 0, 0, 0, 0}; }
 __device__ __forceinline__ double make_zero(double) { return 0.0; }
 
 /* d(b)/d(sigma) on the unit interval (train.py:251-259) */
-template <class T> __device__ __forceinline__ T ode_b(const DevProb &P, T b, T w, double G, double ds)
+template <class T, bool FM = false> __device__ __forceinline__ T ode_b(const DevProb &P, T b, T w, double G, double ds)
 {
-    T rr = P.sr0 + (xsqrt(b)*P.sr1 + b*P.sr2);
+    T rr = P.sr0 + (xsqrt<FM>(b)*P.sr1 + b*P.sr2);
     return ((w - rr) - G)*(2*ds);
 }
 
@@ -245,17 +261,17 @@ template <class T> __device__ __forceinline__ T rk4_b(const DevProb &P, T b, T w
 }
 
 /* one shooting interval: tau = t+ - t and b+ (train.py:296-301 joint RK4, :324-344 trapezoidal time) */
-template <class T> __device__ __forceinline__ void interval_map(const DevProb &P, double b0, double w0, double G, double ds, T &tau, T &bplus)
+template <class T, bool FM = false> __device__ __forceinline__ void interval_map(const DevProb &P, double b0, double w0, double G, double ds, T &tau, T &bplus)
 {
     T b = make_var(T(), b0, 0), w = make_var(T(), w0, 1);
     if (P.numApprox == 1 && P.numSteps == 1) {
         /* the integrator of simulations/config.json (one RK4 step, one trapezoid: every BASELINE config), straight-line */
-        T k1 = ode_b(P, b, w, G, ds);
-        T k2 = ode_b(P, b + k1*0.5, w, G, ds);
-        T k3 = ode_b(P, b + k2*0.5, w, G, ds);
-        T k4 = ode_b(P, b + k3*1.0, w, G, ds);
+        T k1 = ode_b<T, FM>(P, b, w, G, ds);
+        T k2 = ode_b<T, FM>(P, b + k1*0.5, w, G, ds);
+        T k3 = ode_b<T, FM>(P, b + k2*0.5, w, G, ds);
+        T k4 = ode_b<T, FM>(P, b + k3*1.0, w, G, ds);
         T cur = b + ((k1 + k2*2.0) + (k3*2.0 + k4))*(1.0/6);
-        tau = xrecip(xsqrt(b) + xsqrt(cur))*(2*ds*(1.0 - 0.0));
+        tau = xrecip<FM>(xsqrt<FM>(b) + xsqrt<FM>(cur))*(2*ds*(1.0 - 0.0));
         bplus = cur;
         return;
     }
@@ -419,6 +435,9 @@ struct Ctx {
     }
 };
 enum { PH_EVAL = 0, PH_KKT, PH_ASSEMBLE, PH_RICCATI, PH_READBACK, PH_GPHID, PH_STEPLEN, PH_MERIT, PH_UPDATE, PH_OTHER, PH_COUNT };
+/* sub-phases of the stage-parallel KKT solve (ParallelRiccati::solve; what is left under PH_RICCATI is its roll-out): they share the slots of the
+ * three phases the fused iteration does not have, and misc[12..14] */
+enum { PH_R_ELEM = PH_EVAL, PH_R_SCAN_P = PH_READBACK, PH_R_RECUR = PH_STEPLEN, PH_R_SCAN_G = 10, PH_R_FEED = 11, PH_R_SCAN_X = 12, PH_SLOTS = 13 };
 
 struct OpMax { __device__ double operator()(double a, double b) const { return fmax(a, b); } __device__ static double identity() { return -INFINITY; } };
 struct OpMin { __device__ double operator()(double a, double b) const { return fmin(a, b); } __device__ static double identity() { return INFINITY; } };
@@ -1284,9 +1303,9 @@ struct ParallelRiccati {
             /* determinant and row sums of the inverse from the forces' own curvatures (S_OA, S_OB): no difference of large numbers */
             const double oa = s[S_OA], ob = s[S_OB];
             det = Hfp*(oa + ob) + oa*ob;
-            const double id = 1.0/det;
+            const double id = frcp(det);
             rff = Hpp*id; rfp = -Hfp*id; rpp = Hff*id; sf = ob*id; sp = oa*id; sw = (oa + ob)*id;
-        } else { det = Hff; rff = 1.0/Hff; rfp = 0; rpp = 0; sf = rff; sp = 0; sw = rff; }
+        } else { det = Hff; rff = frcp(Hff); rfp = 0; rpp = 0; sf = rff; sp = 0; sw = rff; }
         e.C[sy(0, 0)] = Tw*Tw*sw; e.C[sy(0, 1)] = Tw*Bw*sw; e.C[sy(1, 1)] = Bw*Bw*sw;
         e.C[sy(0, 2)] = Tw*sf; e.C[sy(1, 2)] = Bw*sf; e.C[sy(2, 2)] = rff;
         const double ub = sf*Hbf + sp*Hbp, uq = sf*Hqf, vb = rff*Hbf + rfp*Hbp;
@@ -1305,7 +1324,11 @@ struct ParallelRiccati {
         return isfinite(a[0] + a[1] + a[2] + a[3] + a[4] + a[5]);
     }
 
+#if MSD_TELEMETRY      /* (tuning builds: the sub-phase marks below need the caller's cycle mark) */
+    __device__ static MSD_PARALLEL_ATTR int solve(const int N, const bool pn, Ctx &c)
+#else
     __device__ static MSD_PARALLEL_ATTR int solve(const int N, const bool pn, Ctx c)
+#endif
     {
         double *S = c.S;
         bool ok = true, bad = false;
@@ -1349,6 +1372,7 @@ struct ParallelRiccati {
                 have = true;
             }
         }
+        c.mark(PH_R_ELEM);
         /* ---- 2: suffix scan over the lanes of the wave, then over the waves ---- */
 #pragma unroll 1
         for (int d = 1; d < 64; d <<= 1) {
@@ -1398,6 +1422,7 @@ struct ParallelRiccati {
         }
         if (cnt > 0 && !finite6(Pe)) bad = true;
 
+        c.mark(PH_R_SCAN_P);
         /* ---- 3: ordinary recursion over the own stages (matrix part), chunk map of the value-function gradient ---- */
         double gam[SPT][3], gf0[SPT], gp0[SPT], lfpv[SPT], iffv[SPT], ipv[SPT], Gfpv[SPT];
         Aff bmap;
@@ -1424,10 +1449,10 @@ struct ParallelRiccati {
                 double Gff = Hff + Tw*Mft + Bw*Mfb + Mfq, Gfp = Hfp + Tw*Mpt + Bw*Mpb + Mpq;
                 double Gpp = Hpp + Tw*Mpt + Bw*Mpb;
                 if (!pn) { Gtp = 0; Gbp = 0; Gfp = 0; Gpp = 1; }
-                const double ip = 1.0/Gpp, lfp = Gfp*ip;
+                const double ip = frcp(Gpp), lfp = Gfp*ip;
                 const double df_ = pn ? (oa + Mpq + Pqq) + lfp*(ob - Mpq) : Gff;      /* = Gff - Gfp^2/Gpp, from the own curvatures (S_OA) */
                 if (!(Gpp > 0) || !(df_ > 0)) ok = false;
-                const double iff = 1.0/df_;
+                const double iff = frcp(df_);
                 double Kft = -(Gtf - lfp*Gtp)*iff, Kpt = -(Gtp + Gfp*Kft)*ip;
                 double Kfb = -(Gbf - lfp*Gbp)*iff, Kpb = -(Gbp + Gfp*Kfb)*ip;
                 double Kfq = -(Gqf)*iff,           Kpq = -(Gfp*Kfq)*ip;
@@ -1467,6 +1492,7 @@ struct ParallelRiccati {
             if (uni(v[0]) != 0.0) return 0;
         }
 
+        c.mark(PH_R_RECUR);
         /* ---- 4: suffix scan of the gradient maps ---- */
 #pragma unroll 1
         for (int d = 1; d < 64; d <<= 1) {
@@ -1504,6 +1530,7 @@ struct ParallelRiccati {
         wave_fetch<3>(ps, pe, c.lane + 1);
         if (c.lane == 63) { pe[0] = pb[0]; pe[1] = pb[1]; pe[2] = pb[2]; }
 
+        c.mark(PH_R_SCAN_G);
         /* ---- 5: feed-forward of the own stages, closed-loop chunk map ---- */
         Aff fmap;
         aff_identity(fmap);
@@ -1535,6 +1562,7 @@ struct ParallelRiccati {
                 aff_compose(fmap, st, fmap);
             }
         }
+        c.mark(PH_R_FEED);
         /* ---- 6: prefix scan of the closed-loop maps ---- */
 #pragma unroll 1
         for (int d = 1; d < 64; d <<= 1) {
@@ -1574,6 +1602,7 @@ struct ParallelRiccati {
         wave_fetch<3>(xe, xs, c.lane - 1);
         if (c.lane == 0) { xs[0] = xb[0]; xs[1] = xb[1]; xs[2] = xb[2]; }
 
+        c.mark(PH_R_SCAN_X);
         /* ---- 7: roll-out of the own stages; the owner of stage N-2 continues through the last interval ---- */
         {
             double dt = xs[0], db = xs[1], dq = xs[2];
@@ -2599,7 +2628,7 @@ struct Solver {
     {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < SPT; j++) { const int i = n[j].i; c.xt[i] = x[j][VT]; c.xb[i] = x[j][VB]; c.xs[i] = sqrt(x[j][VB]); c.xf[i] = x[j][VF]; }
+        for (int j = 0; j < SPT; j++) { const int i = n[j].i; c.xt[i] = x[j][VT]; c.xb[i] = x[j][VB]; c.xs[i] = fsqrt(x[j][VB]); c.xf[i] = x[j][VF]; }
         __syncthreads();
     }
 
@@ -2648,10 +2677,10 @@ struct Solver {
                 const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
                 const double q = (i > 0) ? c.xf[i - 1] : 0.0;
                 Jet tau, bp;
-                interval_map<Jet>(P, b, f + p, nd.G, nd.ds, tau, bp);
+                interval_map<Jet, true>(P, b, f + p, nd.G, nd.ds, tau, bp);
                 const double cv0 = t1 - (t + tau.v), cv1 = b1 - bp.v;
                 tb = tau.g0; tw = tau.g1; Bb = bp.g0; Bw = bp.g1; rt = -cv0; rb = -cv1;
-                const double isb = 1.0/sb, isb1 = 1.0/sb1;
+                const double isb = frcp(sb), isb1 = frcp(sb1);
                 const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
                 /* rows d(x), scaled (eval_interval) */
                 double dv[NR];
@@ -2674,7 +2703,7 @@ struct Solver {
                 prim = fmax(prim, fmax(nd.sct*fabs(cv0), nd.scb*fabs(cv1)));
                 prim_u = fmax(prim_u, fmax(fabs(cv0), fabs(cv1)));
                 if (MERIT) th += nd.sct*fabs(cv0) + nd.scb*fabs(cv1);
-                sumlam += fabs(l0)/nd.sct + fabs(l1)/nd.scb; if (MERIT) nlam += 2;
+                sumlam += fabs(l0)*frcp(nd.sct) + fabs(l1)*frcp(nd.scb); if (MERIT) nlam += 2;
                 /* Hessian of the Lagrangian: objective, dynamics, power and acceleration rows (assemble) */
                 a0[2] = oq; a0[3] = of; a0[5] = os;
                 Hff = off;
@@ -2702,12 +2731,12 @@ struct Solver {
                     sumlam += fabs(nd.nu[r]); if (MERIT) nlam += 1;
                     double gsl = -nd.nu[r], S_, g1_;
                     {
-                        const double sl = nd.sg[r] - U.dL[r], z = nd.zLs[r], ri = 1.0/sl, cp = sl*z;
+                        const double sl = nd.sg[r] - U.dL[r], z = nd.zLs[r], ri = frcp(sl), cp = sl*z;
                         gsl -= z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= sl;
                         S_ = z*ri; g1_ = -ri;
                     }
                     if (r <= RACC) {
-                        const double su = U.dU[r] - nd.sg[r], z = nd.zUs[r], ri = 1.0/su, cp = su*z;
+                        const double su = U.dU[r] - nd.sg[r], z = nd.zUs[r], ri = frcp(su), cp = su*z;
                         gsl += z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= su;
                         S_ += z*ri; g1_ += ri;
                     } else { g1_ += K_D; if (MERIT) damp += nd.sg[r] - U.dL[r]; }
@@ -2740,12 +2769,12 @@ struct Solver {
                     Sv[k] = 0; g1v[k] = 0;
                     if ((k == VP && !withPn()) || !nd.on(k)) continue;
                     {
-                        const double sl = nd.x[k] - lbv(k), z = nd.zL[k], ri = 1.0/sl, cp = sl*z;
+                        const double sl = nd.x[k] - lbv(k), z = nd.zL[k], ri = frcp(sl), cp = sl*z;
                         gl[j][k] -= z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= sl;
                         Sv[k] = z*ri; g1v[k] = -ri;
                     }
                     if (hasU(k)) {
-                        const double su = ubv(j, k) - nd.x[k], z = nd.zU[k], ri = 1.0/su, cp = su*z;
+                        const double su = ubv(j, k) - nd.x[k], z = nd.zU[k], ri = frcp(su), cp = su*z;
                         gl[j][k] += z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= su;
                         Sv[k] += z*ri; g1v[k] += ri;
                     } else { g1v[k] += K_D; if (MERIT) damp += nd.x[k] - lbv(k); }
@@ -2763,7 +2792,7 @@ struct Solver {
                     sB[S_TB] = tb; sB[S_TW] = tw; sB[S_BB] = Bb; sB[S_BW] = Bw; sB[S_RT] = rt; sB[S_RB] = rb;
                     /* the slack variable is eliminated here (pivot Hss), except in the last interval (assemble) */
                     const bool last = i == N - 1;
-                    const double is = (Hss > 0) ? 1.0/Hss : NAN;
+                    const double is = (Hss > 0) ? frcp(Hss) : NAN;
                     oa += Sv[VF];
                     if (!last) {
                         const double wf = Hfs*is;
@@ -2865,7 +2894,7 @@ struct Solver {
                 og[VF] = sc*nd.ds; og[VS] = sc*nd.ds;
                 if (i > 0) og[VF] += sc*2e-3*(f - q);
                 if (i + 1 < N) og[VF] += c.o5[i + 1];       /* d(obj)/dq of the next interval (fused_pass left it there) */
-                const double isb = 1.0/sb, isb1 = 1.0/sb1;
+                const double isb = frcp(sb), isb1 = frcp(sb1);
                 const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
                 const double db1 = c.S[(i + 1)*S_STRIDE + S_DB];
                 nd.dsg[RPW0] = c.o1[i] + (g.g0b*d.dx[VB] + g.g0f*d.dx[VF]);      /* (residuals: fused_pass left them in the exchange arrays) */
@@ -2880,12 +2909,12 @@ struct Solver {
                 const double dk = d.dx[k];
                 double gp;
                 {
-                    const double s = nd.x[k] - lbv(k), z = nd.zL[k], w = 1.0/(s*z), r = z*w, iz = s*w;
+                    const double s = nd.x[k] - lbv(k), z = nd.zL[k], w = frcp(s*z), r = z*w, iz = s*w;
                     gp = -mu_*r; rp = fmax(rp, -dk*r);
                     rd = fmax(rd, -(r*(mu_ - z*dk) - z)*iz);
                 }
                 if (hasU(k)) {
-                    const double s = ubv(j, k) - nd.x[k], z = nd.zU[k], w = 1.0/(s*z), r = z*w, iz = s*w;
+                    const double s = ubv(j, k) - nd.x[k], z = nd.zU[k], w = frcp(s*z), r = z*w, iz = s*w;
                     gp += mu_*r; rp = fmax(rp, dk*r);
                     rd = fmax(rd, -(r*(mu_ + z*dk) - z)*iz);
                 } else gp += K_D*mu_;
@@ -2898,12 +2927,12 @@ struct Solver {
                     const double dk = nd.dsg[r_];
                     double gp;
                     {
-                        const double s = nd.sg[r_] - U.dL[r_], z = nd.zLs[r_], w = 1.0/(s*z), r = z*w, iz = s*w;
+                        const double s = nd.sg[r_] - U.dL[r_], z = nd.zLs[r_], w = frcp(s*z), r = z*w, iz = s*w;
                         gp = -mu_*r; rp = fmax(rp, -dk*r);
                         rd = fmax(rd, -(r*(mu_ - z*dk) - z)*iz);
                     }
                     if (r_ <= RACC) {
-                        const double s = U.dU[r_] - nd.sg[r_], z = nd.zUs[r_], w = 1.0/(s*z), r = z*w, iz = s*w;
+                        const double s = U.dU[r_] - nd.sg[r_], z = nd.zUs[r_], w = frcp(s*z), r = z*w, iz = s*w;
                         gp += mu_*r; rp = fmax(rp, dk*r);
                         rd = fmax(rd, -(r*(mu_ + z*dk) - z)*iz);
                     } else gp += K_D*mu_;
@@ -2946,7 +2975,7 @@ struct Solver {
                 const double t = xt[j][VT], b = xt[j][VB], f = xt[j][VF], p = withPn() ? xt[j][VP] : 0.0, s = xt[j][VS];
                 const double t1 = c.xt[i + 1], b1 = c.xb[i + 1], sb = c.xs[i], sb1 = c.xs[i + 1];
                 double tau, bp;
-                interval_map<double>(P, b, f + p, nd.G, nd.ds, tau, bp);
+                interval_map<double, true>(P, b, f + p, nd.G, nd.ds, tau, bp);
                 th += nd.sct*fabs(t1 - (t + tau)) + nd.scb*fabs(b1 - bp);
                 double dv[NR];
                 dv[RPW0] = U.rs[RPW0]*f*sb; dv[RPW1] = U.rs[RPW1]*f*sb1;
@@ -2997,13 +3026,13 @@ struct Solver {
                 if ((k == VP && !withPn()) || !nd.on(k)) continue;
                 const double dk = dd.dx[k], xo = nd.x[k], xn = step_to(xo, apr, dk);
                 {
-                    const double s = xo - lbv(k), z = nd.zL[k], r = 1.0/s;
+                    const double s = xo - lbv(k), z = nd.zL[k], r = frcp(s);
                     const double zn = z + adu*(r*(mu_ - z*dk) - z), cn = zn*(xn - lbv(k));
                     clamp |= !(cn <= hi && cn >= lo);
                     nd.zL[k] = zn;
                 }
                 if (hasU(k)) {
-                    const double s = ubv(j, k) - xo, z = nd.zU[k], r = 1.0/s;
+                    const double s = ubv(j, k) - xo, z = nd.zU[k], r = frcp(s);
                     const double zn = z + adu*(r*(mu_ + z*dk) - z), cn = zn*(ubv(j, k) - xn);
                     clamp |= !(cn <= hi && cn >= lo);
                     nd.zU[k] = zn;
@@ -3016,14 +3045,14 @@ struct Solver {
                     const double dk = nd.dsg[r_], so = nd.sg[r_], sn_ = step_to(so, apr, dk);
                     double Sg, gphi;
                     {
-                        const double s = so - U.dL[r_], z = nd.zLs[r_], r = 1.0/s;
+                        const double s = so - U.dL[r_], z = nd.zLs[r_], r = frcp(s);
                         Sg = z*r; gphi = -mu_*r;
                         const double zn = z + adu*(r*(mu_ - z*dk) - z), cn = zn*(sn_ - U.dL[r_]);
                         clamp |= !(cn <= hi && cn >= lo);
                         nd.zLs[r_] = zn;
                     }
                     if (r_ <= RACC) {
-                        const double s = U.dU[r_] - so, z = nd.zUs[r_], r = 1.0/s;
+                        const double s = U.dU[r_] - so, z = nd.zUs[r_], r = frcp(s);
                         Sg += z*r; gphi += mu_*r;
                         const double zn = z + adu*(r*(mu_ + z*dk) - z), cn = zn*(U.dU[r_] - sn_);
                         clamp |= !(cn <= hi && cn >= lo);
@@ -3129,7 +3158,7 @@ struct Solver {
         const double kp = ext ? P.warmPush : K_PUSH;
         const double mu_start = ext ? P.warmMu : K_MU_INIT;
         const unsigned long long cyc0 = __builtin_readcyclecounter();
-        if (c.tid == 0) { c.misc[1] = 0.0; c.misc[MISC_FALLBACKS] = 0.0; for (int k = 0; k < PH_COUNT; k++) c.misc[2 + k] = 0.0; }
+        if (c.tid == 0) { c.misc[1] = 0.0; c.misc[MISC_FALLBACKS] = 0.0; for (int k = 0; k < PH_SLOTS; k++) c.misc[2 + k] = 0.0; }
         c.tmark = cyc0;
         const double t0 = scen[MSD_SC_T0], tEnd = scen[MSD_SC_TEND], v0sq = scen[MSD_SC_V0SQ], vNsq = scen[MSD_SC_VNSQ];
 
@@ -3796,7 +3825,7 @@ struct Solver {
             stats[MSD_ST_N_REG] = n_reg; stats[MSD_ST_N_SOC] = n_soc; stats[MSD_ST_N_BACKTRACK] = n_back; stats[MSD_ST_N_RESTO] = n_resto; stats[MSD_ST_N_WATCHDOG] = n_wd;
             stats[MSD_ST_CYC_TOTAL] = (double)(__builtin_readcyclecounter() - cyc0); stats[MSD_ST_CYC_KKT] = c.misc[1]; stats[MSD_ST_N_FALLBACK] = c.misc[MISC_FALLBACKS];
             /* phase telemetry of the logged scenario: the last two rows of the history buffer */
-            if (hist && hist_cap >= 4) for (int k = 0; k < PH_COUNT; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
+            if (hist && hist_cap >= 4) for (int k = 0; k < PH_SLOTS; k++) hist[HIST_COLS*(hist_cap - 2) + k] = c.misc[2 + k];
         }
         __syncthreads();
         iters_out = iter;

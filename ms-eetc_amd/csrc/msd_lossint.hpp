@@ -92,7 +92,7 @@ __device__ inline T loss_distance(const DevProb &P, double v0, double dt0, doubl
             sig += h;
             yv = nv; yx = nx; kv[0] = kv[6]; kx[0] = kx[6];     /* first same as last */
         }
-        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow_m02(err) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
         if (h < 1e-14) break;      /* the step control has collapsed */
     }

@@ -40,7 +40,7 @@ __device__ __forceinline__ double inv3(const double (&m)[3][3], double (&r)[3][3
 {
     const double c00 = m[1][1]*m[2][2] - m[1][2]*m[2][1], c10 = m[1][2]*m[2][0] - m[1][0]*m[2][2], c20 = m[1][0]*m[2][1] - m[1][1]*m[2][0];
     const double det = m[0][0]*c00 + m[0][1]*c10 + m[0][2]*c20;
-    const double id = 1.0/det;
+    const double id = frcp(det);
     r[0][0] = c00*id; r[1][0] = c10*id; r[2][0] = c20*id;
     r[0][1] = (m[0][2]*m[2][1] - m[0][1]*m[2][2])*id; r[1][1] = (m[0][0]*m[2][2] - m[0][2]*m[2][0])*id; r[2][1] = (m[0][1]*m[2][0] - m[0][0]*m[2][1])*id;
     r[0][2] = (m[0][1]*m[1][2] - m[0][2]*m[1][1])*id; r[1][2] = (m[0][2]*m[1][0] - m[0][0]*m[1][2])*id; r[2][2] = (m[0][0]*m[1][1] - m[0][1]*m[1][0])*id;

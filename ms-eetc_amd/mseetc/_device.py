@@ -123,6 +123,7 @@ def lib():
         L.msd_integrate_losses.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, ctypes.c_int,
                                            _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr]
 
+        L.msd_fastmath_probe.argtypes = [ctypes.c_int, ctypes.c_int] + [_dptr]*4
         L.msd_host_alloc.argtypes = [ctypes.c_ulonglong, ctypes.POINTER(vp)]
         L.msd_host_free.argtypes = [vp]
         L.msd_mpc_create.argtypes = [vp, vp, ctypes.POINTER(MpcPlan), ctypes.POINTER(vp)]
@@ -459,6 +460,16 @@ def interval_integrate(model, method, params, time, velocitySquared, ds, force, 
         raise DeviceError("msd integrator error {}: {}".format(rc, msg))
 
     return {'time': t, 'velSquared': b, 'status': st}
+
+
+def fastmath_probe(x, device=0):
+    """frcp, fsqrt and the reciprocal square root of csrc/msd_fastmath.hpp on the operands x (test hook: msd_fastmath_probe)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = [np.empty_like(x) for _ in range(3)]
+    if L.msd_fastmath_probe(int(device), x.size, _d(x), *[_d(a) for a in out]) != 0:
+        raise DeviceError(L.msd_interval_last_error().decode())
+    return out
 
 
 def _check_post(rc):

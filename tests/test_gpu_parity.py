@@ -311,6 +311,31 @@ def test_randomized_problems_vs_oracle(seed, tmp_path):
     s.close(); fast.close()
 
 
+def test_fast_reciprocal_and_square_root():
+    """
+    The fused iteration's reciprocal and square root (csrc/msd_fastmath.hpp: v_rcp_f64 / v_rsq_f64 + refinement, without the compiler's range
+    scaling and special-case fix-up) against the correctly rounded results in extended precision: at most one ulp on operands of the iteration's
+    range (slacks from 1e-13, multipliers to 1e13, squared speeds), the square root at most half an ulp off the rounded one.  The reciprocal
+    square root scales the Jacobian of every interval: at 2^-45 -- one refinement step less -- a short-horizon re-solve of config 4 stalled at a
+    dual residual of 1e-6 (test_config4_full_size_warm_and_cold).
+    """
+    from mseetc._device import fastmath_probe
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10.0**rng.uniform(-13, 13, 200000), rng.uniform(0.5, 2.0, 100000), rng.uniform(1.0, 7000.0, 100000),
+                        [1.0, 2.0, 4.0, 0.25, 3.0, 1e-300, 1e300, np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0)]])
+    rc, sq, rs = fastmath_probe(x)
+    xl = x.astype(np.longdouble)
+    def ulps(got, exact):
+        return np.abs((got.astype(np.longdouble) - exact)/np.spacing(np.asarray(exact, dtype=np.float64)).astype(np.longdouble)).astype(np.float64)
+    e_rc, e_sq, e_rs = ulps(rc, 1/xl), ulps(sq, np.sqrt(xl)), ulps(rs, 1/np.sqrt(xl))
+    assert e_rc.max() <= 1.0 and e_sq.max() <= 1.0 and e_rs.max() <= 1.5, (e_rc.max(), e_sq.max(), e_rs.max())
+    assert (rc == 1.0/x).mean() > 0.9 and (sq == np.sqrt(x)).mean() > 0.99      # (mostly the rounded result itself)
+    # what the callers' finiteness / positivity tests rely on
+    rc0, sq0, rs0 = fastmath_probe(np.array([0.0, -1.0, np.inf, np.nan]))
+    assert not np.isfinite(rc0[0]) and rc0[1] == -1.0 and not np.isfinite(rc0[3])
+    assert not (sq0[1] >= 0) and not np.isfinite(sq0[3])
+
+
 @pytest.mark.parametrize('seed,factor', [(176, 2.0), (22, 3.0), (35, 3.0)])
 def test_degenerate_zero_cost_journeys_vs_oracle(seed, factor, tmp_path):
     """

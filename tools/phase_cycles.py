@@ -17,9 +17,9 @@ import ctypes
 L = _device.lib(); h = solver.problem._h
 L.msd_set_history(h, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 64)
 out = solver.problem.solve_batch(scen)
-names = ['EVAL','KKT','ASSEMBLE','RICCATI','READBACK','GPHID','STEPLEN','MERIT','UPDATE','OTHER']
-ph = np.concatenate([raw[62], raw[63]])[:10]
+names = ['EVAL / R:elements','KKT','ASSEMBLE','RICCATI (roll-out)','READBACK / R:scan P','GPHID','STEPLEN / R:recursion','MERIT','UPDATE','OTHER','R:scan grad','R:feed-forward','R:scan state']
+ph = np.concatenate([raw[62], raw[63]])[:13]
 st = out['stats'][0]
 print("geometry", os.environ.get('MSD_GEOMETRY'), "kernel_ms", out['kernel_ms'], "iters", st[1], "cycles total", st[11])
 for nme, v in zip(names, ph):
-    print(f"  {nme:9s} {v/1e3:10.0f} kcycles  {100*v/st[11]:5.1f}%   per iter {v/max(st[1],1)/1e3:8.1f} kcyc")
+    print(f"  {nme:22s} {v/1e3:10.0f} kcycles  {100*v/st[11]:5.1f}%   per iter {v/max(st[1],1)/1e3:8.1f} kcyc")
