@@ -25,4 +25,7 @@ done
 cd $repo
 python3 tools/make_traffic_json.py $out > $out/hbm_traffic.json 2> $out/hbm_traffic.err
 python3 tools/summarize_profiles.py $out > $out/summary.txt 2>&1
+# the bench line once more with the traffic just measured on this build next to it (roofline.traffic, valu_issue)
+cp $out/hbm_traffic.json $repo/profiles/hbm_traffic.json
+python3 bench.py --no-build > $out/bench_with_traffic.json 2> $out/bench_with_traffic.err
 cat $out/summary.txt
