@@ -127,7 +127,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
                          && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
     msd::Geometry geo = (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
                         : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
-    size_t lds = geo.fn ? sizeof(double)*(size_t)msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) : 0;
+    size_t lds = geo.fn ? sizeof(double)*(size_t)(msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) + msd::coop_doubles(geo.NT, gen) + geo.extra) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
         geo = (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)

@@ -18,6 +18,7 @@ struct Geometry {
     int red = RED_DOUBLES;
     KernelFn fn2 = nullptr;              /* not null: `fn` is the first pass of a split solve (solve_kernel's PART = 1) and this the follow-up kernel (PART = 2) */
     KernelFn fn_lsq = nullptr;           /* first pass with the least-squares multiplier estimate in front (PART = 3): launches from the reference's starting point or a primal-only warm start */
+    int extra = 0;                       /* doubles of LDS behind the layout of lds_doubles (the SLDS instantiations' node constants) */
 };
 
 Geometry pick_geometry_static(int N, int full);     /* full: FULL_BOTH / FULL_RG -- the kernels with that structure compiled in (0: none) */

@@ -410,6 +410,98 @@ __device__ inline void dopri_tb_jet(const DevProb &P, Jet b0, Jet w, double G, d
     tau = yt; bplus = yb;
 }
 
+/*
+ * The pieces of dopri_tb_jet for the cooperative evaluation of Solver::evaluate_current (round 5).  On the benchmark grid two intervals of a horizon
+ * -- the first and the last, at 1 m/s -- take 25 ... 28 accepted steps where the others take one or two, and the lanes of their waves wait while one
+ * lane runs 26 sets of stages in jets.  The steps themselves are sequential, their derivatives are not: with the values at the step boundaries known
+ * from the value pass, the local second-order jet of every step (seeded at its own starting value) can be evaluated by another lane, and the owner
+ * composes the local jets by the chain rule.
+ *   DopriValues: the controller in value arithmetic, one attempt per call (same arithmetic as the value stages of dopri_tb_jet / dopri_tb_plain<double>)
+ *   dopri_step_jet: one step of size h in jets from the state yb; returns b+ and the step's share of the running time
+ *   jet_after: chain rule for a local jet phi(b, w) behind the running jet B(b0, w)
+ */
+struct DopriValues {
+    double sig, h, yt, yb, kt0, kb0;
+    __device__ inline void start(const DevProb &P, double b0, double wv, double G, double ds)
+    {
+        sig = 0; h = 1.0; yt = 0; yb = b0;
+        kt0 = xrsqrt<MSD_FAST_MATH != 0>(b0)*ds; kb0 = ode_b<double, MSD_FAST_MATH != 0>(P, b0, wv, G, ds);
+    }
+    __device__ inline bool finished() const { return sig >= 1.0; }
+    /* one attempt: 1 accepted (h_used, y_before describe the step), 0 rejected, -1 the step control has collapsed */
+    __device__ inline int attempt(const DevProb &P, double wv, double G, double ds, double &h_used, double &y_before)
+    {
+        constexpr double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                         a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                         a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                         b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84,
+                         e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+        constexpr bool FM = MSD_FAST_MATH != 0;
+        auto rhsv = [&](const double bj, double &ot, double &ob) { ot = xrsqrt<FM>(bj)*ds; ob = ode_b<double, FM>(P, bj, wv, G, ds); };
+        if (sig + h > 1.0) h = 1.0 - sig;
+        double vt[7], vb[7], sv;
+        vt[0] = kt0; vb[0] = kb0;
+        sv = yb + vb[0]*(h*a21); rhsv(sv, vt[1], vb[1]);
+        sv = (yb + vb[0]*(h*a31)) + vb[1]*(h*a32); rhsv(sv, vt[2], vb[2]);
+        sv = ((yb + vb[0]*(h*a41)) + vb[1]*(h*a42)) + vb[2]*(h*a43); rhsv(sv, vt[3], vb[3]);
+        sv = (((yb + vb[0]*(h*a51)) + vb[1]*(h*a52)) + vb[2]*(h*a53)) + vb[3]*(h*a54); rhsv(sv, vt[4], vb[4]);
+        sv = ((((yb + vb[0]*(h*a61)) + vb[1]*(h*a62)) + vb[2]*(h*a63)) + vb[3]*(h*a64)) + vb[4]*(h*a65); rhsv(sv, vt[5], vb[5]);
+        const double ntv = ((((yt + vt[0]*(h*b1)) + vt[2]*(h*b3)) + vt[3]*(h*b4)) + vt[4]*(h*b5)) + vt[5]*(h*b6);
+        const double nbv = ((((yb + vb[0]*(h*b1)) + vb[2]*(h*b3)) + vb[3]*(h*b4)) + vb[4]*(h*b5)) + vb[5]*(h*b6);
+        const bool finite = isfinite(ntv) && isfinite(nbv) && nbv > 0;
+        double err = 0;
+        if (finite) {
+            rhsv(nbv, vt[6], vb[6]);
+            const double sct = P.intAtol + P.intRtol*fmax(fabs(yt), fabs(ntv)), scb = P.intAtol + P.intRtol*fmax(fabs(yb), fabs(nbv));
+            const double et = h*(e1*vt[0] + e3*vt[2] + e4*vt[3] + e5*vt[4] + e6*vt[5] + e7*vt[6]);
+            const double eb = h*(e1*vb[0] + e3*vb[2] + e4*vb[3] + e5*vb[4] + e6*vb[5] + e7*vb[6]);
+            err = fmax(fabs(et/sct), fabs(eb/scb));
+        }
+        int rc = 0;
+        if (finite && err <= 1.0) {
+            h_used = h; y_before = yb;
+            sig += h; yt = ntv; yb = nbv; kt0 = vt[6]; kb0 = vb[6];     /* first same as last */
+            rc = 1;
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow_m02(err) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-14 && !finished()) rc = -1;
+        return rc;
+    }
+};
+
+__device__ inline void dopri_step_jet(const DevProb &P, Jet &yb, Jet &dtau, const Jet w, double G, double ds, double h)
+{
+    constexpr double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9,
+                     a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729,
+                     a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656,
+                     b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84;
+    constexpr bool FM = MSD_FAST_MATH != 0;
+    auto rhsj = [&](const Jet &bj, Jet &ot, Jet &ob) { ot = xrsqrt<FM>(bj)*ds; ob = ode_b<Jet, FM>(P, bj, w, G, ds); };
+    Jet kt[6], kb[6], s;
+    rhsj(yb, kt[0], kb[0]);
+    s = yb + kb[0]*(h*a21); rhsj(s, kt[1], kb[1]);
+    s = (yb + kb[0]*(h*a31)) + kb[1]*(h*a32); rhsj(s, kt[2], kb[2]);
+    s = ((yb + kb[0]*(h*a41)) + kb[1]*(h*a42)) + kb[2]*(h*a43); rhsj(s, kt[3], kb[3]);
+    s = (((yb + kb[0]*(h*a51)) + kb[1]*(h*a52)) + kb[2]*(h*a53)) + kb[3]*(h*a54); rhsj(s, kt[4], kb[4]);
+    s = ((((yb + kb[0]*(h*a61)) + kb[1]*(h*a62)) + kb[2]*(h*a63)) + kb[3]*(h*a64)) + kb[4]*(h*a65); rhsj(s, kt[5], kb[5]);
+    dtau = ((((kt[0]*(h*b1)) + kt[2]*(h*b3)) + kt[3]*(h*b4)) + kt[4]*(h*b5)) + kt[5]*(h*b6);
+    yb = ((((yb + kb[0]*(h*b1)) + kb[2]*(h*b3)) + kb[3]*(h*b4)) + kb[4]*(h*b5)) + kb[5]*(h*b6);
+}
+
+/* phi(b, w) behind B(b0, w): value, gradient and Hessian of phi(B(b0, w), w) in (b0, w) */
+__device__ inline Jet jet_after(const Jet &phi, const Jet &B)
+{
+    Jet r;
+    r.v = phi.v;
+    r.g0 = phi.g0*B.g0;
+    r.g1 = phi.g0*B.g1 + phi.g1;
+    r.h00 = phi.h00*B.g0*B.g0 + phi.g0*B.h00;
+    r.h01 = phi.h00*B.g0*B.g1 + phi.h01*B.g0 + phi.g0*B.h01;
+    r.h11 = phi.h00*B.g1*B.g1 + 2*phi.h01*B.g1 + phi.h11 + phi.g0*B.h11;
+    return r;
+}
+
 __device__ inline void dopri_tb(const DevProb &P, double b0, double w, double G, double ds, double &tau, double &bplus) { dopri_tb_plain<double>(P, b0, w, G, ds, tau, bplus); }
 __device__ inline void dopri_tb(const DevProb &P, Jet b0, Jet w, double G, double ds, Jet &tau, Jet &bplus)
 {

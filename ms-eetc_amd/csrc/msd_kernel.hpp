@@ -173,6 +173,15 @@ constexpr int S_DT = 6, S_DB = 7, S_DF = 8, S_DP = 9, S_DS = 10, S_LT = 11, S_LB
 /* dynamic loss model only: couplings of (b_i, s_i) with b_{i+1}; never overwritten by the sweeps */
 constexpr int S_EB = 28, S_ES = 29;
 
+/* cooperative evaluation of the adaptive shooting integrator (Solver::coop_adaptive): per wave a header (accepted steps, force, resistance, interval
+ * length of the long interval), its step sizes and step-start values (64 each) and the 64 x 12 components of the steps' local jets.  Behind everything
+ * else in the LDS of the kernels of the shooting-integrator families whose horizon is LDS-resident */
+#ifndef MSD_COOP_ADAPTIVE
+#define MSD_COOP_ADAPTIVE 1
+#endif
+constexpr int COOP_CAP = 64, COOP_HDR = 8, COOP_POOL = COOP_HDR + 2*COOP_CAP + 12*COOP_CAP;
+__host__ __device__ __forceinline__ int coop_doubles(int NT, bool gen) { return (MSD_COOP_ADAPTIVE && gen && NT <= 128) ? (NT/64)*COOP_POOL : 0; }
+
 /* LDS of the streamed kernel: filter, reduction scratch, misc, uniform records */
 __host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96; }
 
@@ -180,6 +189,15 @@ __host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*1
  * problem structure compiled in (Solver::FAST) publishes sqrt(b) too and sends seven contributions in one pass */
 constexpr int XCH_GENERAL = 6, XCH_FAST = 11;
 constexpr int RED_DOUBLES = RED_SLOTS*MAX_WAVES*RED_K;      /* cross-wave reduction scratch; a single-wave FAST kernel has none */
+/* SLDS (template parameter of the fused kernels, round 5): the five per-node constants (interval length, track resistance, scaling of the two dynamics
+ * rows, upper bound of b) in LDS behind everything else; every pass loads the ones it needs instead of carrying them through the solve -- 16 spilled
+ * registers and 48 B of scratch per lane less, 83.2 k -> 81.8 k cycles per iteration on config 1.  The pickers choose these instantiations where the
+ * 5 NS doubles do not cost a resident workgroup (Geometry::extra; 64 x 2: up to 103 intervals, four workgroups per CU either way).  The slack steps kept
+ * in the exchange arrays between post_direction and update_fast the same way bought nothing and are not */
+#ifndef MSD_STATIC_LDS
+#define MSD_STATIC_LDS 1
+#endif
+constexpr int STATIC_FIELDS = 5;
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NS, bool dyn, int nxch = XCH_GENERAL, int red = RED_DOUBLES)
 {
     return stage_stride(dyn)*(N + 1) + nxch*NS + 2*FILT_CAP + red + 32 + CONST_DOUBLES;
@@ -421,6 +439,8 @@ __device__ __forceinline__ double track_resistance(const DevProb &P, double grad
 struct Ctx {
     double *S, *xt, *xb, *xf, *o1, *o2, *o3, *filt, *red, *misc;
     double *xs, *o4, *o5, *o6, *o7;      /* FAST kernels only: sqrt(b) of the published point, four more outgoing contributions */
+    double *st;                          /* MSD_STATIC_LDS: the nodes' constants */
+    double *pool;                        /* shooting-integrator kernels: COOP_POOL doubles per wave (coop_adaptive) */
     int tid, lane, wave, nw, nt, red_slot;
     unsigned long long tmark;
     /* telemetry (tuning builds, -DMSD_TELEMETRY=1: tools/phase_cycles.py): thread 0 accumulates the shader cycles spent since the previous
@@ -693,12 +713,13 @@ struct Ev {
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
 template <bool DERIV, int DYN, bool GEN, int FULL>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
-                                              double (&cv)[2], double (&dv)[NR], Ev &e)
+                                              double (&cv)[2], double (&dv)[NR], Ev &e, const Jet *ptau = nullptr, const Jet *pbp = nullptr)
 {
     const double b = x[VB], f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
-        if (GEN) interval_map_general<Jet>(P, b, f + p, nG, nds, tau, bp); else interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
+        if (ptau) { tau = *ptau; bp = *pbp; }      /* (the interval map evaluated by the lanes of the wave together: Solver::coop_adaptive) */
+        else if (GEN) interval_map_general<Jet>(P, b, f + p, nG, nds, tau, bp); else interval_map<Jet>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau.v); cv[1] = b1 - bp.v;
         e.tb = tau.g0; e.tw = tau.g1; e.tbb = tau.h00; e.tbw = tau.h01; e.tww = tau.h11;
         e.Bb = bp.g0; e.Bw = bp.g1; e.Bbb = bp.h00; e.Bbw = bp.h01; e.Bww = bp.h11;
@@ -1649,7 +1670,7 @@ enum { MODE_NEWTON = 0, MODE_LSQ = 1, MODE_RESTO = 2 };      /* (MODE_RESTO: New
 
 /* PART: which part of a solve the enclosing kernel holds (solve_kernel) -- 0 everything, 1 the first pass (no restoration phase), 2 the follow-up,
  * 3 the first pass with the least-squares multiplier estimate in front (any starting point) */
-template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL, int PART = 0>
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL, int PART = 0, bool SLDS = false>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -2482,9 +2503,94 @@ struct Solver {
     }
 
     /* evaluate the current point with derivatives; residuals of the Newton system into resc/resd */
+    /*
+     * The interval maps of the adaptive shooting integrator with their jets, evaluated by the lanes of a wave together (msd_integ.hpp: DopriValues,
+     * dopri_step_jet, jet_after).  Every lane runs the step-size controller on values; an interval that is through after two accepted steps (all but
+     * the first and the last of a journey from and to standstill) replays them in jets itself.  The lowest lane with a longer interval -- the owner --
+     * finishes its value pass, leaves step sizes and step-start values in the wave's pool, lane k evaluates the local jet of step k, and the owner
+     * composes them by the chain rule: 26 steps cost one set of jet stages plus 26 small compositions instead of 26 sets.  A second long interval in
+     * the same wave, or one with more than COOP_CAP steps, is evaluated the sequential way (dopri_tb_jet).  Values (tau, b+) are the value pass's: the
+     * numbers the value-only evaluation of a trial point computes.  Uniform control flow: every thread of the workgroup calls it.
+     */
+    static constexpr bool COOP = GEN && !STREAM && SPT == 1 && MSD_COOP_ADAPTIVE && NT <= 128;      /* (one node per lane: the benchmark geometries of these families) */
+    __device__ __forceinline__ void coop_adaptive(Jet (&ptau)[SPT], Jet (&pbp)[SPT])
+    {
+        double *pool = c.pool + c.wave*COOP_POOL;
+        double *rec_h = pool + COOP_HDR, *rec_y = rec_h + COOP_CAP, *out = rec_y + COOP_CAP;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const NodeT &nd = n[j];
+            const bool act = nd.ival();
+            const double b0 = nd.x[VB], wv = nd.x[VF] + (withPn() ? nd.x[VP] : 0.0), G = nd.G, ds = nd.ds;
+            DopriValues s;
+            double rh[2] = {0, 0}, ry[2] = {0, 0};
+            int na = 0, state = act ? 0 : 1, tries = 0;      /* state: 0 under way, 1 at the end of the interval, -1 the step control collapsed */
+            if (act) s.start(P, b0, wv, G, ds);
+            while (state == 0 && na < 2) {
+                double h, y;
+                const int rc = s.attempt(P, wv, G, ds, h, y);
+                if (rc == 1) { rh[na] = h; ry[na] = y; na++; if (s.finished()) state = 1; }
+                else if (rc < 0 || ++tries >= 100000) state = -1;
+            }
+            const bool lng = act && state == 0;
+            const int owner = (int)wave_reduce(lng ? (double)c.lane : 64.0, OpMin());
+            if (c.lane == owner) {
+                pool[1] = wv; pool[2] = G; pool[3] = ds;
+                rec_h[0] = rh[0]; rec_y[0] = ry[0]; rec_h[1] = rh[1]; rec_y[1] = ry[1];
+                int k = 2;
+                while (state == 0) {
+                    double h, y;
+                    const int rc = s.attempt(P, wv, G, ds, h, y);
+                    if (rc == 1) { if (k < COOP_CAP) { rec_h[k] = h; rec_y[k] = y; } k++; if (s.finished()) state = 1; }
+                    else if (rc < 0 || ++tries >= 100000) state = -1;
+                }
+                pool[0] = (state == 1 && k <= COOP_CAP) ? (double)k : -1.0;
+            }
+            __syncthreads();
+            const int nL = owner < 64 ? (int)pool[0] : 0;      /* steps of the owner's interval to be shared out (0: none) */
+            Jet tau = {NAN, NAN, NAN, NAN, NAN, NAN}, bp = tau;
+            if (act && !lng) {
+                if (state == 1) {
+                    Jet yb = make_var(Jet(), b0, 0), T = make_zero(Jet());
+                    const Jet w = make_var(Jet(), wv, 1);
+                    for (int k = 0; k < na; k++) { Jet d; dopri_step_jet(P, yb, d, w, G, ds, rh[k]); T = T + d; }
+                    tau = T; bp = yb; tau.v = s.yt; bp.v = s.yb;
+                }
+            } else if (lng && !(c.lane == owner && nL > 0)) {
+                dopri_tb_jet(P, make_var(Jet(), b0, 0), make_var(Jet(), wv, 1), G, ds, tau, bp);
+            }
+            if (nL > 0 && c.lane < nL) {
+                Jet yb = make_var(Jet(), rec_y[c.lane], 0), d;
+                const Jet w = make_var(Jet(), pool[1], 1);
+                dopri_step_jet(P, yb, d, w, pool[2], pool[3], rec_h[c.lane]);
+                double *o = out + 12*c.lane;
+                o[0] = yb.v; o[1] = yb.g0; o[2] = yb.g1; o[3] = yb.h00; o[4] = yb.h01; o[5] = yb.h11;
+                o[6] = d.v; o[7] = d.g0; o[8] = d.g1; o[9] = d.h00; o[10] = d.h01; o[11] = d.h11;
+            }
+            __syncthreads();
+            if (nL > 0 && c.lane == owner) {
+                Jet B = make_var(Jet(), b0, 0), T = make_zero(Jet());
+                for (int k = 0; k < nL; k++) {
+                    const double *o = out + 12*k;
+                    const Jet phi = {o[0], o[1], o[2], o[3], o[4], o[5]}, psi = {o[6], o[7], o[8], o[9], o[10], o[11]};
+                    T = T + jet_after(psi, B);
+                    B = jet_after(phi, B);
+                }
+                tau = T; bp = B; tau.v = s.yt; bp.v = s.yb;
+            }
+            ptau[j] = tau; pbp[j] = bp;
+            if (SPT > 1) __syncthreads();      /* the pool is the next node's */
+        }
+    }
+
     __device__ __forceinline__ void evaluate_current()
     {
         publish_current();
+        Jet ptau[SPT], pbp[SPT];
+        bool pre = false;
+        if constexpr (COOP) {
+            if (P.integ == MSD_INTEGRATOR_ADAPTIVE) { coop_adaptive(ptau, pbp); pre = true; }
+        }
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<7>();
@@ -2496,7 +2602,7 @@ struct Solver {
                 Ev ej;
 #pragma unroll
                 for (int k = 0; k < NV; k++) xl[k] = n[j].x[k];
-                eval_interval<true, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej);
+                eval_interval<true, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xl, c.xt[n[j].i + 1], c.xb[n[j].i + 1], cv, dv, ej, pre ? &ptau[j] : nullptr, pre ? &pbp[j] : nullptr);
                 resc[j][0] = cv[0]; resc[j][1] = cv[1];
 #pragma unroll
                 for (int r = 0; r < NR; r++) resd[j][r] = rowOn(r) ? dv[r] - n[j].sg[r] : 0.0;
@@ -2623,6 +2729,26 @@ struct Solver {
 
     __device__ static __forceinline__ double step_to(double x, double alpha, double d) { return fma(alpha, d, x); }
 
+    static constexpr bool STATIC_LDS = SLDS;      /* (the instantiations the pickers choose where the LDS has the room: STATIC_FIELDS) */
+    __device__ __forceinline__ void store_static()
+    {
+        if constexpr (STATIC_LDS) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) { const NodeT &nd = n[j]; const int i = nd.i; c.st[i] = nd.ds; c.st[NS + i] = nd.G; c.st[2*NS + i] = nd.sct; c.st[3*NS + i] = nd.scb; c.st[4*NS + i] = nd.ubB; }
+            __syncthreads();
+        }
+    }
+    /* WHAT: bit 0 ds, G; 1 sct, scb; 2 ubB */
+    template <int WHAT> __device__ __forceinline__ void load_static(int j)
+    {
+        if constexpr (STATIC_LDS) {
+            NodeT &nd = n[j]; const int i = nd.i;
+            if (WHAT & 1) { nd.ds = c.st[i]; nd.G = c.st[NS + i]; }
+            if (WHAT & 2) { nd.sct = c.st[2*NS + i]; nd.scb = c.st[3*NS + i]; }
+            if (WHAT & 4) nd.ubB = c.st[4*NS + i];
+        }
+    }
+
     /* (t, b, sqrt(b), Fel) of a point into the exchange arrays */
     __device__ __forceinline__ void publish_fast(const double (&x)[SPT][NV])
     {
@@ -2662,6 +2788,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<0>();
+            load_static<7>(j);
             NodeT &nd = n[j];
             const int i = nd.i;
             double Htt = 0, Hbb = 0, Hbq = 0, Hbf = 0, Hbp = 0, Hqq = 0, Hqf = 0, Hff = 0, Hfp = 0, Hfs = 0, Hpp = 0, Hss = 0;
@@ -2881,6 +3008,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<9>();
+            load_static<5>(j);
             NodeT &nd = n[j];
 #pragma unroll
             for (int r = 0; r < NR; r++) nd.dsg[r] = 0;
@@ -2968,6 +3096,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<5>();
+            load_static<7>(j);
             const NodeT &nd = n[j];
             const int i = nd.i;
             double prod = 1.0;
@@ -3018,6 +3147,7 @@ struct Solver {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<10>();
+            load_static<4>(j);
             NodeT &nd = n[j];
             if (!nd.node()) continue;
             Dir dd; load_dir(j, dd);
@@ -3380,6 +3510,7 @@ struct Solver {
             }
         }
 
+        if constexpr (FL) store_static();
         int park = 0;                      /* why the iterate is parked at the top of the next pass (STATUS_RESTO) */
         double park_theta = 0, park_phi = 0;
         for (iter = iter_first;; iter++) {
@@ -3864,7 +3995,7 @@ __device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, U
  *   2  the follow-up: general iteration + restoration phase + second attempt, for the scenarios of the list (P.follow) or, without a
  *      list, for the whole batch (launches none of whose scenarios can start fused: the reference's starting point, a primal-only warm start)
  */
-template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0>
+template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0, bool SLDS = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
@@ -3886,7 +4017,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     }
     c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
-    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL, PART>;
+    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL, PART, SLDS>;
     constexpr bool FASTK = SolverT::FAST;
     c.xs = c.o4 = c.o5 = c.o6 = c.o7 = nullptr;
     if (FASTK) { c.xs = c.o3 + NS; c.o4 = c.xs + NS; c.o5 = c.o4 + NS; c.o6 = c.o5 + NS; c.o7 = c.o6 + NS; }
@@ -3894,6 +4025,8 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     c.red = c.filt + 2*FILT_CAP; c.misc = c.red + ((FASTK && NT == 64) ? 0 : RED_DOUBLES);      /* (a single wave reduces in registers) */
     /* the problem record and the scenario's uniform data live in LDS: phases read what they need (broadcast reads) instead of
      * carrying some eighty uniform values through the whole solve in registers */
+    c.st = c.misc + 32 + CONST_DOUBLES;
+    c.pool = c.st;      /* (kernels of the shooting-integrator families have no node constants there) */
     DevProb *Pl = reinterpret_cast<DevProb *>(c.misc + 32);
     Uni *Ul = reinterpret_cast<Uni *>(c.misc + 32 + UNI_OFF);
     static_assert(sizeof(DevProb) <= 8*UNI_OFF && sizeof(Uni) <= 8*(CONST_DOUBLES - UNI_OFF), "LDS room for the uniform records");

@@ -18,6 +18,9 @@ Geometry pick_geometry_full_rg(int N)
     const char *nf = getenv("MSD_NO_FULL");      /* MSD_NO_FULL=1: the general kernels (A/B runs) */
     if (nf && *nf == '1') return {0, 0, nullptr};
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
+    /* (SLDS: the node constants in LDS where they do not cost the fourth resident workgroup of a compute unit -- msd_kernel.hpp: STATIC_FIELDS) */
+    if (MSD_STATIC_LDS && sizeof(double)*(size_t)(lds_doubles(N, 128, false, XCH_FAST, 0) + STATIC_FIELDS*128) <= 40*1024 && nodes > 64)
+        return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1, true>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3, true>, STATIC_FIELDS*128};
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};     /* the benchmark geometry */
     if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, RED_DOUBLES, follow_kernel_full_rg(128, 2), solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
     /* longer horizons while the five additional exchange arrays still fit the LDS of a compute unit next to the stage blocks */

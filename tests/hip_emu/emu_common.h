@@ -23,7 +23,7 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
         std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, (FULL && DYN == 0 && !GEN) ? msd::XCH_FAST : msd::XCH_GENERAL,
-                                                                                                   (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
+                                                                                                   (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
         blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
         std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
         std::vector<std::thread> th;
