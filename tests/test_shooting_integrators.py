@@ -218,6 +218,37 @@ def test_gpu_other_integrators_vs_oracle(method, io, integration, N, crop, T):
             assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 6
 
 
+@pytest.mark.gpu
+def test_gpu_adaptive_integrator_shared_evaluation_equals_the_sequential_one(monkeypatch):
+    """
+    The 'CVODES' kernels with one node per lane evaluate the jets of a long interval -- the first and the last of a journey from and to
+    standstill: 25-28 accepted steps -- with the lanes of the wave together (msd_kernel.hpp: Solver::coop_adaptive: values first, the local jet
+    of step k on lane k, chain-rule composition by the owner); the two-nodes-per-lane geometry (a tuning switch of the pickers) runs every interval
+    the sequential way (msd_integ.hpp: dopri_tb_jet).  Same discrete map, same derivatives: the two solves take the same iterations and agree to
+    rounding.  v0 = vN = 1 m/s (both ends long) and a journey that starts at speed (one long interval, in the second wave).
+    """
+    from mseetc.ocp import casadiSolver
+    train, track = cases.train_default(), cases.track_00()
+    Ts = 1541.0*np.array([1.0, 1.03, 1.08, 1.15])
+    for v0 in (1.0, 20.0):
+        out = {}
+        for geometry in ('default', '64x2'):
+            if geometry == 'default':
+                monkeypatch.delenv('MSD_GEOMETRY2', raising=False)
+            else:
+                monkeypatch.setenv('MSD_GEOMETRY2', geometry)
+            solver = casadiSolver(train, track, dict(numIntervals=100, maxIterations=400, integrationMethod='CVODES'), startingPoint='profile')
+            scen = solver._scenarios(Ts, 0, 1, v0)
+            out[geometry] = solver.problem.solve_batch(scen)
+            assert tuple(solver.problem.geometry()) == ((128, 1) if geometry == 'default' else (64, 2))
+            solver.close()
+        a, b = out['default'], out['64x2']
+        assert np.all(a['stats'][:, 0] == 0) and np.all(b['stats'][:, 0] == 0)
+        assert np.array_equal(a['stats'][:, 1], b['stats'][:, 1])                                     # iterations
+        assert np.max(np.abs(a['stats'][:, 2] - b['stats'][:, 2])/np.abs(b['stats'][:, 2])) < 1e-11      # objective
+        assert np.max(np.abs(a['z'] - b['z'])/np.maximum(1, np.abs(b['z']))) < 1e-8
+
+
 def _dynamic_train():
     "figure5.py's train with the dynamic loss model of efficiency.py (no pneumatic brake)"
     from mseetc.train import Train
