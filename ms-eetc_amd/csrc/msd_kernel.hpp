@@ -180,7 +180,10 @@ constexpr int S_EB = 28, S_ES = 29;
 #define MSD_COOP_ADAPTIVE 1
 #endif
 constexpr int COOP_CAP = 64, COOP_HDR = 8, COOP_POOL = COOP_HDR + 2*COOP_CAP + 12*COOP_CAP;
-__host__ __device__ __forceinline__ int coop_doubles(int NT, bool gen) { return (MSD_COOP_ADAPTIVE && gen && NT <= 128) ? (NT/64)*COOP_POOL : 0; }
+/* ... and per lane what its own value pass left (Solver::coop_values): two step sizes and step-start values, tau and b+, a status word, and the (b, force) the
+ * pass was run at -- the evaluation of the current point that follows an accepted trial point finds the value pass done */
+constexpr int COOP_REC = 9;
+__host__ __device__ __forceinline__ int coop_doubles(int NT, bool gen) { return (MSD_COOP_ADAPTIVE && gen && NT <= 128) ? (NT/64)*COOP_POOL + COOP_REC*NT : 0; }
 
 /* LDS of the streamed kernel: filter, reduction scratch, misc, uniform records */
 __host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96; }
@@ -713,7 +716,8 @@ struct Ev {
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
 template <bool DERIV, int DYN, bool GEN, int FULL>
 __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, const double nG, const double nds, const double (&x)[NV], double t1, double b1,
-                                              double (&cv)[2], double (&dv)[NR], Ev &e, const Jet *ptau = nullptr, const Jet *pbp = nullptr)
+                                              double (&cv)[2], double (&dv)[NR], Ev &e, const Jet *ptau = nullptr, const Jet *pbp = nullptr,
+                                              const double *vtau = nullptr, const double *vbp = nullptr)
 {
     const double b = x[VB], f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
@@ -725,7 +729,8 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
         e.Bb = bp.g0; e.Bw = bp.g1; e.Bbb = bp.h00; e.Bbw = bp.h01; e.Bww = bp.h11;
     } else {
         double tau, bp;
-        if (GEN) interval_map_general<double>(P, b, f + p, nG, nds, tau, bp); else interval_map<double>(P, b, f + p, nG, nds, tau, bp);
+        if (vtau) { tau = *vtau; bp = *vbp; }      /* (Solver::coop_values) */
+        else if (GEN) interval_map_general<double>(P, b, f + p, nG, nds, tau, bp); else interval_map<double>(P, b, f + p, nG, nds, tau, bp);
         cv[0] = t1 - (x[VT] + tau); cv[1] = b1 - bp;
     }
     const double sb = sqrt(b), sb1 = sqrt(b1);
@@ -2428,6 +2433,14 @@ struct Solver {
         double xt[SPT][NV], st[SPT][NR];
         trial_point(alpha, xt, st);
         publish(xt);
+        double ctau = 0, cbp = 0;
+        bool pre = false;
+        if constexpr (COOP) {
+            if (P.integ == MSD_INTEGRATOR_ADAPTIVE) {
+                coop_values(n[0].ival(), xt[0][VB], xt[0][VF] + (withPn() ? xt[0][VP] : 0.0), n[0].G, n[0].ds, ctau, cbp);
+                coop_valid = true; pre = true;
+            }
+        }
         double th = 0, logs = 0, damp = 0, bad = 0, obj = 0;
         LogSum lsum;
 #pragma unroll
@@ -2437,7 +2450,7 @@ struct Solver {
             double prod = 1.0;
             if (nd.ival()) {
                 double cv[2], dv[NR]; Ev dummy;
-                eval_interval<false, DYN, GEN, FULL>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy);
+                eval_interval<false, DYN, GEN, FULL>(P, U, nd.G, nd.ds, xt[j], c.xt[nd.i + 1], c.xb[nd.i + 1], cv, dv, dummy, nullptr, nullptr, pre ? &ctau : nullptr, pre ? &cbp : nullptr);
                 if (!resto) th += nd.sct*fabs(cv[0]) + nd.scb*fabs(cv[1]);
                 else {
                     /* restoration problem: relaxed rows with the trial (n, p); barrier and penalty terms of (n, p) */
@@ -2487,6 +2500,14 @@ struct Solver {
         double xt[SPT][NV], st[SPT][NR];
         trial_point(alpha, xt, st);
         publish(xt);
+        double ctau = 0, cbp = 0;
+        bool pre = false;
+        if constexpr (COOP) {
+            if (P.integ == MSD_INTEGRATOR_ADAPTIVE) {
+                coop_values(n[0].ival(), xt[0][VB], xt[0][VF] + (withPn() ? xt[0][VP] : 0.0), n[0].G, n[0].ds, ctau, cbp);
+                coop_valid = true; pre = true;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             node_fence<6>();
@@ -2495,7 +2516,7 @@ struct Solver {
             for (int r = 0; r < NR; r++) td[j][r] = 0;
             if (n[j].ival()) {
                 double dv[NR]; Ev dummy;
-                eval_interval<false, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy);
+                eval_interval<false, DYN, GEN, FULL>(P, U, n[j].G, n[j].ds, xt[j], c.xt[n[j].i + 1], c.xb[n[j].i + 1], tc[j], dv, dummy, nullptr, nullptr, pre ? &ctau : nullptr, pre ? &cbp : nullptr);
 #pragma unroll
                 for (int r = 0; r < NR; r++) td[j][r] = rowOn(r) ? dv[r] - st[j][r] : 0.0;
             }
@@ -2513,75 +2534,107 @@ struct Solver {
      * numbers the value-only evaluation of a trial point computes.  Uniform control flow: every thread of the workgroup calls it.
      */
     static constexpr bool COOP = GEN && !STREAM && SPT == 1 && MSD_COOP_ADAPTIVE && NT <= 128;      /* (one node per lane: the benchmark geometries of these families) */
-    __device__ __forceinline__ void coop_adaptive(Jet (&ptau)[SPT], Jet (&pbp)[SPT])
+    __device__ __forceinline__ double &coop_rec(int f) const { return c.pool[c.nw*COOP_POOL + f*NT + c.tid]; }
+    /* the value pass of every lane's interval at (b0, force wv): step-size controller on values, records for the jets (above), tau and b+ */
+    __device__ __forceinline__ void coop_values(const bool act, const double b0, const double wv, const double G, const double ds, double &tauv, double &bpv)
     {
         double *pool = c.pool + c.wave*COOP_POOL;
-        double *rec_h = pool + COOP_HDR, *rec_y = rec_h + COOP_CAP, *out = rec_y + COOP_CAP;
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            const NodeT &nd = n[j];
-            const bool act = nd.ival();
-            const double b0 = nd.x[VB], wv = nd.x[VF] + (withPn() ? nd.x[VP] : 0.0), G = nd.G, ds = nd.ds;
-            DopriValues s;
-            double rh[2] = {0, 0}, ry[2] = {0, 0};
-            int na = 0, state = act ? 0 : 1, tries = 0;      /* state: 0 under way, 1 at the end of the interval, -1 the step control collapsed */
-            if (act) s.start(P, b0, wv, G, ds);
-            while (state == 0 && na < 2) {
+        double *rec_h = pool + COOP_HDR, *rec_y = rec_h + COOP_CAP;
+        DopriValues s;
+        double rh[2] = {0, 0}, ry[2] = {0, 0};
+        int na = 0, state = act ? 0 : 1, tries = 0;      /* state: 0 under way, 1 at the end of the interval, -1 the step control collapsed */
+        if (act) s.start(P, b0, wv, G, ds);
+        while (state == 0 && na < 2) {
+            double h, y;
+            const int rc = s.attempt(P, wv, G, ds, h, y);
+            if (rc == 1) { rh[na] = h; ry[na] = y; na++; if (s.finished()) state = 1; }
+            else if (rc < 0 || ++tries >= 100000) state = -1;
+        }
+        const bool lng = act && state == 0;
+        const int owner = (int)wave_reduce(lng ? (double)c.lane : 64.0, OpMin());
+        int k = 2;
+        if (lng) {
+            const bool own = c.lane == owner;
+            if (own) { pool[1] = wv; pool[2] = G; pool[3] = ds; rec_h[0] = rh[0]; rec_y[0] = ry[0]; rec_h[1] = rh[1]; rec_y[1] = ry[1]; }
+            while (state == 0) {
                 double h, y;
                 const int rc = s.attempt(P, wv, G, ds, h, y);
-                if (rc == 1) { rh[na] = h; ry[na] = y; na++; if (s.finished()) state = 1; }
+                if (rc == 1) { if (own && k < COOP_CAP) { rec_h[k] = h; rec_y[k] = y; } k++; if (s.finished()) state = 1; }
                 else if (rc < 0 || ++tries >= 100000) state = -1;
             }
-            const bool lng = act && state == 0;
-            const int owner = (int)wave_reduce(lng ? (double)c.lane : 64.0, OpMin());
-            if (c.lane == owner) {
-                pool[1] = wv; pool[2] = G; pool[3] = ds;
-                rec_h[0] = rh[0]; rec_y[0] = ry[0]; rec_h[1] = rh[1]; rec_y[1] = ry[1];
-                int k = 2;
-                while (state == 0) {
-                    double h, y;
-                    const int rc = s.attempt(P, wv, G, ds, h, y);
-                    if (rc == 1) { if (k < COOP_CAP) { rec_h[k] = h; rec_y[k] = y; } k++; if (s.finished()) state = 1; }
-                    else if (rc < 0 || ++tries >= 100000) state = -1;
-                }
-                pool[0] = (state == 1 && k <= COOP_CAP) ? (double)k : -1.0;
-            }
-            __syncthreads();
-            const int nL = owner < 64 ? (int)pool[0] : 0;      /* steps of the owner's interval to be shared out (0: none) */
-            Jet tau = {NAN, NAN, NAN, NAN, NAN, NAN}, bp = tau;
-            if (act && !lng) {
-                if (state == 1) {
-                    Jet yb = make_var(Jet(), b0, 0), T = make_zero(Jet());
-                    const Jet w = make_var(Jet(), wv, 1);
-                    for (int k = 0; k < na; k++) { Jet d; dopri_step_jet(P, yb, d, w, G, ds, rh[k]); T = T + d; }
-                    tau = T; bp = yb; tau.v = s.yt; bp.v = s.yb;
-                }
-            } else if (lng && !(c.lane == owner && nL > 0)) {
-                dopri_tb_jet(P, make_var(Jet(), b0, 0), make_var(Jet(), wv, 1), G, ds, tau, bp);
-            }
-            if (nL > 0 && c.lane < nL) {
-                Jet yb = make_var(Jet(), rec_y[c.lane], 0), d;
-                const Jet w = make_var(Jet(), pool[1], 1);
-                dopri_step_jet(P, yb, d, w, pool[2], pool[3], rec_h[c.lane]);
-                double *o = out + 12*c.lane;
-                o[0] = yb.v; o[1] = yb.g0; o[2] = yb.g1; o[3] = yb.h00; o[4] = yb.h01; o[5] = yb.h11;
-                o[6] = d.v; o[7] = d.g0; o[8] = d.g1; o[9] = d.h00; o[10] = d.h01; o[11] = d.h11;
-            }
-            __syncthreads();
-            if (nL > 0 && c.lane == owner) {
-                Jet B = make_var(Jet(), b0, 0), T = make_zero(Jet());
-                for (int k = 0; k < nL; k++) {
-                    const double *o = out + 12*k;
-                    const Jet phi = {o[0], o[1], o[2], o[3], o[4], o[5]}, psi = {o[6], o[7], o[8], o[9], o[10], o[11]};
-                    T = T + jet_after(psi, B);
-                    B = jet_after(phi, B);
-                }
-                tau = T; bp = B; tau.v = s.yt; bp.v = s.yb;
-            }
-            ptau[j] = tau; pbp[j] = bp;
-            if (SPT > 1) __syncthreads();      /* the pool is the next node's */
+            if (own) pool[0] = (state == 1 && k <= COOP_CAP) ? (double)k : -1.0;
         }
+        if (c.lane == 0) pool[4] = (double)owner;
+        tauv = (act && state == 1) ? s.yt : NAN; bpv = (act && state == 1) ? s.yb : NAN;
+        coop_rec(0) = rh[0]; coop_rec(1) = rh[1]; coop_rec(2) = ry[0]; coop_rec(3) = ry[1]; coop_rec(4) = tauv; coop_rec(5) = bpv;
+        coop_rec(6) = (double)(na + 4*(state + 1) + 16*(lng ? 1 : 0));
+        coop_rec(7) = b0; coop_rec(8) = wv;
+        __syncthreads();
     }
+
+    /*
+     * The interval maps of the adaptive shooting integrator with their jets, evaluated by the lanes of a wave together (msd_integ.hpp: DopriValues,
+     * dopri_step_jet, jet_after).  Every lane runs the step-size controller on values (coop_values -- or finds that pass done: the current point is the
+     * trial point the line search accepted); an interval that is through after two accepted steps (all but the first and the last of a journey from and
+     * to standstill) replays them in jets itself.  The lowest lane with a longer interval -- the owner -- has left step sizes and step-start values in
+     * the wave's pool, lane k evaluates the local jet of step k, and the owner composes them by the chain rule: 26 steps cost one set of jet stages plus
+     * 26 small compositions instead of 26 sets.  A second long interval in the same wave, or one with more than COOP_CAP steps, is evaluated the
+     * sequential way (dopri_tb_jet).  Values (tau, b+) are the value pass's: the numbers the value-only evaluation of a trial point computes.  Uniform
+     * control flow: every thread of the workgroup calls it.
+     */
+    __device__ __forceinline__ void coop_adaptive(Jet (&ptau)[SPT], Jet (&pbp)[SPT])
+    {
+        const NodeT &nd = n[0];
+        const bool act = nd.ival();
+        const double b0 = nd.x[VB], wv = nd.x[VF] + (withPn() ? nd.x[VP] : 0.0), G = nd.G, ds = nd.ds;
+        {
+            /* is the value pass on record the one of this point?  (bit-equal b and force in every lane: x + alpha d is formed the same way twice) */
+            double v[1] = {(!act || (coop_valid && coop_rec(7) == b0 && coop_rec(8) == wv)) ? 1.0 : 0.0};
+            block_reduce<1>(v, OpMin(), c);
+            double tv, bv;
+            if (uni(v[0]) == 0.0) coop_values(act, b0, wv, G, ds, tv, bv);
+            coop_valid = true;
+        }
+        double *pool = c.pool + c.wave*COOP_POOL;
+        const double *rec_h = pool + COOP_HDR, *rec_y = rec_h + COOP_CAP;
+        double *out = pool + COOP_HDR + 2*COOP_CAP;
+        const int code = (int)coop_rec(6), na = code & 3, state = ((code >> 2) & 3) - 1;
+        const bool lng = (code & 16) != 0;
+        const int owner = (int)pool[4];
+        const int nL = owner < 64 ? (int)pool[0] : 0;      /* steps of the owner's interval to be shared out (0: none) */
+        Jet tau = {NAN, NAN, NAN, NAN, NAN, NAN}, bp = tau;
+        if (act && !lng) {
+            if (state == 1) {
+                Jet yb = make_var(Jet(), b0, 0), T = make_zero(Jet());
+                const Jet w = make_var(Jet(), wv, 1);
+                for (int k = 0; k < na; k++) { Jet d; dopri_step_jet(P, yb, d, w, G, ds, coop_rec(k)); T = T + d; }
+                tau = T; bp = yb; tau.v = coop_rec(4); bp.v = coop_rec(5);
+            }
+        } else if (lng && !(c.lane == owner && nL > 0)) {
+            dopri_tb_jet(P, make_var(Jet(), b0, 0), make_var(Jet(), wv, 1), G, ds, tau, bp);
+        }
+        if (nL > 0 && c.lane < nL) {
+            Jet yb = make_var(Jet(), rec_y[c.lane], 0), d;
+            const Jet w = make_var(Jet(), pool[1], 1);
+            dopri_step_jet(P, yb, d, w, pool[2], pool[3], rec_h[c.lane]);
+            double *o = out + 12*c.lane;
+            o[0] = yb.v; o[1] = yb.g0; o[2] = yb.g1; o[3] = yb.h00; o[4] = yb.h01; o[5] = yb.h11;
+            o[6] = d.v; o[7] = d.g0; o[8] = d.g1; o[9] = d.h00; o[10] = d.h01; o[11] = d.h11;
+        }
+        __syncthreads();
+        if (nL > 0 && c.lane == owner) {
+            Jet B = make_var(Jet(), b0, 0), T = make_zero(Jet());
+            for (int k = 0; k < nL; k++) {
+                const double *o = out + 12*k;
+                const Jet phi = {o[0], o[1], o[2], o[3], o[4], o[5]}, psi = {o[6], o[7], o[8], o[9], o[10], o[11]};
+                T = T + jet_after(psi, B);
+                B = jet_after(phi, B);
+            }
+            tau = T; bp = B; tau.v = coop_rec(4); bp.v = coop_rec(5);
+        }
+        ptau[0] = tau; pbp[0] = bp;
+    }
+    bool coop_valid = false;      /* the records of coop_values are this solve's (the LDS is the previous scenario's at the start) */
 
     __device__ __forceinline__ void evaluate_current()
     {
