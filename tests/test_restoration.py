@@ -85,7 +85,7 @@ def test_emulated_restoration_phase_follows_the_oracle():
     assert int(st[0, ST['STATUS']]) == int(ref['stats']['STATUS']) == -1
     # the iteration limit after a restoration phase counts as a breakdown: both sides repeat the solve from the other starting point (60 + 60
     # iterations; the statistics and the history are those of the second attempt, which goes through restoration phases of its own)
-    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 120
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 2*maxit
     assert int(st[0, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
     h = ref['hist']
     for i in range(60):
@@ -148,7 +148,8 @@ def test_emulated_restoration_phase_in_the_other_kernel_families(family, monkeyp
     T = 200.0 if family == 'dynamic' else 300.0
     if family == 'streamed':
         monkeypatch.setenv('EMU_GEOMETRY', 'stream')
-    train, track, opts, prob, kw = _family_case(family, N, 60)
+    maxit = 40      # (per attempt: the emulation runs the streamed kernel's 512 lanes as host threads -- a second per iteration)
+    train, track, opts, prob, kw = _family_case(family, N, maxit)
     solver = casadiSolver(train, track, opts, startingPoint='reference')
     scen = solver._scenarios(T, 0, kw.get('terminalVelocity', 1), kw.get('initialVelocity', 1))
     nz = (4 + int(solver.withPnBrake))*N + 2
@@ -157,14 +158,14 @@ def test_emulated_restoration_phase_in_the_other_kernel_families(family, monkeyp
     assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), cap) == 0
     ref = oracle.solve(prob, prob.scenario(T, **kw), start='reference', history=True)
     assert int(st[0, ST['STATUS']]) == int(ref['stats']['STATUS']) == -1
-    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 120
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS']) == 2*maxit
     assert int(st[0, ST['N_RESTO']]) == int(ref['stats']['N_RESTO']) >= 2
     h = ref['hist']
     # (collocation: the Newton iteration inside the integrator -- OptionsIRK.maxIter steps, no convergence test, like casadi.simpleIRK -- lets the two drift
     #  apart: 1.2e-4 in the dual infeasibility of the restoration iterates from row 24 on, 1e-4 in everything after forty iterations)
     #  integrateLosses: the loss integrals come from an adaptive integrator (CVODES' tolerances, msd_lossint.hpp); the two implementations agree to 1e-10 up
     #  to the breakdown at row 20 -- dual infeasibility 3e9 -- and to 1e-5 ... 1e-4 on the restoration iterates behind it, which start from that point)
-    for i in range(36 if family == 'collocation' else 60):
+    for i in range(36 if family == 'collocation' else maxit):
         rtol = 3e-4 if family == 'collocation' else (1e-3 if i > 25 else 1e-4) if family == 'integrateLosses' else 1e-4
         assert np.allclose(hist[i, 1:5], h[i, 1:5], rtol=rtol, atol=1e-9), (i, hist[i], h[i])
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < (1e-2 if family == 'collocation' else 1e-4)
