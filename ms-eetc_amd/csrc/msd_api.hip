@@ -150,6 +150,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
     P.coll = nullptr;
     P.resto = d->no_restoration ? 0 : 1;
+    P.oneAttempt = 0;
     P.wdTrigger = d->watchdog_trigger == 0 ? 10 : d->watchdog_trigger;      /* IPOPT's default */
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;      /* train.py:314 */
 
@@ -214,6 +215,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     P.follow = nullptr; P.list = nullptr; P.queue = nullptr;
     P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
     P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
+    P.oneAttempt = ws.one_attempt ? 1 : 0;
     const bool split = pl.kernel2 != nullptr;
     const bool plain = !pl.fused_family || (ws.d_guess ? ws.d_dual_in != nullptr : P.start == MSD_START_PROFILE);      /* no multiplier estimate needed */
     const bool first_pass = split && (plain || pl.kernel_lsq != nullptr);

@@ -43,7 +43,8 @@ int check_desc(const msd_problem_desc *d);
 int make_plan(int device, const msd_problem_desc *d, Plan *out);      /* (check_desc() must have accepted d) */
 
 struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0;
-                   const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr; };
+                   const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr;
+                   bool one_attempt = false; };      /* one_attempt: a solve that breaks down is not repeated from the other starting point (msd_mpc.hip: the loop certifies it first) */
 
 /*
  * One batch on `stream`: the first pass + the follow-up kernel of a split solve, or the one kernel that holds everything.

@@ -100,6 +100,7 @@ struct DevProb {
     const double *coll;      /* C[(collD+1)^2], D[collD+1] of casadi.simpleIRK */
     int resto;               /* feasibility restoration phase where the line search breaks down (IPOPT's behaviour; msd_resto.hpp) */
     int wdTrigger;           /* shortened iterations in a row that start the watchdog procedure (IPOPT: 10; <= 0: never) */
+    int oneAttempt;          /* a solve that breaks down ends there: no second attempt from the other starting point (the re-solves of msd_mpc.hip) */
     /* split launches (solve_kernel's PART): the first-pass kernel appends the scenarios it does not finish to this list, the follow-up kernel drains it.
      * follow[0] entries written, [1] entries taken, [2] follow-up workgroups that found the list empty (the last one zeroes the three for the next
      * launch of the handle), [FOLLOW_HDR + 2k] scenario, [FOLLOW_HDR + 2k + 1] iterations already spent on it (>= 0: its first attempt broke down,
@@ -4180,6 +4181,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                     }
                     break;
                 }
+                if (P.oneAttempt) break;
                 if (attempt == 0 && c.tid == 0) atomicAdd(P.follow + FOLLOW_WHY + 5, 1);      /* (telemetry: second attempts made here) */
                 spent = iters;
                 if (guess) guess = nullptr;
@@ -4211,6 +4213,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
              * restoration phase (it can leave the iterate where the original iteration only crawls; the other starting point is the way out) */
             if (st >= 0 || st == MSD_STATUS_INFEASIBLE) break;
             if (st == MSD_STATUS_MAXITER && !(SolverT::HAS_RESTO && stats[(size_t)MSD_ST_COUNT*sidx + MSD_ST_N_RESTO] > 0)) break;
+            if (P.oneAttempt) break;
             spent = iters;
             if (guess) guess = nullptr;      /* a warm start that breaks down: once more from the problem's own starting point */
             else startKind = (startKind == MSD_START_PROFILE) ? MSD_START_REFERENCE : MSD_START_PROFILE;

@@ -4,9 +4,11 @@
  * Reference mechanism: Track.updateLimits(positionStart) (track.py:420-450) + casadiSolver on the cropped track + solve(T, initialTime,
  * initialVelocity) (ocp.py:310); mseetc/mpc.py: shrinkingHorizon is the host-side statement of the loop this file runs without the host.
  * One stream (the energy problem's handle), per re-solve:  scenario records from the measured state -> solve (first pass + follow-up kernel,
- * warm-started from the previous solutions and multipliers where the new grid is a tail of the old one) -> failed scenarios collected in a
- * list -> their minimum running times from the time-optimal twin (complete kernel launched on the list) -> arrival times moved, list
- * re-solved (up to three times with growing margins) -> log -> measured state for the next re-solve.  Every launch is unconditional; the
+ * warm-started from the previous solutions and multipliers where the new grid is a tail of the old one; one attempt per scenario when the loop
+ * relaxes infeasible arrival times: WarmStart::one_attempt) -> failed scenarios collected in a list -> their minimum running times from the
+ * time-optimal twin (complete kernel launched on the list) -> arrival times of the late ones moved, list re-solved (up to three times with
+ * growing margins; what the twin does not declare late is on the first of these lists too, arrival time unchanged, and gets both attempts
+ * there) -> log -> measured state for the next re-solve.  Every launch is unconditional; the
  * kernels launched on an empty list return at once.
  */
 #include <hip/hip_runtime.h>
@@ -79,7 +81,15 @@ __global__ void mpc_relax(int B, int attempt, const double *stats, const double 
         const bool ok = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_STATUS] >= 0 || (isfinite(viol) && viol <= 1e-6);
         const double tmin = z_tw[(size_t)nz_tw*s + nz_tw - 2] - tnow[s];
         if (ok && tmin > T[s] - tnow[s]) { tm[s] = tmin; flag[s] = 2; again = true; log[(size_t)MSD_MPC_COUNT*s + MSD_MPC_RELAXED] = 1.0; }
-        else flag[s] = 0;
+        else {
+            /* not late: the breakdown was the solver's.  The main launch makes one attempt per scenario (a late scenario would spend its second one, from
+             * the other starting point, on a problem without a solution -- nine of 512 per re-solve, a third of the loop's time in round 4); the ones
+             * the twin clears get both here, from the problem's own starting point, with their arrival time unchanged */
+            flag[s] = 3;
+            const int k = atomicAdd(list, 1);
+            list[HDR + 2*k] = s; list[HDR + 2*k + 1] = -1;
+            return;
+        }
     } else {
         if (flag[s] != 2) return;
         if (stats[(size_t)MSD_ST_COUNT*s + MSD_ST_STATUS] < 0) again = true; else flag[s] = 0;
@@ -322,6 +332,7 @@ int msd_mpc_run(msd_mpc_handle m, int nscen, const double *T, double initial_tim
             ws.d_dual_in = m->d_dual[prev]; ws.dual_stride = (long long)MSD_DUAL_STRIDE*(pp.P.N + 1); ws.dual_shift = m->stride;
         }
         ws.d_dual_out = m->warm ? m->d_dual[cur] : nullptr;
+        ws.one_attempt = m->relax;      /* (mpc_relax: what the twin does not declare late is solved again with both attempts) */
         rc = msd_host::launch_plan(pl, st, m->d_work, m->d_follow, queue(), B, m->d_scen, nullptr, m->d_z[cur], nullptr, m->d_st[cur], nullptr, 0, ws);
         if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }      /* (nothing of a loop that failed half-way stays queued on the handle's stream) */
         if (m->relax) {
