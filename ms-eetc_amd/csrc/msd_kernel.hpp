@@ -2831,7 +2831,7 @@ struct Solver {
      * barrier sums and the objective (first iteration, or after an iteration on the general path); otherwise E keeps the values
      * the accepted trial point left there.
      */
-    __device__ __forceinline__ void fused_pass(const bool MERIT, Err &E, double (&h0)[SPT][HV], double (&h1)[SPT][HV])
+    __device__ __forceinline__ void fused_pass(const bool MERIT, Err &E, double (&h0)[SPT][HV], double (&h1)[SPT][HV], const double dw = 0.0)
     {
         const int N = P.N;
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;      /* (nlam, nz: MERIT passes only) */
@@ -2922,6 +2922,7 @@ struct Solver {
                         S_ += z*ri; g1_ += ri;
                     } else { g1_ += K_D; if (MERIT) damp += nd.sg[r] - U.dL[r]; }
                     dual = fmax(dual, fabs(gsl));
+                    S_ += dw;      /* (inertia correction: delta_w on the slack's diagonal entry, like assemble()) */
                     Sg[r] = S_; c0[r] = S_*rd_; c1[r] = g1_;
                 }
                 /* h += coef grad(row), H += Sigma grad grad^T over the rows' non-zeros */
@@ -2959,6 +2960,7 @@ struct Solver {
                         gl[j][k] += z; cmax = fmax(cmax, cp); cmin = fmin(cmin, cp); sumz += z; nz += 1; prod *= su;
                         Sv[k] += z*ri; g1v[k] += ri;
                     } else { g1v[k] += K_D; if (MERIT) damp += nd.x[k] - lbv(k); }
+                    Sv[k] += dw;
                 }
                 Htt += Sv[VT]; a1[0] += g1v[VT]; Hbb += Sv[VB]; a1[1] += g1v[VB]; Hff += Sv[VF]; a1[3] += g1v[VF]; Hpp += Sv[VP]; a1[4] += g1v[VP];
                 Hss += Sv[VS]; a1[5] += g1v[VS];
@@ -3194,7 +3196,7 @@ struct Solver {
     /* accept x + alpha d (the point merit_fast published); multipliers like the general path's update.  The safeguard that keeps
      * Sigma = z/slack within [mu/(kappa_Sigma slack), kappa_Sigma mu/slack] (W&B eq. (16)) is tested on the product z slack; the division it
      * needs when it acts (kappa_Sigma = 1e10: next to never) is left to a second pass that runs only then */
-    __device__ __forceinline__ void update_fast(double apr, double adu, double mu_)
+    __device__ __forceinline__ void update_fast(double apr, double adu, double mu_, const double dw = 0.0)
     {
         const double hi = K_SIGMA*mu_, lo = mu_*(1.0/K_SIGMA);
         bool clamp = false;
@@ -3243,7 +3245,7 @@ struct Solver {
                         nd.zUs[r_] = zn;
                     } else gphi += K_D*mu_;
                     /* new inequality multiplier nu+ = Sigma dsigma + grad phi_sigma, at the old point */
-                    nd.nu[r_] += apr*(Sg*dk + gphi - nd.nu[r_]);
+                    nd.nu[r_] += apr*((Sg + dw)*dk + gphi - nd.nu[r_]);
                     nd.sg[r_] = sn_;
                 }
                 nd.lam[0] += apr*(dd.lt - nd.lam[0]); nd.lam[1] += apr*(dd.lb - nd.lam[1]);
@@ -3540,6 +3542,9 @@ struct Solver {
         int nfilt = 0;
         double delta_last = 0, theta_max = 0, theta_min = 0;
         int status = MSD_STATUS_MAXITER, iter = 0, acc_count = 0, tiny_count = 0;
+        /* inertia correction of the fused iteration (W&B Algorithm IC): the pass over the current point runs again with delta_w on the diagonal */
+        double ic_dw = 0;
+        bool ic_retry = false;
         int n_reg = 0, n_soc = 0, n_back = 0, n_resto = 0, iter_first = 0, forced = 0;
         int wd_short = 0, wd_trial = 0, n_wd = 0, wd_reg_inc = 0;      /* watchdog: successive shortened iterations, trial iterations of a running procedure, procedures started */
         bool in_wd = false, wd_arm = false;      /* (wd_arm: the iterate of this iteration has been copied for the procedure, which starts at its line search) */
@@ -3602,7 +3607,7 @@ struct Solver {
                         for (int k = 0; k < NV; k++) xc[j][k] = n[j].x[k];
                     publish_fast(xc);
                 }
-                fused_pass(iter == 0, E, h0, h1);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
+                fused_pass(iter == 0, E, h0, h1, ic_dw);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
                 c.mark(PH_KKT); phase_fence(PH_KKT);
             } else {
                 if (iter > 0 || (RESUMABLE && !FL && resume)) evaluate_current();
@@ -3623,7 +3628,7 @@ struct Solver {
             /* (acc_now: the current point meets the acceptable tolerances -- where the line search then finds no step the solve ends with
              *  Solved_To_Acceptable_Level, IPOPT's "Restoration phase called at acceptable point", instead of breaking down: below) */
             const bool acc_now = E0 <= ACC_TOL && dual_u <= 1e10 && E.primal_u <= 1e-2 && compl_u <= 1e-2;
-            if (acc_now) { if (++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
+            if (acc_now) { if (!(FL && ic_retry) && ++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
             else acc_count = 0;
             if (iter >= P.maxIter) { status = MSD_STATUS_MAXITER; break; }
             if (!isfinite(E0)) { status = MSD_STATUS_NUMERIC; break; }
@@ -3631,7 +3636,7 @@ struct Solver {
             /* barrier parameter (monotone, W&B eq. (7)); E_mu differs from E_0 only in the complementarity part */
             {
                 bool changed = false;
-                while (total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {
+                while (!(FL && ic_retry) && total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {      /* (ic_retry: the same point once more, below) */
                     const double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, mu*sqrt(mu)));      /* mu^theta_mu with theta_mu = K_MU_SUP = 1.5 */
                     if (nm >= mu) break;
                     mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = true;
@@ -3647,7 +3652,16 @@ struct Solver {
                 const int par = ParallelRiccati<SPT, DYN>::solve(P.N, withPn(), c);
                 c.red_slot++;
                 c.mark(PH_RICCATI); phase_fence(PH_RICCATI);
-                if (par != 1) { status = STATUS_GENERAL; why_general = 1; break; }      /* wrong inertia or scan breakdown (never seen on the benchmark batches) */
+                if (par == 0) {
+                    /* wrong inertia (a pivot of the stage recursion is not positive): delta_w on the diagonal and the pass over this point again -- W&B
+                     * Algorithm IC, the schedule of the general iteration below.  Round 5: warm-started re-solves of config 4 meet it in 3 % of the
+                     * solves; they used to be solved again from scratch by the follow-up kernel (40 % of the loop's device time) */
+                    if (!ic_retry) { n_reg++; ic_dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last); }
+                    else ic_dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
+                    if (ic_dw <= DW_MAX) { ic_retry = true; iter--; continue; }
+                }
+                if (par != 1) { status = STATUS_GENERAL; why_general = 1; break; }      /* scan breakdown, or no delta_w up to DW_MAX gives the inertia */
+                if (ic_dw > 0) delta_last = ic_dw;
                 double gphid, amax;
                 bool tiny_step;
                 post_direction(mu, tau, gphid, dnorm, tiny_step, amax, alpha_du);
@@ -3697,7 +3711,8 @@ struct Solver {
                     nfilt++;
                     __syncthreads();
                 }
-                update_fast(alpha_pr, alpha_du, mu);
+                update_fast(alpha_pr, alpha_du, mu, ic_dw);
+                ic_dw = 0; ic_retry = false;
                 E.theta = T.theta; E.L = T.L; E.D = T.D; E.obj = T.obj;
                 c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
             } else {

@@ -41,6 +41,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol; P.coll = d->coll_tables;
     P.resto = d->no_restoration ? 0 : 1;
     P.wdTrigger = d->watchdog_trigger == 0 ? 10 : d->watchdog_trigger;
+    P.oneAttempt = 0;
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE) P.numApprox = 0;
     const bool dyn = d->loss_kind == 2;
     const int nodes = P.N + 1;
