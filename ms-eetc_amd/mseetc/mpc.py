@@ -12,6 +12,7 @@ import copy
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+from ._device import ST as _ST
 
 from .ocp import casadiSolver
 
@@ -297,7 +298,9 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
 
             log.append(dict(position=position, numIntervals=Nk, t0=t_now.copy(), v0=v_now.copy(), T=T.copy(), status=res['status'].copy(),
                             iterations=res['iterations'].copy(), cost=res['cost'].copy(), z=res['z'], relaxed=relaxed,
-                            kernel_ms=float(res.get('kernel_ms', 0.0)) + kernel_extra))
+                            kernel_ms=float(res.get('kernel_ms', 0.0)) + kernel_extra,
+                            # (inertia corrections of the main launch's solves, where the solver reports its statistics: the device solver)
+                            regularisations=(res['stats'][:, _ST['N_REG']].astype(int) if 'stats' in res else None)))
 
             last = solver
 

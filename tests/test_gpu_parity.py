@@ -1287,6 +1287,37 @@ def test_device_resident_shrinking_horizon_loop_vs_host_loop():
         assert (hm != dm).sum() <= 2
 
 
+def test_fused_iteration_corrects_the_inertia_itself():
+    """
+    Round 5: where a pivot of the stage recursion is not positive the fused iteration puts delta_w on the diagonal and runs its pass over the point
+    again (W&B Algorithm IC, the schedule of the general iteration and of the oracle) instead of handing the scenario to the follow-up kernel.
+    Warm-started re-solves of config 4 meet it in a few per cent of the solves: the loop's handles report inertia corrections, none of its
+    scenarios goes to the follow-up kernel for that reason, and the closed loop is the cold-started one (test_config4_full_size_warm_and_cold
+    holds the full comparison).
+    """
+    from mseetc import workloads as wl
+    from mseetc.mpc import shrinkingHorizon
+    from mseetc.ocp import casadiSolver
+    train, track, N = wl.config('c4')
+    T = wl.c1_times(128, seed=20260615)
+    counts = []
+
+    def factory(tr, tk, op):
+        s = casadiSolver(tr, tk, op, restoration=False, watchdogTrigger=-1)
+        close = s.close
+
+        def closing():
+            counts.append(s.problem.follow_counts())
+            close()
+        s.close = closing
+        return s
+    log = shrinkingHorizon(train, track, wl.options(N), T, numResolves=50, noise=0.01, seed=1, warmStart=True, solverFactory=factory)
+    reg = sum(int(l['regularisations'].sum()) for l in log)
+    by_reason = np.sum([c[1] for c in counts], axis=0)      # (no fused start, inertia / scan, tiny step, second-order correction, line search, ...)
+    assert reg > 0 and by_reason[1] == 0, (reg, by_reason)
+    assert all((l['status'] < 0).sum() <= (0 if k < 48 else 4) for k, l in enumerate(log))
+
+
 @pytest.mark.parametrize('variant', ['rg', 'both'])
 def test_short_horizons_through_the_follow_up_kernel(variant):
     """
