@@ -12,6 +12,10 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 #include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
 
 
@@ -24,8 +28,13 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
         pthread_barrier_init(&blk.bar, nullptr, NT);
         std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, (FULL && DYN == 0 && !GEN) ? msd::XCH_FAST : msd::XCH_GENERAL,
                                                                                                    (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
+        /* EMU_POISON=1 (environment): LDS and work area start as NaN instead of zero -- a read of shared memory before its first write, which on the
+         * device sees whatever the kernel before left there, then shows in the results */
+        const char *poison = getenv("EMU_POISON");
+        if (poison && *poison == '1') std::fill(lds.begin(), lds.end(), std::nan(""));
         blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
         std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
+        if (poison && *poison == '1') std::fill(work.begin(), work.end(), std::nan(""));
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {

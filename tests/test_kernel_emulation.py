@@ -68,6 +68,33 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
 
 
+@pytest.mark.parametrize('variant,start', [('both', 'reference'), ('rg', 'reference'), ('both', 'profile')])
+def test_emulated_kernels_read_no_shared_memory_before_writing_it(emu, variant, start, monkeypatch):
+    """
+    EMU_POISON=1: the emulated workgroup's LDS and work area start as NaN instead of zero.  On the device a read of shared memory before its first write
+    sees what the kernel before left there -- the kind of fault that shows as a non-deterministic failure on the GPU and never in a zero-initialised
+    emulation.  First pass + follow-up kernel of both rolling-stock structures from both starting points: bit for bit the results of the zero-initialised
+    run, history included.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    train, track, N, T = (cases.train_fig10() if variant == 'rg' else cases.train_default()), cases.track_00(30000), 70, 1100.0
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint=start)
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    runs = {}
+    for poison in ('0', '1'):
+        monkeypatch.setenv('EMU_POISON', poison)
+        z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.zeros((1, ST['COUNT'])), np.zeros((40, 8))
+        assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 40) == 0
+        assert st[0, ST['STATUS']] == 0
+        st[0, ST['CYC_TOTAL']] = st[0, ST['CYC_KKT']] = 0      # (time stamps)
+        runs[poison] = (z, lam, st, hist)
+    for a, b in zip(runs['0'], runs['1']):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('N,start', [(70, 'profile'), (70, 'reference'), (40, 'profile')])
 def test_emulated_one_brake_kernels_match_oracle(emu, N, start):
     """
