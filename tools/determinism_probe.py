@@ -12,7 +12,7 @@ from mseetc._device import ST
 from test_gpu_parity import _random_problem, _solver
 np.set_printoptions(linewidth=220, precision=4)
 seed, k = int(sys.argv[1]), int(sys.argv[2])
-factors = [1.05, 1.1, 1.2, 1.45, 2.0]
+factors = [1.05, 1.1, 1.2, 1.45, 2.0] if len(sys.argv) < 4 else [float(x) for x in sys.argv[3].split(',')]      # (third argument: the running times, as multiples of the minimum)
 with tempfile.TemporaryDirectory() as tmp:
     train, track, N, rng = _random_problem(seed, Path(tmp))
     v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
