@@ -3357,6 +3357,15 @@ struct Solver {
             nd.bind(work + nd.i);
             resc[j].bind(work + W_RESC*NS + nd.i); resd[j].bind(work + W_RESD*NS + nd.i);
             evs[j].bind(work + W_EV*NS + nd.i); lgs[j].bind(work + W_LG*NS + nd.i);
+            if constexpr (!STREAM) {
+                /* defined values in the interval derivatives of every node slot.  They are written for intervals only (store_ev) and loaded for every slot
+                 * (load_ev, stash): a register read before it was written -- harmless as long as the value went unused, which held for every library up to
+                 * the end of round 5, when a header change that compiled to the same code elsewhere made the one-brake follow-up kernels non-deterministic
+                 * from the reference's starting point (status -3 at iteration 0; profiles/r05/README.md).  Very likely round 4's unexplained fault of the
+                 * 64 x 1 follow-up kernel as well (profiles/r05/follow_64x1_fault.md) */
+#pragma unroll
+                for (int k = 0; k < 13; k++) evs[j][k] = 0.0;
+            }
             const bool ival = nd.i < N, node = nd.i <= N;
             nd.ds = ival ? P.ds[nd.i] : 0.0;
             nd.G = ival ? track_resistance(P, P.grad[nd.i], P.curv[nd.i]) : 0.0;
