@@ -93,6 +93,9 @@ def parse_args(argv=None):
                     help='the transcription of the reference\'s options the workload is solved with (default: RK4 + trapezoidal time, simulations/config.json)')
     ap.add_argument('--single-process', action='store_true',
                     help='one process drives all --gpus devices (one handle and stream per device), no torch.distributed')
+    ap.add_argument('--process-group', action='store_true',
+                    help='form the rank process group (RCCL) also at world size 1 and run the barrier and the reductions through it: a smoke test of the '
+                         'multi-GPU code path on a one-GPU box (no scaling claim comes out of it)')
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = dict(c1=500, c2=50, c3=100, c4=5)[args.workload]
@@ -429,9 +432,12 @@ def main():
     red_dev = 'cpu' if share else 'cuda'
 
     backend = None      # what carries the barrier and the reductions between the ranks (the data path has no collective)
-    if world > 1:
+    grouped = world > 1 or (args.process_group and not args.single_process)      # (--process-group: the same code at world size 1)
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1 and 'MASTER_PORT' not in os.environ:
+            os.environ['MASTER_PORT'] = str(free_port())
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
             backend = 'gloo (MSD_BENCH_SHARE_DEVICES=1: ranks share devices, RCCL refuses that)'
@@ -460,7 +466,7 @@ def main():
 
     def group_fields():
         "process-group facts of a multi-rank line: backend, ranks seen by a reduction, the device of every rank"
-        if world == 1:
+        if not grouped:
             return {"process_group_backend": None, "world_size_seen": 1, "device_of_rank": [local_rank]}
         seen = torch.ones(1, dtype=torch.int64, device=red_dev)
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
@@ -471,7 +477,7 @@ def main():
 
     def barrier(sync_only=False):
         torch.cuda.synchronize()
-        if world > 1 and not sync_only:
+        if grouped and not sync_only:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -487,7 +493,7 @@ def main():
         N = args.intervals or N
         T = wl.c1_times(B, seed=20260615 + rank)
         elapsed, info = measure_mpc(train, track, N, T, args.steps, args.warmup, local_rank, warm=True, barrier=barrier)
-        if world > 1:
+        if grouped:
             t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -520,7 +526,7 @@ def main():
             line["config"].update(gf)
             line["roofline"]["launch_ms_note"] = "device time of one whole loop (events around its 50 re-solves: solver launches and bookkeeping kernels, shrinking horizons)"
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return 0
 
@@ -534,7 +540,7 @@ def main():
         elapsed, launch_ms, st = measure(solver, scen, overrides, args.steps, args.warmup, barrier)
         first_ms, listed = (measure.first_pass_ms or None), measure.listed_per_launch
 
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -543,7 +549,7 @@ def main():
     iters = st[:, ST['ITERS']]
 
     by_rank = None
-    if world > 1:
+    if grouped:
         ok = torch.tensor([n_ok], dtype=torch.int64, device=red_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.SUM)
         n_ok_all = int(ok.item())
@@ -597,7 +603,7 @@ def main():
 
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
     return 0

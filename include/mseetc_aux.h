@@ -27,6 +27,13 @@ int msd_host_alloc(unsigned long long bytes, void **ptr);
 int msd_host_free(void *ptr);
 
 /*
+ * Tuning switches of the kernel pickers for the problems created afterwards (process-wide; A/B measurements and one GPU test -- the library itself reads no
+ * environment variable).  "no_full" != 0: the kernels without the structure of the NLP compiled in; "two_nodes_per_lane" != 0: the 64 x 2 geometry for
+ * horizons of 64 ... 127 intervals of the shooting-integrator and integrateLosses families (default 128 x 1).  Unknown name: MSD_E_INVALID.
+ */
+int msd_tuning(const char *name, int value);
+
+/*
  * Test hook: the reciprocal and the square root / reciprocal square root of the fused interior-point iteration (csrc/msd_fastmath.hpp: v_rcp_f64 /
  * v_rsq_f64 refined without the compiler's range scaling) evaluated on n operands, so that the GPU tests can bound their error against the IEEE
  * operations (tests/test_gpu_parity.py::test_fast_reciprocal_and_square_root: <= 1 ulp on normal operands).  Errors: msd_interval_last_error().

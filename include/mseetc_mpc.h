@@ -26,7 +26,7 @@ enum { MSD_MPC_T0 = 0,        /* measured time the re-solve starts from */
        MSD_MPC_V0,            /* measured speed (before the clipping of ocp.py:343) */
        MSD_MPC_T,             /* arrival time of the re-solve (moved where the measured state no longer allowed the one asked for) */
        MSD_MPC_STATUS, MSD_MPC_ITERS, MSD_MPC_OBJ,      /* MSD_ST_STATUS / _ITERS / _OBJ of the re-solve's last launch for the scenario */
-       MSD_MPC_RELAXED,       /* 1: the arrival time was moved in this re-solve */
+       MSD_MPC_RELAXED,       /* > 0: the arrival time was moved in this re-solve -- 1 on the verdict of a converged time-optimal twin, 2 on that of a twin that ended next to its optimum without converging */
        MSD_MPC_COUNT };
 
 typedef struct {

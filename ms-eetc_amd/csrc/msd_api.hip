@@ -25,6 +25,10 @@ namespace {
 thread_local std::string g_err;
 }
 
+namespace msd {
+Tuning &tuning() { static Tuning t; return t; }
+}
+
 namespace msd_host {
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 }
@@ -64,8 +68,10 @@ int check_desc(const msd_problem_desc *d)
         if (!d->coll_tables) return fail(MSD_E_INVALID, "collocation integrator without its tables");
     }
     if (d->integrator == MSD_INTEGRATOR_ADAPTIVE && (!(d->int_abstol > 0) || !(d->int_reltol > 0))) return fail(MSD_E_INVALID, "tolerances of the adaptive integrator must be positive");
-    if (d->integrate_losses && d->energy_optimal && d->loss_kind != 1)
-        return fail(MSD_E_UNSUPPORTED, "integrateLosses runs with constant efficiencies (loss_kind 1)");
+    if (d->integrate_losses && d->energy_optimal && d->loss_kind == 0)
+        return fail(MSD_E_UNSUPPORTED, "integrateLosses needs a loss model (loss_kind 1 or 2)");
+    if (d->integrate_losses && d->energy_optimal && d->loss_kind == 2 && d->integrator != 0)
+        return fail(MSD_E_UNSUPPORTED, "integrateLosses with a loss table runs with explicit Runge-Kutta shooting (integrator 0)");
     return MSD_OK;
 }
 
@@ -119,18 +125,19 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     const bool dyn = d->loss_kind == 2;
     const bool gen = d->integrator != 0, intloss = d->integrate_losses != 0 && d->energy_optimal != 0;
     const bool wide = dyn || intloss;      /* stage blocks with the slack-b and slack-Fpb couplings */
+    const bool itab = dyn && intloss;      /* the loss table integrated over the running time (msd_lossint_table.hpp: DYN = LOSS_INTEGRATED_TABLE) */
     /* both brakes, power rows (finite by construction: ocp.py:186-187), energy objective, finite acceleration bounds (ocp.py:113-114) */
     const bool full = d->with_pn_brake != 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                       && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
     /* the same without the pneumatic brake (forceMinPn = 0: the reference's scripts); static loss rows + explicit Runge-Kutta shooting only */
     const bool full_rg = d->with_pn_brake == 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                          && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
-    msd::Geometry geo = (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
+    msd::Geometry geo = itab ? msd::pick_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
                         : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
     size_t lds = geo.fn ? sizeof(double)*(size_t)(msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) + msd::coop_doubles(geo.NT, gen) + geo.extra) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
-        geo = (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
+        geo = itab ? msd::pick_stream_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
               : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
         lds = sizeof(double)*(size_t)msd::lds_doubles_stream();
         if (!geo.fn)
@@ -144,7 +151,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
-    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
+    P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.socSeen = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = P.grad = P.curv = P.bmax = P.pos = nullptr;      /* (the owner of the profile buffer fills these) */
     P.loss = nullptr;
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
@@ -182,7 +189,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
          * stock compiled in): a first-pass kernel -- the general iteration without the restoration phase and the watchdog procedure; a scenario that needs
          * either is followed up by the streamed kernel of the family (msd_kernel.hpp: FAMILY_HAS_RESTO, WD_HANDOVER).  The follow-up restarts the
          * scenario, so the two geometries need not agree */
-        const msd::Geometry g2 = (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N)
+        const msd::Geometry g2 = itab ? msd::pick_stream_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N)
                                  : intloss ? msd::pick_stream_geometry_intloss(N) : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
         if (!g2.fn2) return fail(MSD_E_UNSUPPORTED, "no follow-up kernel for numIntervals = " + std::to_string(N));
         geo.fn2 = g2.fn2; pl.NT2 = g2.NT; pl.SPT2 = g2.SPT;
@@ -204,6 +211,12 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     pl.work_doubles = geo.stream ? msd::stream_doubles(N, geo.NT*geo.SPT, wide) : std::max(work2, msd::work_doubles(std::max(geo.NT*geo.SPT, work2 ? 0 : pl.NT2*pl.SPT2)));
     pl.nz = (4 + P.withPn)*N + 2; pl.nl = ((P.hasPower ? 2 : 0) + 3 + (P.energyOpt ? 2 : 0))*N;
     pl.kernel = geo.fn; pl.kernel2 = geo.fn2; pl.kernel_lsq = geo.fn_lsq;
+    pl.kernel_soc = nullptr;
+    if (geo.fn_soc) {
+        /* (same launch as `kernel`; taken only when it is as resident) */
+        int per_cu_soc = 0;
+        if (kernel_limits(device, (const void *)geo.fn_soc, geo.NT, lds, &per_cu_soc) == MSD_OK && per_cu_soc*cus >= pl.max_grid) pl.kernel_soc = geo.fn_soc;
+    }
     return MSD_OK;
 }
 
@@ -212,7 +225,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
 {
     if (!pl.kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
     msd::DevProb P = pl.P;
-    P.follow = nullptr; P.list = nullptr; P.queue = nullptr;
+    P.follow = nullptr; P.list = nullptr; P.queue = nullptr; P.socSeen = ws.d_soc_seen;
     P.guess = ws.d_guess; P.guessStride = ws.stride; P.guessStatus = ws.d_status; P.warmMu = ws.mu; P.warmPush = ws.push;
     P.dualIn = ws.d_dual_in; P.dualInStride = ws.dual_stride; P.dualShift = ws.dual_shift; P.dualOut = ws.d_dual_out;
     P.oneAttempt = ws.one_attempt ? 1 : 0;
@@ -233,7 +246,7 @@ int launch_plan(const Plan &pl, hipStream_t stream, double *d_work, int *d_follo
     /* split solves (msd::Geometry::fn2): first pass + follow-up kernel behind it on the stream, the list of unfinished scenarios between them.
      * The first pass is the kernel without the least-squares multiplier estimate when every scenario can start without it (profile start,
      * primal-dual warm start), the one with it otherwise (the reference's starting point, a primal-only warm start) */
-    const msd::KernelFn fn = (split && !first_pass) ? pl.kernel2 : plain ? pl.kernel : pl.kernel_lsq;
+    const msd::KernelFn fn = (split && !first_pass) ? pl.kernel2 : plain ? ((ws.use_soc && pl.kernel_soc) ? pl.kernel_soc : pl.kernel) : pl.kernel_lsq;
     const int cap = (split && !first_pass) ? pl.max_grid2 : plain ? pl.max_grid : pl.max_grid_lsq;
     const int grid = nscen < cap ? nscen : cap;
     const int threads = (split && !first_pass) ? pl.NT2 : pl.NT;
@@ -275,6 +288,15 @@ using msd_host::check_desc;
 extern "C" {
 
 const char *msd_last_error(void) { return g_err.c_str(); }
+
+int msd_tuning(const char *name, int value)
+{
+    if (!name) return fail(MSD_E_INVALID, "null argument");
+    if (!strcmp(name, "no_full")) msd::tuning().no_full = value != 0;
+    else if (!strcmp(name, "two_nodes_per_lane")) msd::tuning().two_nodes_per_lane = value != 0;
+    else return fail(MSD_E_INVALID, std::string("unknown tuning switch: ") + name);
+    return MSD_OK;
+}
 
 int msd_device_count(void)
 {
@@ -361,7 +383,13 @@ static int configure(msd_problem *h, const msd_problem_desc *d)
         h->prev_nscen = 0;
         h->cap_nz = nz; h->cap_nl = nl;
     }
-    h->kernel = pl.kernel; h->kernel2 = pl.kernel2; h->kernel_lsq = pl.kernel_lsq;
+    h->kernel = pl.kernel; h->kernel2 = pl.kernel2; h->kernel_lsq = pl.kernel_lsq; h->kernel_soc = pl.kernel_soc;
+    if (h->kernel_soc && !h->h_soc_seen) {
+        /* one word of page-locked host memory the kernels can write: "a launch of this handle handed a second-order correction over" */
+        HIP_TRY(hipHostMalloc((void **)&h->h_soc_seen, sizeof(int), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&h->d_soc_seen, (void *)h->h_soc_seen, 0));
+    }
+    if (h->h_soc_seen) *h->h_soc_seen = 0;      /* (another problem: the verdict starts afresh; the stream was synchronised above) */
     return MSD_OK;
 }
 
@@ -403,6 +431,7 @@ int msd_problem_destroy(msd_handle h)
     hipFree(h->d_scen); hipFree(h->d_ovr); hipFree(h->d_z); hipFree(h->d_lam); hipFree(h->d_stats); hipFree(h->d_hist); hipFree(h->d_guess); hipFree(h->d_eval);
     hipFree(h->d_z2); hipFree(h->d_stats2); hipFree(h->d_dual); hipFree(h->d_dual2); hipFree(h->d_coll);
     if (h->h_stage) hipHostFree(h->h_stage);
+    if (h->h_soc_seen) hipHostFree((void *)h->h_soc_seen);
     for (int k = 0; k < msd_problem::FP_RING; k++) { if (h->fp_beg[k]) hipEventDestroy(h->fp_beg[k]); if (h->fp_end[k]) hipEventDestroy(h->fp_end[k]); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -423,16 +452,26 @@ static msd_host::Plan plan_of(const msd_problem *h)
 {
     msd_host::Plan pl;
     pl.P = h->P; pl.NT = h->NT; pl.SPT = h->SPT; pl.lds_bytes = h->lds_bytes; pl.stream = h->stream_kernel;
-    pl.kernel = h->kernel; pl.kernel_lsq = h->kernel_lsq; pl.kernel2 = h->kernel2; pl.NT2 = h->NT2; pl.SPT2 = h->SPT2; pl.lds_bytes2 = h->lds_bytes2;
+    pl.kernel = h->kernel; pl.kernel_lsq = h->kernel_lsq; pl.kernel2 = h->kernel2; pl.kernel_soc = h->kernel_soc; pl.NT2 = h->NT2; pl.SPT2 = h->SPT2; pl.lds_bytes2 = h->lds_bytes2;
     pl.max_grid = h->max_grid; pl.max_grid_lsq = h->max_grid_lsq; pl.max_grid2 = h->max_grid2; pl.fused_family = h->fused_family;
     pl.work_doubles = h->work_per_wg; pl.nz = msd_problem_nz(const_cast<msd_problem *>(h)); pl.nl = msd_problem_rows_per_interval(const_cast<msd_problem *>(h))*h->P.N;
     return pl;
 }
 
 static int launch(msd_handle h, int nscen, const double *d_scen, const double *d_ovr, double *d_z, double *d_lam, double *d_stats, double *d_hist, int hist_cap,
-                  const WarmStart &ws = WarmStart())
+                  const WarmStart &ws_in = WarmStart())
 {
     if (!h->kernel) return fail(MSD_E_INVALID, "the handle holds no problem: its last (re)configuration failed");
+    /* Second-order corrections (IPOPT's default behaviour, ocp.py:290): the first-pass kernel of the benchmark geometries hands a scenario that needs one to
+     * the follow-up kernel, whose general iteration solves it again from its starting point -- one such scenario is the tail of its launch (config 3: 1.3 ms
+     * behind a 6.3 ms first pass).  A handle whose launches have met one takes the first-pass kernel with the correction inside the fused iteration from
+     * then on (msd_kernel.hpp: SOCK; 4 % slower per iteration, no tail); the kernels report it through a word of mapped host memory, read here without
+     * waiting for anything */
+    WarmStart ws = ws_in;
+    if (h->kernel_soc) {
+        ws.d_soc_seen = h->d_soc_seen;
+        if (*h->h_soc_seen != 0) ws.use_soc = true;
+    }
     if (h->kernel2) {
         const size_t need = msd::FOLLOW_HDR + 2*(size_t)nscen;
         if (need > h->cap_follow) {

@@ -19,11 +19,19 @@ struct Geometry {
     KernelFn fn2 = nullptr;              /* not null: `fn` is the first pass of a split solve (solve_kernel's PART = 1) and this the follow-up kernel (PART = 2) */
     KernelFn fn_lsq = nullptr;           /* first pass with the least-squares multiplier estimate in front (PART = 3): launches from the reference's starting point or a primal-only warm start */
     int extra = 0;                       /* doubles of LDS behind the layout of lds_doubles (the SLDS instantiations' node constants) */
+    KernelFn fn_soc = nullptr;           /* `fn` with the second-order correction inside the fused iteration (SOCK: msd_kernels_full4.hip), same launch */
 };
+
+/* tuning switches of the pickers, set through msd_tuning() of include/mseetc_aux.h (A/B runs, one GPU test): the library reads no environment variable.
+ * no_full: the kernels without the structure of the NLP compiled in; two_nodes_per_lane: the 64 x 2 geometry for 65 ... 128 nodes of the shooting-integrator
+ * and integrateLosses families (default there: 128 x 1) */
+struct Tuning { bool no_full = false, two_nodes_per_lane = false; };
+Tuning &tuning();      /* (msd_api.hip) */
 
 Geometry pick_geometry_static(int N, int full);     /* full: FULL_BOTH / FULL_RG -- the kernels with that structure compiled in (0: none) */
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
 KernelFn follow_kernel_full(int NT, int SPT);       /* follow-up kernels of that family (msd_kernels_full3.hip) */
+KernelFn soc_kernel_full(int NT, int SPT, bool slds);      /* msd_kernels_full4.hip; nullptr: none for this geometry */
 Geometry pick_geometry_full_rg(int N);                /* the same with the regenerative brake alone (FULL_RG: msd_kernels_rg.hip, msd_kernels_rg2.hip) */
 KernelFn follow_kernel_full_rg(int NT, int SPT);
 Geometry pick_geometry_dynamic(int N);
@@ -31,6 +39,8 @@ Geometry pick_stream_geometry_static(int N);
 Geometry pick_geometry_general_long(int N);      /* 257 ... 640 nodes of the same family (msd_kernels_general2.hip) */
 Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */
+Geometry pick_geometry_intloss_table(int N);          /* integrateLosses with a loss table (msd_lossint_table.hpp): LDS-resident first-pass kernels up to 127 intervals (msd_kernels_intloss_table.hip) */
+Geometry pick_stream_geometry_intloss_table(int N);   /* ... the streamed pair of that family, up to 1023 intervals (msd_kernels_intloss_table2.hip) */
 Geometry pick_geometry_general_dynamic(int N);      /* collocation / adaptive shooting integrators with the dynamic loss model (msd_kernels_compose.hip) */
 Geometry pick_geometry_general_intloss(int N);      /* collocation / adaptive shooting integrators with integrateLosses (msd_kernels_compose.hip) */
 /* the other transcriptions beyond the LDS-resident horizons, up to 1023 intervals (msd_kernels_stream3.hip): dynamic loss model, collocation /

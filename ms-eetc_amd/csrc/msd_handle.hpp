@@ -31,6 +31,7 @@ struct Plan {
     msd::KernelFn kernel = nullptr;                   /* complete kernel, or the first pass of a split solve (kernel2 != nullptr) */
     msd::KernelFn kernel_lsq = nullptr;               /* first pass for launches that need the least-squares multiplier estimate (msd::Geometry::fn_lsq) */
     msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2) */
+    msd::KernelFn kernel_soc = nullptr;               /* `kernel` with the second-order correction inside the fused iteration (msd::Geometry::fn_soc): WarmStart::use_soc */
     int NT2 = 0, SPT2 = 0;                            /* its own launch geometry (it restarts a scenario from its starting point, so it need not share the first pass's) */
     size_t lds_bytes2 = 0;
     int max_grid = 0, max_grid_lsq = 0, max_grid2 = 0;      /* resident workgroups of the three */
@@ -44,7 +45,9 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out);      /* (check_
 
 struct WarmStart { const double *d_guess = nullptr; long long stride = 0; const double *d_status = nullptr; double mu = 0, push = 0;
                    const double *d_dual_in = nullptr; long long dual_stride = 0; int dual_shift = 0; double *d_dual_out = nullptr;
-                   bool one_attempt = false; };      /* one_attempt: a solve that breaks down is not repeated from the other starting point (msd_mpc.hip: the loop certifies it first) */
+                   bool one_attempt = false;         /* a solve that breaks down is not repeated from the other starting point (msd_mpc.hip: the loop certifies it first) */
+                   bool use_soc = false;             /* the first-pass kernel with the second-order correction inside (Plan::kernel_soc), where the plan has one */
+                   int *d_soc_seen = nullptr; };     /* DevProb::socSeen of the launch (device address of a mapped host word) */
 
 /*
  * One batch on `stream`: the first pass + the follow-up kernel of a split solve, or the one kernel that holds everything.
@@ -70,6 +73,9 @@ struct msd_problem {
     msd::KernelFn kernel_lsq = nullptr;               /* first pass for launches that need the least-squares multiplier estimate (msd::Geometry::fn_lsq) */
     int max_grid_lsq = 0;
     msd::KernelFn kernel2 = nullptr;                  /* follow-up kernel of a split solve (msd::Geometry::fn2), its resident workgroups and the list between the two */
+    msd::KernelFn kernel_soc = nullptr;               /* first pass with the second-order correction inside the fused iteration (msd::Geometry::fn_soc; same launch as `kernel`) */
+    volatile int *h_soc_seen = nullptr;               /* mapped host word: a launch of the handle handed a second-order correction over (launch() then takes kernel_soc) */
+    int *d_soc_seen = nullptr;                        /* its device address */
     int max_grid2 = 0;
     int NT2 = 0, SPT2 = 0; size_t lds_bytes2 = 0;     /* launch geometry of the follow-up kernel */
     int *d_follow = nullptr; size_t cap_follow = 0;

@@ -145,7 +145,7 @@ __device__ __forceinline__ T irk_b_small(const DevProb &P, T b0, T w, double G, 
     T xb = b0, xt = t ? *t : jconst(T(), 0.0);
     for (int k = 0; k < P.numSteps; k++) {
         double v[D], F[D];
-        LuSmall<D> L;
+        LuSmall<D> L = {};      /* (defined also where the Newton loop below does not run at all: OptionsIRK.maxIter < 0 is rejected by the host, which the compiler cannot know) */
         const double xv = jval(xb);
         bool valid = true;
 #pragma unroll

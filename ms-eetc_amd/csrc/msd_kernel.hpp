@@ -108,6 +108,8 @@ struct DevProb {
     int *follow;
     int *list;               /* not null: the kernel solves the scenarios of this list only (same layout as `follow`: the follow-up kernel's input is the first pass's
                               * `follow`; a first-pass kernel can be given a list too -- msd_mpc.hip's re-solves -- and hands over through `follow` as usual) */
+    int *socSeen;            /* not null: a word of host memory mapped into the device; a first-pass kernel that hands a scenario over for a second-order correction sets it,
+                              * and the handle's next launches take the first-pass kernel that has the correction inside its fused iteration (msd_api.hip: launch) */
 };
 /* behind the three counters: telemetry that is never reset -- [3] scenarios listed so far, [4 + why] by reason: 0 no fused start for the scenario
  * (a warm start whose previous solve failed), 1 wrong inertia or a scan breakdown, 2 tiny step, 3 first trial point rejected where a
@@ -136,7 +138,10 @@ constexpr int RPW0 = 0, RPW1 = 1, RACC = 2, RLTR = 3, RLRG = 4, NR = 5;
 /* DYN (template parameter of the kernels): loss transcription -- 0 constant efficiencies at the mid-point speed (ocp.py:221-226), 1 dynamic
  * table (efficiency.py), 2 constant efficiencies integrated over the running time (integrateLosses, ocp.py:231-241; msd_lossint.hpp).
  * 1 and 2 couple the loss slack with b and Fpb and use the wider stage block */
-constexpr int LOSS_STATIC = 0, LOSS_TABLE = 1, LOSS_INTEGRATED = 2;
+constexpr int LOSS_STATIC = 0, LOSS_TABLE = 1, LOSS_INTEGRATED = 2, LOSS_INTEGRATED_TABLE = 3;
+/* (3, round 6: the loss table integrated over the running time -- integrateLosses with the dynamic loss model or a tabulated loss function, msd_lossint_table.hpp;
+ *  2 and 3 share everything that comes from the rows' dependence on the running time t_{i+1} - t_i) */
+__host__ __device__ constexpr bool loss_integrated(int dyn) { return dyn == LOSS_INTEGRATED || dyn == LOSS_INTEGRATED_TABLE; }
 /* FULL (template parameter of the kernels): structure of the NLP known at compile time -- 0 nothing (row set, brakes and objective read from the
  * problem record), 1 both brakes + power rows + energy objective (the rolling stock of the reference's JSON files: BASELINE configs 1-4),
  * 2 the same with the regenerative brake alone (forceMinPn = 0: what every script of the reference sets -- figure5.py:88, figure6.py:108,
@@ -202,6 +207,12 @@ constexpr int RED_DOUBLES = RED_SLOTS*MAX_WAVES*RED_K;      /* cross-wave reduct
 #define MSD_STATIC_LDS 1
 #endif
 constexpr int STATIC_FIELDS = 5;
+/* SOCK (template parameter of the fused first-pass kernels, round 5): the second-order correction (W&B section 2.4) inside the fused iteration, as passes of its
+ * loop over the same point (Solver::run: soc_mode) instead of a handover to the follow-up kernel.  Config 4's warm loop runs at 289 k instead of 217 k successful
+ * re-solves/s with it -- but the loop's extra control flow costs the hot path 4.5 % (config 1: 86.0 k instead of 81.6 k cycles per iteration, also with the
+ * correction's loads and stores compiled out: the register allocator's answer to the control flow).  So it is an instantiation of its own (msd_kernels_full4.hip),
+ * every line of it behind `if constexpr (SOCK)` -- the other instantiations compile what they compiled before -- and taken where corrections are the rule: the
+ * re-solves of msd_mpc.hip (WarmStart::use_soc) */
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NS, bool dyn, int nxch = XCH_GENERAL, int red = RED_DOUBLES)
 {
     return stage_stride(dyn)*(N + 1) + nxch*NS + 2*FILT_CAP + red + 32 + CONST_DOUBLES;
@@ -404,22 +415,30 @@ __device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, doub
  * In the linear-extension branch the third derivative that g_vv would need is dropped: that branch is not active at a solution
  * and only Newton's curvature is affected, not the NLP (same convention as the oracle).
  */
-__device__ __forceinline__ void loss_rows(const DynLoss &D, double f, double v, double (&lr)[2][6])
+/* the split loss power itself (utils.py:197-220; specific, W/kg): l = {L, L_f, L_v, L_ff, L_fv, L_vv} of the traction part (row 0) or the regenerative-brake
+ * part (row 1) at (f, v); beta = spec_losses(D, true, 0, v) */
+__device__ __forceinline__ void loss_split(const DynLoss &D, const int row, double f, double v, const Jet &beta, double (&l)[6])
 {
     const double tol = 1e-10;
+    const bool traction = (row == 0);
+    const bool truth = traction ? (f >= 0) : (f < 0);
+    if (truth) {
+        const Jet s = spec_losses(D, traction, f, v);
+        l[0] = s.v; l[1] = s.g0; l[2] = s.g1; l[3] = s.h00; l[4] = s.h01; l[5] = s.h11;
+    } else {
+        const Jet a = spec_losses(D, traction, traction ? tol : -tol, v);
+        l[0] = a.g0*f + beta.v; l[1] = a.g0; l[2] = a.h01*f + beta.g1; l[3] = 0; l[4] = a.h01; l[5] = beta.h11;
+    }
+}
+
+__device__ __forceinline__ void loss_rows(const DynLoss &D, double f, double v, double (&lr)[2][6])
+{
     const Jet beta = spec_losses(D, true, 0.0, v);
 #pragma unroll
     for (int row = 0; row < 2; row++) {
-        const bool traction = (row == 0);
-        const bool truth = traction ? (f >= 0) : (f < 0);
-        double L, Lf, Lv, Lff, Lfv, Lvv;
-        if (truth) {
-            const Jet s = spec_losses(D, traction, f, v);
-            L = s.v; Lf = s.g0; Lv = s.g1; Lff = s.h00; Lfv = s.h01; Lvv = s.h11;
-        } else {
-            const Jet a = spec_losses(D, traction, traction ? tol : -tol, v);
-            L = a.g0*f + beta.v; Lf = a.g0; Lv = a.h01*f + beta.g1; Lff = 0; Lfv = a.h01; Lvv = beta.h11;
-        }
+        double l[6];
+        loss_split(D, row, f, v, beta, l);
+        const double L = l[0], Lf = l[1], Lv = l[2], Lff = l[3], Lfv = l[4], Lvv = l[5];
         const double iv = 1/v;
         lr[row][0] = L*iv;
         lr[row][1] = Lf*iv;
@@ -429,6 +448,8 @@ __device__ __forceinline__ void loss_rows(const DynLoss &D, double f, double v, 
         lr[row][5] = Lvv*iv - 2*Lv*iv*iv + 2*L*iv*iv*iv;
     }
 }
+
+#include "msd_lossint_table.hpp"
 
 __device__ __forceinline__ double track_resistance(const DevProb &P, double grad, double curv)
 {
@@ -620,16 +641,17 @@ template <int CNT, int NS> struct Field<CNT, NS, true> {
 
 /* layout of the work area, in fields of NS doubles */
 constexpr int W_X = 0, W_SG = 5, W_LAM = 10, W_NU = 12, W_ZL = 17, W_ZU = 22, W_ZLS = 27, W_ZUS = 32, W_DSG = 37, W_RESC = 42, W_RESD = 44,
-              W_EV = 49, W_LG = 62, W_FIELDS_ITERATE = 72;
+              W_EV = 49, W_LG = 62, W_LG_FIELDS = 30, W_FIELDS_ITERATE = W_LG + W_LG_FIELDS;      /* (W_LG: 2 x 5 derivatives of the loss rows, 2 x 15 with an integrated loss table) */
 /* behind the iterate: what the feasibility restoration phase keeps (msd_resto.hpp; kernels whose horizon fits the LDS only).  Row scaling of the
  * dynamics (2), the relaxation variables n, p and their multipliers per relaxed row (4 x 7), their steps (4 x 7), the reference point (x 5,
  * sigma 5), the bound multipliers of the original problem (20), D of the two dynamics rows (2), the steps of the row multipliers (5), the filter of
  * the restoration problem (2 fields >= 2 FILT_CAP doubles), one field of scalars handed between the two iterations and five fields (>= 320
  * doubles) for the dense temporaries of riccati_resto -- on the stack they would size the scratch memory of every launch of the kernel */
-constexpr int W_SC = 72, W_RN = 74, W_RP = 81, W_RZN = 88, W_RZP = 95, W_RDN = 102, W_RDP = 109, W_RDZN = 116, W_RDZP = 123, W_XR = 130, W_SGR = 135,
-              W_OZL = 140, W_OZU = 145, W_OZLS = 150, W_OZUS = 155, W_RD = 160, W_DNU = 162, W_RFILT = 167, W_SCAL = 169, W_RTMP = 170;
+constexpr int W_SC = W_FIELDS_ITERATE, W_RN = W_SC + 2, W_RP = W_SC + 9, W_RZN = W_SC + 16, W_RZP = W_SC + 23, W_RDN = W_SC + 30, W_RDP = W_SC + 37, W_RDZN = W_SC + 44,
+              W_RDZP = W_SC + 51, W_XR = W_SC + 58, W_SGR = W_SC + 63, W_OZL = W_SC + 68, W_OZU = W_SC + 73, W_OZLS = W_SC + 78, W_OZUS = W_SC + 83, W_RD = W_SC + 88,
+              W_DNU = W_SC + 90, W_RFILT = W_SC + 95, W_SCAL = W_SC + 97, W_RTMP = W_SC + 98;
 /* behind that: the reference point of the watchdog procedure -- a copy of the iterate's fields W_X ... W_ZUS in the same order (Solver::wd_restore) */
-constexpr int W_WD = 175, W_WD_FIELDS = 37;
+constexpr int W_WD = W_SC + 103, W_WD_FIELDS = 37;
 static_assert(W_DSG == W_WD_FIELDS, "the iterate proper: the fields in front of the slack steps");
 /* behind that: what assemble(MODE_RESTO) hands to riccati_resto next to the stage blocks when the loss rows depend on the running time (integrateLosses):
  * curvature and gradient of the rows' share in d = t_{i+1} - t_i -- W_dd, W_bd, W_fd, W_pd, W_sd, h_d */
@@ -710,8 +732,9 @@ __device__ __forceinline__ double uni(double v)
 struct Ev {
     double sb, sb1, b1;
     double tb, tw, tbb, tbw, tww, Bb, Bw, Bbb, Bbw, Bww;
-    double lg[2][5];     /* dynamic loss rows: g_f, g_v, g_ff, g_fv, g_vv of the traction / brake row at (f, vbar);
-                          * integrated losses: X, X_v, X_d, X_w, X_vv | X_vd, X_vw, X_dd, X_dw, X_ww (d = running time) */
+    double lg[2][15];    /* dynamic loss rows: g_f, g_v, g_ff, g_fv, g_vv of the traction / brake row at (f, vbar);
+                          * integrated losses: X, X_v, X_d, X_w, X_vv | X_vd, X_vw, X_dd, X_dw, X_ww (d = running time);
+                          * integrated loss table: E_k and its 4 + 10 derivatives wrt (v, d, w, f) per row (Jet4);  the kernels keep LGW entries per row */
 };
 
 /* values of the interval functions at x: c (dynamics defects) and d (inequality rows) */
@@ -739,7 +762,29 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
     dv[RPW0] = U.rs[RPW0]*f*sb;                                             /* ocp.py:189 */
     dv[RPW1] = U.rs[RPW1]*f*sb1;
     dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nG);     /* ocp.py:199 */
-    if (DYN == LOSS_INTEGRATED) {
+    if (DYN == LOSS_INTEGRATED_TABLE) {
+        /* ocp.py:233-240 with a loss table: s - E_tr, s - E_rgb, E_k = int L_k(f, v(t)) dt over t1 - t (msd_lossint_table.hpp) */
+        const DynLoss D(P.loss, P.lossMass);
+        if (DERIV) {
+            Jet4 E[2];
+            loss_energy<Jet4>(P, D, sb, t1 - x[VT], f + p, f, nG, E);
+            dv[RLTR] = U.rs[RLTR]*(s - E[0].v);
+            dv[RLRG] = U.rs[RLRG]*(s - E[1].v);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                e.lg[k][0] = E[k].v;
+#pragma unroll
+                for (int m = 0; m < 4; m++) e.lg[k][1 + m] = E[k].g[m];
+#pragma unroll
+                for (int m = 0; m < 10; m++) e.lg[k][5 + m] = E[k].h[m];
+            }
+        } else {
+            double E[2];
+            loss_energy<double>(P, D, sb, t1 - x[VT], f + p, f, nG, E);
+            dv[RLTR] = U.rs[RLTR]*(s - E[0]);
+            dv[RLRG] = U.rs[RLRG]*(s - E[1]);
+        }
+    } else if (DYN == LOSS_INTEGRATED) {
         /* ocp.py:233-240: s - E_tr, s - E_rgb with E = int loss power dt over t1 - t = +-kappa f X(v, t1 - t, f + p) */
         if (DERIV) {
             const Jet3 X = loss_distance<Jet3>(P, sb, t1 - x[VT], f + p, nG);
@@ -1017,7 +1062,7 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
 #pragma unroll
         for (int a = 0; a < 6; a++) E[a][0] = E[a][1] = 0;
         if (DYN == LOSS_TABLE && !last) { E[1][1] = s[S_EB]; E[5][1] = s[S_ES]; }
-        if (DYN == LOSS_INTEGRATED) {
+        if (loss_integrated(DYN)) {
             const double Wdd = X[0*NS + i], Wbd = X[1*NS + i], Wfd = X[2*NS + i], Wpd = X[3*NS + i], Wsd = X[4*NS + i];
             /* d = t+ - t: entries at t are minus, at t+ plus the running time's (H_tt already carries W_dd, the next node's too: assemble) */
             H[0][1] = H[1][0] = -Wbd; H[0][3] = H[3][0] = -Wfd; H[0][4] = H[4][0] = -Wpd; H[0][5] = H[5][0] = -Wsd;
@@ -1239,7 +1284,7 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
         double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
         /* + E^T y */
         if (DYN == LOSS_TABLE && !last) g1 += s[S_EB]*x1 + s[S_ES]*dsl;
-        if (DYN == LOSS_INTEGRATED) g0 += -X[0*NS + i]*x0 + X[1*NS + i]*x1 + X[2*NS + i]*df + X[3*NS + i]*dp + X[4*NS + i]*dsl;
+        if (loss_integrated(DYN)) g0 += -X[0*NS + i]*x0 + X[1*NS + i]*x1 + X[2*NS + i]*df + X[3*NS + i]*dp + X[4*NS + i]*dsl;
         double lt, lb, nt, nb;
         if (last) { lt = -g0/(1 + Ptt*Dt); lb = u0/sqrt(Db); nt = at + Dt*lt; nb = 0; }
         else {
@@ -1676,7 +1721,7 @@ enum { MODE_NEWTON = 0, MODE_LSQ = 1, MODE_RESTO = 2 };      /* (MODE_RESTO: New
 
 /* PART: which part of a solve the enclosing kernel holds (solve_kernel) -- 0 everything, 1 the first pass (no restoration phase), 2 the follow-up,
  * 3 the first pass with the least-squares multiplier estimate in front (any starting point) */
-template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL, int PART = 0, bool SLDS = false>
+template <int NT, int SPT, int DYN, bool STREAM, bool GEN, int FULL, int PART = 0, bool SLDS = false, bool SOCK = false>
 struct Solver {
     static constexpr int S_STRIDE = stage_stride(DYN);
     static constexpr int NS = NT*SPT;      /* node slots of the workgroup */
@@ -1690,8 +1735,11 @@ struct Solver {
     Field<2, NS, STREAM> resc[SPT];
     Field<NR, NS, STREAM> resd[SPT];
     /* evaluation of the current point with derivatives (evaluate_current), read back by the phases that need it */
+    static constexpr bool INTEG = loss_integrated(DYN), ITAB = DYN == LOSS_INTEGRATED_TABLE;
+    static constexpr int LGW = ITAB ? 15 : 5;      /* derivatives kept per loss row (Ev::lg) */
+    static_assert(2*LGW <= W_LG_FIELDS, "room of the loss-row derivatives in the work area");
     Field<13, NS, STREAM> evs[SPT];
-    Field<10, NS, STREAM> lgs[SPT];
+    Field<2*LGW, NS, STREAM> lgs[SPT];
 
     __device__ __forceinline__ Solver(const DevProb &P_, Ctx &c_, double *work_, Uni &U_) : P(P_), c(c_), work(work_), U(U_) {}
 
@@ -1713,7 +1761,7 @@ struct Solver {
 #pragma unroll
             for (int k = 0; k < 2; k++)
 #pragma unroll
-                for (int m = 0; m < 5; m++) lgs[j][5*k + m] = e.lg[k][m];
+                for (int m = 0; m < LGW; m++) lgs[j][LGW*k + m] = e.lg[k][m];
         }
     }
     __device__ __forceinline__ void load_ev(int j, Ev &e) const
@@ -1723,7 +1771,7 @@ struct Solver {
 #pragma unroll
         for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int m = 0; m < 5; m++) e.lg[k][m] = DYN ? lgs[j][5*k + m] : 0.0;
+            for (int m = 0; m < LGW; m++) e.lg[k][m] = DYN ? lgs[j][LGW*k + m] : 0.0;
     }
     /* first-order part only (sb, sb1, b1, tb, tw, Bb, Bw and the loss-row gradients): what the residual pass and the read-back need */
     __device__ __forceinline__ void load_ev1(int j, Ev &e) const
@@ -1733,7 +1781,7 @@ struct Solver {
 #pragma unroll
         for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int m = 0; m < 5; m++) e.lg[k][m] = DYN ? lgs[j][5*k + m] : 0.0;
+            for (int m = 0; m < LGW; m++) e.lg[k][m] = DYN ? lgs[j][LGW*k + m] : 0.0;
     }
     /* explicit home of the register-resident iterate in the work area (same layout as the memory-backed fields): stash() writes the
      * fields of node j selected by the mask, fetch() reads them back.  Between a stash and the next fetch the values are dead in
@@ -1767,7 +1815,7 @@ struct Solver {
             if (M & H_ZS) { put<NR>(nd.zLs, W_ZLS, sl); put<NR>(nd.zUs, W_ZUS, sl); }
             if (M & H_DSG) put<NR>(nd.dsg, W_DSG, sl);
             if (M & H_RES) { put<2>(resc[j], W_RESC, sl); put<NR>(resd[j], W_RESD, sl); }
-            if (M & H_EV) { put<13>(evs[j], W_EV, sl); if (DYN) put<10>(lgs[j], W_LG, sl); }
+            if (M & H_EV) { put<13>(evs[j], W_EV, sl); if (DYN) put<2*LGW>(lgs[j], W_LG, sl); }
         }
         asm volatile("" ::: "memory");
     }
@@ -1786,7 +1834,7 @@ struct Solver {
             if (M & H_ZS) { get<NR>(nd.zLs, W_ZLS, sl); get<NR>(nd.zUs, W_ZUS, sl); }
             if (M & H_DSG) get<NR>(nd.dsg, W_DSG, sl);
             if (M & H_RES) { get<2>(resc[j], W_RESC, sl); get<NR>(resd[j], W_RESD, sl); }
-            if (M & H_EV) { get<13>(evs[j], W_EV, sl); if (DYN) get<10>(lgs[j], W_LG, sl); }
+            if (M & H_EV) { get<13>(evs[j], W_EV, sl); if (DYN) get<2*LGW>(lgs[j], W_LG, sl); }
         }
     }
 
@@ -1873,6 +1921,32 @@ struct Solver {
         L.ff = f*Xww + 2*Xw; L.fp = f*Xww + Xw; L.fd = f*Xdw + Xd; L.pp = f*Xww; L.pd = f*Xdw; L.dd = f*Xdd;
         return L;
     }
+    /* sum over the two loss rows of nu_r hess(row_r) wrt (b, f, p, d) -- what the Hessian of the Lagrangian takes from the integrated loss rows.
+     * Constant efficiencies: rows s + kappa_r f X, one function for both (loss_hess).  Loss table (ITAB): rows s - E_r(v(b), d, f + p, f), the cached jets of
+     * E_tr and E_rgb */
+    __device__ __forceinline__ LossHess rows_hess(int j, double f, double b, const Ev &ev) const
+    {
+        LossHess L;
+        if constexpr (ITAB) {
+            const double vb = 0.5/ev.sb, vbb = -0.25/(b*ev.sb);
+            L.bb = L.bf = L.bp = L.bd = L.ff = L.fp = L.fd = L.pp = L.pd = L.dd = 0;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int r = (k == 0) ? RLTR : RLRG;
+                const double wk = -n[j].nu[r]*U.rs[r];
+                const double *E = ev.lg[k];      /* value, g[4] at 1, h[10] at 5 */
+                const double g0 = E[1], h00 = E[5 + j4h(0, 0)], h01 = E[5 + j4h(0, 1)], h02 = E[5 + j4h(0, 2)], h03 = E[5 + j4h(0, 3)], h11 = E[5 + j4h(1, 1)],
+                             h12 = E[5 + j4h(1, 2)], h13 = E[5 + j4h(1, 3)], h22 = E[5 + j4h(2, 2)], h23 = E[5 + j4h(2, 3)], h33 = E[5 + j4h(3, 3)];
+                L.bb += wk*(h00*vb*vb + g0*vbb); L.bf += wk*(h02 + h03)*vb; L.bp += wk*h02*vb; L.bd += wk*h01*vb;
+                L.ff += wk*(h22 + 2*h23 + h33); L.fp += wk*(h22 + h23); L.fd += wk*(h12 + h13); L.pp += wk*h22; L.pd += wk*h12; L.dd += wk*h11;
+            }
+        } else {
+            L = loss_hess(f, b, ev);
+            const double W = n[j].nu[RLTR]*U.rs[RLTR]*(-P.ct) + n[j].nu[RLRG]*U.rs[RLRG]*P.cr;
+            L.bb *= W; L.bf *= W; L.bp *= W; L.bd *= W; L.ff *= W; L.fp *= W; L.fd *= W; L.pp *= W; L.pd *= W; L.dd *= W;
+        }
+        return L;
+    }
 
     /* gradient entries of the rows wrt (b, f, p, s, b1) and wrt the running time t1 - t (gd; integrated losses only) */
     __device__ __forceinline__ void row_grads(int j, const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], double (&gs)[NR], double (&gb1)[NR],
@@ -1884,7 +1958,15 @@ struct Solver {
         gf[RPW0] = ev.sb; gb[RPW0] = 0.5*f/ev.sb;
         gf[RPW1] = ev.sb1; gb1[RPW1] = 0.5*f/ev.sb1;
         gf[RACC] = 1; gp[RACC] = withPn() ? 1.0 : 0.0; gb[RACC] = -(0.5*P.sr1/ev.sb + P.sr2);
-        if (DYN == LOSS_INTEGRATED) {
+        if (DYN == LOSS_INTEGRATED_TABLE) {
+            /* rows s - E_k(v(b), t1 - t, f + p, f): derivatives wrt (v, d, w, f) at lg[k][1..4] */
+            const double vb = 0.5/ev.sb;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int r = (k == 0) ? RLTR : RLRG;
+                gs[r] = 1; gf[r] = -(ev.lg[k][3] + ev.lg[k][4]); gp[r] = withPn() ? -ev.lg[k][3] : 0.0; gb[r] = -ev.lg[k][1]*vb; gd[r] = -ev.lg[k][2];
+            }
+        } else if (DYN == LOSS_INTEGRATED) {
             /* rows s + kappa f X(v(b), t1 - t, f + p), kappa = -ct, +cr */
             const double X = ev.lg[0][0], Xv = ev.lg[0][1], Xd = ev.lg[0][2], Xw = ev.lg[0][3], vb = 0.5/ev.sb;
 #pragma unroll
@@ -1912,7 +1994,7 @@ struct Solver {
      */
     __device__ __forceinline__ void fold_running_time(const Ev &ev, double (&gb)[NR], double (&gf)[NR], double (&gp)[NR], const double (&gd)[NR]) const
     {
-        if (DYN != LOSS_INTEGRATED) return;
+        if (!INTEG) return;
 #pragma unroll
         for (int r = RLTR; r <= RLRG; r++) { gb[r] += gd[r]*ev.tb; gf[r] += gd[r]*ev.tw; if (withPn()) gp[r] += gd[r]*ev.tw; }
     }
@@ -1925,7 +2007,7 @@ struct Solver {
         if (!n[j].ival()) return;
         const double f = n[j].x[VF], p = withPn() ? n[j].x[VP] : 0.0;
         if (energyOpt()) {
-            of = sc*n[j].ds; os = (DYN == LOSS_INTEGRATED) ? sc : sc*n[j].ds;
+            of = sc*n[j].ds; os = INTEG ? sc : sc*n[j].ds;
             if (n[j].i > 0) { of += sc*2e-3*(f - q); oq = -sc*2e-3*(f - q); off = sc*2e-3; }
         } else {
             of = sc*2e-4*f; off = sc*2e-4;
@@ -1989,7 +2071,7 @@ struct Solver {
                 for (int r = 0; r < NR; r++) {
                     if (!rowOn(r)) continue;
                     gl[j][VB] += nd.nu[r]*gb[r]; gl[j][VF] += nd.nu[r]*gf[r]; gl[j][VP] += nd.nu[r]*gp[r]; gl[j][VS] += nd.nu[r]*gs[r]; out_b1 += nd.nu[r]*gb1[r];
-                    if (DYN == LOSS_INTEGRATED) { out_t1 += nd.nu[r]*gd[r]; gl[j][VT] -= nd.nu[r]*gd[r]; }      /* running time = t1 - t */
+                    if (INTEG) { out_t1 += nd.nu[r]*gd[r]; gl[j][VT] -= nd.nu[r]*gd[r]; }      /* running time = t1 - t */
                 }
                 /* dynamics rows: c_t = t1 - t - tau, c_b = b1 - b+ */
                 out_t1 += nd.lam[0]; gl[j][VT] -= nd.lam[0];
@@ -2042,7 +2124,7 @@ struct Solver {
                 { double xl[NV];
 #pragma unroll
                     for (int k = 0; k < NV; k++) xl[k] = nd.x[k];
-                    obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xl, q, U.sf); }
+                    obj += objective_term<loss_integrated(DYN), FULL>(P, nd, xl, q, U.sf); }
             }
             lsum.add(prod);
             /* the contributions that belong to the neighbours' variables */
@@ -2091,7 +2173,7 @@ struct Solver {
      */
     __device__ __forceinline__ void assemble(const int mode, double mu_, double dw, const double eta = 0.0)
     {
-        constexpr bool UNFOLD = DYN == LOSS_INTEGRATED;      /* (see below: MODE_RESTO keeps the running time of the integrated loss rows unfolded) */
+        constexpr bool UNFOLD = loss_integrated(DYN);      /* (see below: MODE_RESTO keeps the running time of the integrated loss rows unfolded) */
         Ev e[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++) load_ev(j, e[j]);
@@ -2133,11 +2215,11 @@ struct Solver {
                     if (rowOn(RPW0)) { Hbf += nd.nu[RPW0]*U.rs[RPW0]*0.5/e[j].sb; Hbb += nd.nu[RPW0]*U.rs[RPW0]*(-0.25*f/(b*e[j].sb)); }
                     if (rowOn(RPW1)) { nHbq += nd.nu[RPW1]*U.rs[RPW1]*0.5/e[j].sb1; nHbb += nd.nu[RPW1]*U.rs[RPW1]*(-0.25*f/(e[j].b1*e[j].sb1)); }
                     if (rowOn(RACC)) Hbb += nd.nu[RACC]*U.rs[RACC]*0.25*P.sr1/(b*e[j].sb);
-                    if (DYN == LOSS_INTEGRATED && rowOn(RLTR)) {
-                        /* rows s + kappa f X(v(b), d, f + p), d = t1 - t: nu * hess(kappa f X) in (b, f, p, d), then d folded away with
-                         * dd = tb db + tw (df + dp) + rt (quadratic form; the part linear in rt goes to the gradient) */
-                        const LossHess L = loss_hess(f, b, e[j]);
-                        const double W = nd.nu[RLTR]*U.rs[RLTR]*(-P.ct) + nd.nu[RLRG]*U.rs[RLRG]*P.cr;
+                    if (INTEG && rowOn(RLTR)) {
+                        /* rows s + kappa f X(v(b), d, f + p) resp. s - E_k(v(b), d, f + p, f), d = t1 - t: sum_r nu_r hess(row_r) in (b, f, p, d) (rows_hess), then
+                         * d folded away with dd = tb db + tw (df + dp) + rt (quadratic form; the part linear in rt goes to the gradient) */
+                        const LossHess L = rows_hess(j, f, b, e[j]);
+                        constexpr double W = 1.0;
                         const double tb = unfold ? 0.0 : e[j].tb, tw = unfold ? 0.0 : e[j].tw;
                         if (unfold) { Wbd += W*L.bd; Wfd += W*L.fd; Wdd += W*L.dd; if (withPn()) Wpd += W*L.pd; }
                         Hbb += W*(L.bb + 2*tb*L.bd + tb*tb*L.dd);
@@ -2340,7 +2422,7 @@ struct Solver {
                 if (!nd.ival()) continue;
                 Dir d; load_dir(j, d);
                 const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
-                const double dd = (DYN == LOSS_INTEGRATED) ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time */
+                const double dd = INTEG ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time */
                 double gb[NR], gf[NR], gp[NR], gs[NR], gb1[NR], gd[NR];
                 Ev ej; load_ev1(j, ej);
                 row_grads(j, ej, gb, gf, gp, gs, gb1, gd);
@@ -2351,7 +2433,7 @@ struct Solver {
                     /* Newton: slack step; least squares: nu = Sigma dsigma + (-zL + zU) with Sigma = 1, parked in dsg */
                     nd.dsg[r] = (mode == MODE_NEWTON) ? resd[j][r] + lin : lin + (-nd.zLs[r] + nd.zUs[r]);
                 }
-                if (DYN == LOSS_INTEGRATED && rowOn(RLTR)) {
+                if (INTEG && rowOn(RLTR)) {
                     /* the sweeps solved the system with the running time folded into (b, f, p): their multiplier of the time equation is
                      * lam_t + sum_r (gd_r nu_r+ + nu_r d(grad_d row_r)); take the rows' share out again (fold_running_time) */
                     double corr = 0;
@@ -2362,8 +2444,8 @@ struct Solver {
                         corr += gd[r]*nup;
                     }
                     if (mode == MODE_NEWTON) {
-                        const LossHess L = loss_hess(nd.x[VF], nd.x[VB], ej);
-                        const double W = nd.nu[RLTR]*U.rs[RLTR]*(-P.ct) + nd.nu[RLRG]*U.rs[RLRG]*P.cr;
+                        const LossHess L = rows_hess(j, nd.x[VF], nd.x[VB], ej);
+                        constexpr double W = 1.0;
                         corr += W*(L.bd*d.dx[VB] + L.fd*d.dx[VF] + L.pd*d.dx[VP] + L.dd*dd);
                     }
                     c.S[nd.i*S_STRIDE + S_LT] -= corr;
@@ -2484,7 +2566,7 @@ struct Solver {
                     else damp += xt[j][k] - lbv(k);
                     if (resto) { const double xr = wf(W_XR + k, nd.i), qv = (xt[j][k] - xr)/fmax(1.0, fabs(xr)); obj += 0.5*eta*qv*qv; }
                 }
-                if (!resto) obj += objective_term<DYN == LOSS_INTEGRATED, FULL>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
+                if (!resto) obj += objective_term<loss_integrated(DYN), FULL>(P, nd, xt[j], (nd.i > 0) ? c.xf[nd.i - 1] : 0.0, U.sf);
             }
             lsum.add(prod);
         }
@@ -2758,8 +2840,8 @@ struct Solver {
                 if (hasPower()) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             }
             double sl;
-            if (DYN == LOSS_TABLE) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
-            else sl = fmax(P.ct*fel, -P.cr*fel)*((DYN == LOSS_INTEGRATED) ? nd.ds : 1.0) + S0;      /* integrated losses: the slack is an energy per interval */
+            if (DYN == LOSS_TABLE || ITAB) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0])*(ITAB ? nd.ds : 1.0) + S0; }
+            else sl = fmax(P.ct*fel, -P.cr*fel)*(INTEG ? nd.ds : 1.0) + S0;      /* integrated losses: the slack is an energy per interval */
             nd.x[VF] = fel; nd.x[VP] = fpb; nd.x[VS] = sl;
         }
         __syncthreads();
@@ -2831,7 +2913,7 @@ struct Solver {
      * barrier sums and the objective (first iteration, or after an iteration on the general path); otherwise E keeps the values
      * the accepted trial point left there.
      */
-    __device__ __forceinline__ void fused_pass(const bool MERIT, Err &E, double (&h0)[SPT][HV], double (&h1)[SPT][HV], const double dw = 0.0)
+    __device__ __forceinline__ void fused_pass(const bool MERIT, Err &E, double (&h0)[SPT][HV], double (&h1)[SPT][HV], const double dw = 0.0, const bool soc = false)
     {
         const int N = P.N;
         double dual = 0, prim = 0, prim_u = 0, cmax = -INFINITY, cmin = INFINITY, sumlam = 0, sumz = 0, nlam = 0, nz = 0;      /* (nlam, nz: MERIT passes only) */
@@ -2859,7 +2941,9 @@ struct Solver {
                 const double q = (i > 0) ? c.xf[i - 1] : 0.0;
                 Jet tau, bp;
                 interval_map<Jet, true>(P, b, f + p, nd.G, nd.ds, tau, bp);
-                const double cv0 = t1 - (t + tau.v), cv1 = b1 - bp.v;
+                double cv0_ = t1 - (t + tau.v), cv1_ = b1 - bp.v;
+                if constexpr (SOCK) { if (soc) { cv0_ = wf(W_RESC, i); cv1_ = wf(W_RESC + 1, i); } }      /* (second-order correction: the accumulated residuals, merit_fast) */
+                const double cv0 = cv0_, cv1 = cv1_;
                 tb = tau.g0; tw = tau.g1; Bb = bp.g0; Bw = bp.g1; rt = -cv0; rb = -cv1;
                 const double isb = frcp(sb), isb1 = frcp(sb1);
                 const RowG g = row_grads_fast(f, sb, sb1, isb, isb1);
@@ -2904,7 +2988,9 @@ struct Solver {
                 double Sg[NR], c0[NR], c1[NR];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const double rd_ = dv[r] - nd.sg[r];
+                    double rd0_ = dv[r] - nd.sg[r];
+                    if constexpr (SOCK) { if (soc) rd0_ = wf(W_RESD + r, i); }
+                    const double rd_ = rd0_;
                     resd[j][r] = rd_;
                     const double viol = fabs(rd_);
                     prim = fmax(prim, viol); prim_u = fmax(prim_u, viol*U.irs[r]);
@@ -3134,7 +3220,11 @@ struct Solver {
     }
 
     /* the point x + alpha d: published, theta / barrier sums / objective into T (which become the next current point's when it is accepted) */
-    __device__ __forceinline__ void merit_fast(double alpha, double mu_, Err &T, double &phi, bool &ok)
+    /* soc_store (SOCK kernels; second-order correction, W&B section 2.4): 1 / 2 -- also c_soc = alpha c_soc + c(x + alpha d) per lane into the work area (fields
+     * W_RESC, W_RESD: the general iteration's residual fields, unused by these kernels otherwise), from where the next pass over the current point takes its
+     * right-hand sides (fused_pass(..., soc)); 1: c_soc starts as c(x), the residuals the last pass left in the stage blocks (dynamics) and in the exchange
+     * arrays (rows) */
+    __device__ __forceinline__ void merit_fast(double alpha, double mu_, Err &T, double &phi, bool &ok, const int soc_store = 0)
     {
         double xt[SPT][NV], st[SPT][NR];
 #pragma unroll
@@ -3166,6 +3256,18 @@ struct Solver {
                 dv[RPW0] = U.rs[RPW0]*f*sb; dv[RPW1] = U.rs[RPW1]*f*sb1;
                 dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nd.G);
                 dv[RLTR] = U.rs[RLTR]*(s - P.ct*f); dv[RLRG] = U.rs[RLRG]*(s + P.cr*f);
+                if constexpr (SOCK) {
+                    if (soc_store != 0) {
+                        const bool first = soc_store == 1;
+                        const double *sB = c.S + i*S_STRIDE;
+                        const double o0 = first ? -sB[S_RT] : wf(W_RESC, i), o1 = first ? -sB[S_RB] : wf(W_RESC + 1, i);
+                        wf(W_RESC, i) = alpha*o0 + (t1 - (t + tau)); wf(W_RESC + 1, i) = alpha*o1 + (b1 - bp);
+                        const double oldr[NR] = {first ? c.o1[i] : wf(W_RESD + RPW0, i), first ? c.o2[i] : wf(W_RESD + RPW1, i), first ? c.o3[i] : wf(W_RESD + RACC, i),
+                                                 first ? c.o4[i] : wf(W_RESD + RLTR, i), first ? c.o6[i] : wf(W_RESD + RLRG, i)};
+#pragma unroll
+                        for (int r = 0; r < NR; r++) wf(W_RESD + r, i) = alpha*oldr[r] + (dv[r] - st[j][r]);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     th += fabs(dv[r] - st[j][r]);
@@ -3297,6 +3399,9 @@ struct Solver {
      * they sat in the same code object (round 4) */
     static constexpr bool FAMILY_HAS_RESTO = MSD_RESTO && (STREAM || FIRST || PART == 2 || (DYN == LOSS_STATIC && !GEN && NT <= 256));
     static constexpr bool HAS_RESTO = FAMILY_HAS_RESTO && !FIRST;      /* (a first-pass kernel leaves the phase to its follow-up kernel) */
+    /* assemble(MODE_RESTO) hands the integrated loss rows' share in the running time to riccati_resto through the work area (fields W_RX), which only the
+     * streamed kernels write: an LDS-resident kernel of these families with the phase inside would read fields nobody wrote */
+    static_assert(!(loss_integrated(DYN) && HAS_RESTO && !STREAM), "integrated loss rows: the restoration phase lives in the streamed follow-up kernels");
     static constexpr int STATUS_RESTO = -101;
 
     /* ---- watchdog procedure (IPOPT: IpBacktrackingLineSearch::StartWatchDog / StopWatchDog, FilterLSAcceptor::StartWatchDog / StopWatchDog; the options
@@ -3554,6 +3659,11 @@ struct Solver {
         /* inertia correction of the fused iteration (W&B Algorithm IC): the pass over the current point runs again with delta_w on the diagonal */
         double ic_dw = 0;
         bool ic_retry = false;
+        /* SOCK: second-order correction of the fused iteration: 1 passes over the current point with the accumulated residuals, 2 the Newton step once more
+         * after corrections that did not help, backtracking goes on from half the step.  (What a correction keeps between its passes lives in LDS,
+         * misc[27..31]: uniform values held in registers across the loop are what the hot path spills first) */
+        int soc_mode = 0;
+        constexpr int MISC_SOC = 27;
         int n_reg = 0, n_soc = 0, n_back = 0, n_resto = 0, iter_first = 0, forced = 0;
         int wd_short = 0, wd_trial = 0, n_wd = 0, wd_reg_inc = 0;      /* watchdog: successive shortened iterations, trial iterations of a running procedure, procedures started */
         bool in_wd = false, wd_arm = false;      /* (wd_arm: the iterate of this iteration has been copied for the procedure, which starts at its line search) */
@@ -3608,7 +3718,7 @@ struct Solver {
             c.mark(PH_OTHER); phase_fence(PH_OTHER);
             double h0[SPT][HV], h1[SPT][HV];
             if constexpr (FL) {
-                if (iter == 0) {
+                if (iter == 0 || (SOCK && soc_mode != 0)) {      /* (soc_mode: the exchange arrays hold the rejected trial point) */
                     double xc[SPT][NV];
 #pragma unroll
                     for (int j = 0; j < SPT; j++)
@@ -3616,7 +3726,7 @@ struct Solver {
                         for (int k = 0; k < NV; k++) xc[j][k] = n[j].x[k];
                     publish_fast(xc);
                 }
-                fused_pass(iter == 0, E, h0, h1, ic_dw);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
+                fused_pass(iter == 0, E, h0, h1, ic_dw, SOCK && soc_mode == 1);      /* later iterations: theta, barrier sums and objective are the accepted trial point's */
                 c.mark(PH_KKT); phase_fence(PH_KKT);
             } else {
                 if (iter > 0 || (RESUMABLE && !FL && resume)) evaluate_current();
@@ -3631,21 +3741,23 @@ struct Solver {
                 double *hh = hist + HIST_COLS*iter;
                 hh[0] = iter; hh[1] = objv; hh[2] = E.primal; hh[3] = E.dual; hh[4] = log10(mu); hh[5] = dnorm; hh[6] = alpha_du; hh[7] = alpha_pr;
             }
+            const bool soc_pass = SOCK && FL && soc_mode != 0;      /* (the same point once more, with other residuals: no tests, no barrier update) */
             const double E0 = total_err(E, 0.0);
             const double dual_u = E.dual/U.sf, compl_u = compl_err(E, 0.0)/U.sf;
-            if (E0 <= P.tol && dual_u <= 1.0 && E.primal_u <= 1e-4 && compl_u <= 1e-4) { status = MSD_STATUS_SOLVED; break; }
+            if (!soc_pass && E0 <= P.tol && dual_u <= 1.0 && E.primal_u <= 1e-4 && compl_u <= 1e-4) { status = MSD_STATUS_SOLVED; break; }
             /* (acc_now: the current point meets the acceptable tolerances -- where the line search then finds no step the solve ends with
              *  Solved_To_Acceptable_Level, IPOPT's "Restoration phase called at acceptable point", instead of breaking down: below) */
             const bool acc_now = E0 <= ACC_TOL && dual_u <= 1e10 && E.primal_u <= 1e-2 && compl_u <= 1e-2;
-            if (acc_now) { if (!(FL && ic_retry) && ++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
+            if (soc_pass) { }
+            else if (acc_now) { if (!(FL && ic_retry) && ++acc_count >= ACC_ITER) { status = MSD_STATUS_ACCEPTABLE; break; } }
             else acc_count = 0;
-            if (iter >= P.maxIter) { status = MSD_STATUS_MAXITER; break; }
-            if (!isfinite(E0)) { status = MSD_STATUS_NUMERIC; break; }
+            if (!soc_pass && iter >= P.maxIter) { status = MSD_STATUS_MAXITER; break; }
+            if (!soc_pass && !isfinite(E0)) { status = MSD_STATUS_NUMERIC; break; }
 
             /* barrier parameter (monotone, W&B eq. (7)); E_mu differs from E_0 only in the complementarity part */
             {
                 bool changed = false;
-                while (!(FL && ic_retry) && total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {      /* (ic_retry: the same point once more, below) */
+                while (!(FL && ic_retry) && !soc_pass && total_err(E, mu) <= K_EPS*mu && mu > mu_floor) {      /* (ic_retry, soc_pass: the same point once more, below) */
                     const double nm = fmax(mu_floor, fmin(K_MU_LIN*mu, mu*sqrt(mu)));      /* mu^theta_mu with theta_mu = K_MU_SUP = 1.5 */
                     if (nm >= mu) break;
                     mu = nm; tau = fmax(K_TAU_MIN, 1 - mu); changed = true;
@@ -3684,6 +3796,78 @@ struct Solver {
                     if (theta <= theta_min) amin = fmin(amin, K_DELTA*hpow(theta, S_THETA)/hpow(-gphid, S_PHI));
                 }
                 amin *= ALPHA_MIN_FRAC;
+                if constexpr (SOCK) {
+                double alpha = amax;
+                bool accepted = false, ftype_armijo = false, soc_go = false;
+                Err T = E;
+                int ls = 0, store = 0;
+                const bool soc_trial = soc_mode == 1;      /* this pass's step is a corrected one: tested like the step it corrects (its alpha, its directional derivative) */
+                bool resume_half = false;
+                if (soc_mode == 2) { soc_mode = 0; alpha = 0.5*amax; ls = 1; n_back++; resume_half = alpha < amin; }
+                if (!resume_half)
+                for (;;) {
+                    double ph_t; bool okt;
+                    merit_fast(alpha, mu, T, ph_t, okt, store);
+                    if (store != 0) { soc_go = true; break; }      /* (the trial point once more, for its residuals: the corrected step comes with the next pass) */
+                    if (soc_trial) {
+                        n_soc++;
+                        const double soc_alpha0 = uni(c.misc[MISC_SOC]), soc_gphid = uni(c.misc[MISC_SOC + 1]), soc_thprev = uni(c.misc[MISC_SOC + 2]);
+                        const int soc_count = (int)uni(c.misc[MISC_SOC + 3]) + 1;
+                        const bool soc_ftype = uni(c.misc[MISC_SOC + 4]) != 0.0;
+                        if (acceptable(okt, T.theta, ph_t, theta, phi, soc_alpha0, soc_gphid, soc_ftype, theta_max, theta_min, nfilt)) {
+                            accepted = true; ftype_armijo = soc_ftype && cmp_le(ph_t - phi, ETA_PHI*soc_alpha0*soc_gphid, phi);
+                            soc_mode = 0;
+                            break;
+                        }
+                        if (okt && T.theta <= K_SOC*soc_thprev && soc_count < P_MAX_SOC) {
+                            __syncthreads();
+                            if (c.tid == 0) { c.misc[MISC_SOC + 2] = T.theta; c.misc[MISC_SOC + 3] = (double)soc_count; }
+                            __syncthreads();
+                            store = 2; continue;
+                        }
+                        soc_mode = 2; soc_go = true;      /* no help: the Newton step once more, backtracking goes on */
+                        break;
+                    }
+                    bool ftype = false;
+                    if (gphid < 0) {
+                        double lhs = alpha*hpow(-gphid, S_PHI), rhs = K_DELTA*hpow(theta, S_THETA);
+                        if (fabs(lhs - rhs) <= 1e-4*fmax(lhs, rhs)) { lhs = alpha*pow(-gphid, S_PHI); rhs = K_DELTA*pow(theta, S_THETA); }
+                        ftype = lhs > rhs;
+                    }
+                    if (acceptable(okt, T.theta, ph_t, theta, phi, alpha, gphid, ftype, theta_max, theta_min, nfilt)) {
+                        accepted = true; ftype_armijo = ftype && cmp_le(ph_t - phi, ETA_PHI*alpha*gphid, phi);
+                        break;
+                    }
+                    /* second-order correction: the trial point evaluated once more to leave its residuals (store), then fused_pass with the accumulated
+                     * residuals as right-hand sides, the KKT solve, and the corrected step through this same line search -- one call site each */
+                    if (ls == 0 && okt && T.theta >= theta) {
+                        __syncthreads();
+                        if (c.tid == 0) { c.misc[MISC_SOC] = alpha; c.misc[MISC_SOC + 1] = gphid; c.misc[MISC_SOC + 2] = T.theta; c.misc[MISC_SOC + 3] = 0.0; c.misc[MISC_SOC + 4] = ftype ? 1.0 : 0.0; }
+                        __syncthreads();
+                        soc_mode = 1; store = 1; continue;
+                    }
+                    alpha *= 0.5; n_back++; ls++;
+                    if (alpha < amin) break;
+                }
+                if (soc_go) iter--;      /* (the same point once more: the loop's own back-edge) */
+                else {
+                if (!accepted && acc_now) { status = MSD_STATUS_ACCEPTABLE; break; }
+                if (!accepted) { status = (HAS_RESTO && P.resto) ? STATUS_GENERAL : MSD_STATUS_LINESEARCH; why_general = 4; break; }
+                alpha_pr = alpha;
+                if (ls == 0) wd_short = 0; else if (ls > 1) wd_short++;
+                c.mark(PH_MERIT); phase_fence(PH_MERIT);
+                if (!ftype_armijo && nfilt < FILT_CAP) {
+                    __syncthreads();
+                    if (c.tid == 0) { c.filt[2*nfilt] = (1 - G_THETA)*theta; c.filt[2*nfilt + 1] = phi - G_PHI*theta; }
+                    nfilt++;
+                    __syncthreads();
+                }
+                update_fast(alpha_pr, alpha_du, mu, ic_dw);
+                ic_dw = 0; ic_retry = false;
+                E.theta = T.theta; E.L = T.L; E.D = T.D; E.obj = T.obj;
+                }
+                c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
+                } else {
                 double alpha = amax;
                 bool accepted = false, ftype_armijo = false, general = false;
                 Err T = E;
@@ -3724,6 +3908,7 @@ struct Solver {
                 ic_dw = 0; ic_retry = false;
                 E.theta = T.theta; E.L = T.L; E.D = T.D; E.obj = T.obj;
                 c.mark(PH_UPDATE); phase_fence(PH_UPDATE);
+                }
             } else {
 
             /* search direction with inertia correction (W&B Algorithm IC); one call site */
@@ -4073,7 +4258,7 @@ __device__ __noinline__ int resto_entry(const DevProb *P, Ctx c, double *work, U
  *   2  the follow-up: general iteration + restoration phase + second attempt, for the scenarios of the list (P.follow) or, without a
  *      list, for the whole batch (launches none of whose scenarios can start fused: the reference's starting point, a primal-only warm start)
  */
-template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0, bool SLDS = false>
+template <int NT, int SPT, int WPS, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0, bool SLDS = false, bool SOCK = false>
 __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, const double *scen, const double *overrides, double *z_out, double *lam_out,
                                                        double *stats, double *hist, int hist_cap, double *work)
 {
@@ -4095,7 +4280,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     }
     c.xb = c.xt + NS; c.xf = c.xb + NS;
     c.o1 = c.xf + NS; c.o2 = c.o1 + NS; c.o3 = c.o2 + NS;
-    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL, PART, SLDS>;
+    using SolverT = Solver<NT, SPT, DYN, STREAM, GEN, FULL, PART, SLDS, SOCK>;
     constexpr bool FASTK = SolverT::FAST;
     c.xs = c.o4 = c.o5 = c.o6 = c.o7 = nullptr;
     if (FASTK) { c.xs = c.o3 + NS; c.o4 = c.xs + NS; c.o5 = c.o4 + NS; c.o6 = c.o5 + NS; c.o7 = c.o6 + NS; }
@@ -4202,6 +4387,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                         P.follow[FOLLOW_HDR + 2*k] = sidx; P.follow[FOLLOW_HDR + 2*k + 1] = attempt == 0 ? -1 : spent;
                         atomicAdd(P.follow + FOLLOW_TOTAL, 1);
                         atomicAdd(P.follow + FOLLOW_WHY + (st == SolverT::STATUS_GENERAL ? s.why_general : 4), 1);
+                        if (P.socSeen && st == SolverT::STATUS_GENERAL && s.why_general == 3) *P.socSeen = 1;
                     }
                     break;
                 }

@@ -15,14 +15,13 @@ static_assert(Solver<64, 2, LOSS_STATIC, false, false, FULL_BOTH, 1>::FAST && So
 Geometry pick_geometry_full(int N)
 {
     const int nodes = N + 1;
-    const char *nf = getenv("MSD_NO_FULL");      /* MSD_NO_FULL=1: the general kernels (A/B runs) */
-    if (nf && *nf == '1') return {0, 0, nullptr};
+    if (tuning().no_full) return {0, 0, nullptr};      /* (msd_tuning("no_full", 1): the general kernels, A/B runs) */
 #ifndef MSD_HOT_ONLY_64X2
-    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, 0, follow_kernel_full(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>};
+    if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, 0, follow_kernel_full(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>, 0, soc_kernel_full(64, 1, false)};
 #endif
     /* (SLDS: the node constants in LDS where they do not cost the fourth resident workgroup of a compute unit -- msd_kernel.hpp: STATIC_FIELDS) */
     if (MSD_STATIC_LDS && sizeof(double)*(size_t)(lds_doubles(N, 128, false, XCH_FAST, 0) + STATIC_FIELDS*128) <= 40*1024 && nodes > 64)
-        return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 1, true>, false, XCH_FAST, 0, follow_kernel_full(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 3, true>, STATIC_FIELDS*128};
+        return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 1, true>, false, XCH_FAST, 0, follow_kernel_full(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 3, true>, STATIC_FIELDS*128, soc_kernel_full(64, 2, true)};
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 1>, false, XCH_FAST, 0, follow_kernel_full(64, 2), solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_BOTH, 3>};     /* the benchmark geometry */
 #ifdef MSD_HOT_ONLY_64X2      /* tuning builds of the benchmark geometry alone (tools/build_hot.py: a fifth of the unit's compile time) */
     return {0, 0, nullptr};

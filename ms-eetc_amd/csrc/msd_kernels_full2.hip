@@ -9,8 +9,8 @@
 
 namespace msd {
 
-static bool no_full() { const char *nf = getenv("MSD_NO_FULL"); return nf && *nf == '1'; }
-static bool two_nodes_per_lane() { const char *g = getenv("MSD_GEOMETRY2"); return g && !strcmp(g, "64x2"); }      /* tuning runs */
+static bool no_full() { return tuning().no_full; }
+static bool two_nodes_per_lane() { return tuning().two_nodes_per_lane; }      /* tuning runs (msd_tuning of mseetc_aux.h) */
 
 /*
  * 65 ... 128 nodes: two waves per scenario with one node per lane and the whole register file of a SIMD each.  The jets through the

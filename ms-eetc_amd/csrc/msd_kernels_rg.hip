@@ -15,8 +15,7 @@ static_assert(Solver<64, 2, LOSS_STATIC, false, false, FULL_RG, 1>::FAST && Solv
 Geometry pick_geometry_full_rg(int N)
 {
     const int nodes = N + 1;
-    const char *nf = getenv("MSD_NO_FULL");      /* MSD_NO_FULL=1: the general kernels (A/B runs) */
-    if (nf && *nf == '1') return {0, 0, nullptr};
+    if (tuning().no_full) return {0, 0, nullptr};      /* (msd_tuning("no_full", 1): the general kernels, A/B runs) */
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 1>, false, XCH_FAST, 0, follow_kernel_full_rg(64, 1), solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 3>};
     /* (SLDS: the node constants in LDS where they do not cost the fourth resident workgroup of a compute unit -- msd_kernel.hpp: STATIC_FIELDS) */
     if (MSD_STATIC_LDS && sizeof(double)*(size_t)(lds_doubles(N, 128, false, XCH_FAST, 0) + STATIC_FIELDS*128) <= 40*1024 && nodes > 64)

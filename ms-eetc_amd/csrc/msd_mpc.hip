@@ -75,12 +75,19 @@ __global__ void mpc_relax(int B, int attempt, const double *stats, const double 
     bool again = false;
     if (attempt == 0) {
         if (flag[s] != 1) return;
-        /* usable: the twin converged, or ended on a feasible point without converging -- the time of a feasible run bounds the minimum from above, so
-         * an arrival time moved there can be met (mseetc/ocp.py: minimumTime) */
-        const double viol = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_CONSTR_VIOL];
-        const bool ok = st_tw[(size_t)MSD_ST_COUNT*s + MSD_ST_STATUS] >= 0 || (isfinite(viol) && viol <= 1e-6);
+        /* usable: the twin converged -- or it ended without converging on a feasible point NEXT TO its optimum: far down the central path (mu <= 1e-5) or
+         * with an optimality error of 1e-4 (its primal point settles long before its multipliers do where both brakes share an active acceleration bound).
+         * Round 6: feasibility alone is not enough.  The twin is given three times the running time asked for and its profile start uses that
+         * time up, so a twin that breaks down EARLY sits on a feasible point whose time says nothing about the minimum: the scenario was declared late and
+         * its arrival time moved by up to a factor of three although it may be feasible.  Such a scenario now keeps its arrival time and is solved again
+         * with both attempts (flag 3).  The log tells the two kinds of verdict apart: 1 converged twin, 2 twin next to its optimum
+         * (mseetc/ocp.py: minimumTime restates the rule) */
+        const double *stw = st_tw + (size_t)MSD_ST_COUNT*s;
+        const double viol = stw[MSD_ST_CONSTR_VIOL];
+        const bool conv = stw[MSD_ST_STATUS] >= 0;
+        const bool ok = conv || (isfinite(viol) && viol <= 1e-6 && (stw[MSD_ST_MU] <= 1e-5 || stw[MSD_ST_KKT] <= 1e-4));
         const double tmin = z_tw[(size_t)nz_tw*s + nz_tw - 2] - tnow[s];
-        if (ok && tmin > T[s] - tnow[s]) { tm[s] = tmin; flag[s] = 2; again = true; log[(size_t)MSD_MPC_COUNT*s + MSD_MPC_RELAXED] = 1.0; }
+        if (ok && tmin > T[s] - tnow[s]) { tm[s] = tmin; flag[s] = 2; again = true; log[(size_t)MSD_MPC_COUNT*s + MSD_MPC_RELAXED] = conv ? 1.0 : 2.0; }
         else {
             /* not late: the breakdown was the solver's.  The main launch makes one attempt per scenario (a late scenario would spend its second one, from
              * the other starting point, on a problem without a solution -- nine of 512 per re-solve, a third of the loop's time in round 4); the ones
@@ -333,6 +340,7 @@ int msd_mpc_run(msd_mpc_handle m, int nscen, const double *T, double initial_tim
         }
         ws.d_dual_out = m->warm ? m->d_dual[cur] : nullptr;
         ws.one_attempt = m->relax;      /* (mpc_relax: what the twin does not declare late is solved again with both attempts) */
+        ws.use_soc = true;              /* (second-order corrections are the rule in these re-solves: the first-pass kernel that has them, msd_kernel.hpp: SOCK) */
         rc = msd_host::launch_plan(pl, st, m->d_work, m->d_follow, queue(), B, m->d_scen, nullptr, m->d_z[cur], nullptr, m->d_st[cur], nullptr, 0, ws);
         if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }      /* (nothing of a loop that failed half-way stays queued on the handle's stream) */
         if (m->relax) {
@@ -345,6 +353,7 @@ int msd_mpc_run(msd_mpc_handle m, int nscen, const double *T, double initial_tim
                 hipLaunchKernelGGL(mpc_relax, gb, tb, 0, st, B, a, m->d_st[cur], m->d_ztw, tw.nz, m->d_sttw, m->d_T, m->d_tnow, m->d_tm, m->d_flag, m->d_listB, m->d_scen, margin, logk);
                 msd_host::WarmStart cold;
                 cold.d_dual_out = ws.d_dual_out;
+                cold.use_soc = true;
                 rc = msd_host::launch_plan(pl, st, m->d_work, m->d_follow, queue(), B, m->d_scen, nullptr, m->d_z[cur], nullptr, m->d_st[cur], nullptr, 0, cold, m->d_listB);
                 if (rc != MSD_OK) { hipStreamSynchronize(st); return rc; }
             }

@@ -230,7 +230,7 @@ __device__ __forceinline__ int restoration(const double *scen, double *hist, int
                 }
                 if (!nd.ival()) continue;
                 const double db1 = c.S[(nd.i + 1)*S_STRIDE + S_DB];
-                const double dd_ = (DYN == LOSS_INTEGRATED) ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time (integrated loss rows) */
+                const double dd_ = INTEG ? c.S[(nd.i + 1)*S_STRIDE + S_DT] - d.dx[VT] : 0.0;      /* step of the running time (integrated loss rows) */
                 double gb[NR], gf[NR], gp_[NR], gs[NR], gb1[NR], gdd[NR];
                 Ev ej; load_ev1(j, ej);
                 row_grads(j, ej, gb, gf, gp_, gs, gb1, gdd);

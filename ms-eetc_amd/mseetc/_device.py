@@ -123,6 +123,7 @@ def lib():
         L.msd_integrate_losses.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, ctypes.c_int,
                                            _dptr, _dptr, _dptr, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr]
 
+        L.msd_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.msd_fastmath_probe.argtypes = [ctypes.c_int, ctypes.c_int] + [_dptr]*4
         L.msd_host_alloc.argtypes = [ctypes.c_ulonglong, ctypes.POINTER(vp)]
         L.msd_host_free.argtypes = [vp]

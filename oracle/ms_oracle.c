@@ -145,21 +145,29 @@ static jet spec_losses(const DynLoss *D, int traction, double f, double v)
  * derivative d3L/df dv2 that g_vv would need is dropped (the branch is never active at a solution; only the
  * curvature used by Newton's method is affected, not the NLP).
  */
-static void loss_rows(const DynLoss *D, double f, double v, double out[2][6])
+/* the split loss power itself (utils.py:197-220; specific, W/kg): out = {L, L_f, L_v, L_ff, L_fv, L_vv} of the traction part (row 0) or the
+ * regenerative-brake part (row 1) at (f, v); beta = spec_losses(D, 1, 0, v) */
+static void loss_split(const DynLoss *D, int row, double f, double v, const jet *beta, double out[6])
 {
     const double tol = 1e-10;
+    const int traction = (row == 0);
+    const int truth = traction ? (f >= 0) : (f < 0);
+    if (truth) {
+        jet s = spec_losses(D, traction, f, v);
+        out[0] = s.v; out[1] = s.g0; out[2] = s.g1; out[3] = s.h00; out[4] = s.h01; out[5] = s.h11;
+    } else {
+        jet a = spec_losses(D, traction, traction ? tol : -tol, v);    /* slope alpha(v) = a.g0, alpha'(v) = a.h01 */
+        out[0] = a.g0*f + beta->v; out[1] = a.g0; out[2] = a.h01*f + beta->g1; out[3] = 0; out[4] = a.h01; out[5] = beta->h11;
+    }
+}
+
+static void loss_rows(const DynLoss *D, double f, double v, double out[2][6])
+{
     jet beta = spec_losses(D, 1, 0.0, v);
     for (int row = 0; row < 2; row++) {
-        const int traction = (row == 0);
-        const int truth = traction ? (f >= 0) : (f < 0);
-        double L, Lf, Lv, Lff, Lfv, Lvv;
-        if (truth) {
-            jet s = spec_losses(D, traction, f, v);
-            L = s.v; Lf = s.g0; Lv = s.g1; Lff = s.h00; Lfv = s.h01; Lvv = s.h11;
-        } else {
-            jet a = spec_losses(D, traction, traction ? tol : -tol, v);    /* slope alpha(v) = a.g0, alpha'(v) = a.h01 */
-            L = a.g0*f + beta.v; Lf = a.g0; Lv = a.h01*f + beta.g1; Lff = 0; Lfv = a.h01; Lvv = beta.h11;
-        }
+        double l[6];
+        loss_split(D, row, f, v, &beta, l);
+        const double L = l[0], Lf = l[1], Lv = l[2], Lff = l[3], Lfv = l[4], Lvv = l[5];
         const double iv = 1/v;
         out[row][0] = L*iv;
         out[row][1] = Lf*iv;
@@ -495,6 +503,117 @@ void oracle_loss_distance(const int *ip, const double *dp, double v0, double dt,
     for (int k = 0; k < 6; k++) out10[4 + k] = X.h[k];
 }
 
+/* ------------------------------------------------------------------------------------------
+ * integrateLosses with a loss TABLE (dynamic loss model of efficiency.py, or any tabulated loss function): the loss slack bounds
+ *     E_k(v_i, dt, w, f) = int_0^dt L_k(f, v(t)) dt,   dv/dt = w - rr(v) - G,  v(0) = v_i,     k = traction part / regenerative-brake part
+ * (ocp.py:231-241 -> TrainIntegrator.initLosses / calcLosses, train.py:367-413: "energyTrDot = lossesTrFun(F, vel)/totalMass").  L_k is the specific
+ * split loss power (loss_split).  Intended semantics: the reference hands initLosses the SPECIFIC functions of train.powerLossesFuns() (ocp.py:99,118-120)
+ * and initLosses scales force and result by the mass once more (train.py:376-377) -- exact for losses linear in F v (constant efficiencies: what the
+ * static rows above reproduce), off by a factor of the mass in the force argument for a table; the reference's own switch for this combination sits
+ * commented out at simulations/figure6.py:178.  Here the loss power is L(F, v)/M with F = f M, like utils.py:261-289 (postProcessDataFrame) integrates it.
+ * Same adaptive Dormand-Prince pair as loss_distance at CVODES' tolerances (train.py:396), step control on the values of (v, E_tr, E_rgb); second-order
+ * jets in (v_i, dt, w, f) through the accepted steps.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double v, g[4], h[10]; } jet4;      /* variables (v0, dt, w, f); h: 00 01 02 03 11 12 13 22 23 33 */
+static const int J4A[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, J4B[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+static int j4h(int a, int b) { if (a > b) { int t = a; a = b; b = t; } return a == 0 ? b : a == 1 ? 3 + b : a == 2 ? 5 + b : 9; }
+static jet4 j4_const(double c) { jet4 r; memset(&r, 0, sizeof r); r.v = c; return r; }
+static jet4 j4_var(double v, int k) { jet4 r = j4_const(v); r.g[k] = 1; return r; }
+static jet4 j4_axpy(double s, jet4 a, jet4 y) { y.v += s*a.v; for (int k = 0; k < 4; k++) y.g[k] += s*a.g[k]; for (int k = 0; k < 10; k++) y.h[k] += s*a.h[k]; return y; }
+static jet4 j4_mul(jet4 a, jet4 b)
+{
+    jet4 r; r.v = a.v*b.v;
+    for (int k = 0; k < 4; k++) r.g[k] = a.v*b.g[k] + b.v*a.g[k];
+    for (int k = 0; k < 10; k++) r.h[k] = a.v*b.h[k] + b.v*a.h[k] + a.g[J4A[k]]*b.g[J4B[k]] + a.g[J4B[k]]*b.g[J4A[k]];
+    return r;
+}
+/* L(f, v) with v a jet and f variable 3: l = {L, L_f, L_v, L_ff, L_fv, L_vv} */
+static jet4 j4_loss(const double l[6], jet4 v)
+{
+    jet4 r; r.v = l[0];
+    for (int a = 0; a < 4; a++) r.g[a] = l[2]*v.g[a] + (a == 3 ? l[1] : 0.0);
+    for (int k = 0; k < 10; k++) {
+        const int a = J4A[k], b = J4B[k];
+        r.h[k] = l[2]*v.h[k] + l[5]*v.g[a]*v.g[b] + l[4]*((a == 3 ? v.g[b] : 0.0) + (b == 3 ? v.g[a] : 0.0)) + ((a == 3 && b == 3) ? l[3] : 0.0);
+    }
+    return r;
+}
+
+#define DP54_TABLEAU \
+    static const double a21 = 1.0/5, a31 = 3.0/40, a32 = 9.0/40, a41 = 44.0/45, a42 = -56.0/15, a43 = 32.0/9, \
+                 a51 = 19372.0/6561, a52 = -25360.0/2187, a53 = 64448.0/6561, a54 = -212.0/729, \
+                 a61 = 9017.0/3168, a62 = -355.0/33, a63 = 46732.0/5247, a64 = 49.0/176, a65 = -5103.0/18656, \
+                 b1 = 35.0/384, b3 = 500.0/1113, b4 = 125.0/192, b5 = -2187.0/6784, b6 = 11.0/84, \
+                 e1 = 71.0/57600, e3 = -71.0/16695, e4 = 71.0/1920, e5 = -17253.0/339200, e6 = 22.0/525, e7 = -1.0/40;
+
+/* E[0], E[1] = E_tr, E_rgb with derivatives (order 2) or their values only (order 0: E[k].v; same steps, the step control looks at values only) */
+static double g_le_atol = 1e-8, g_le_rtol = 1e-6;      /* train.py:396 (the test hook below tightens them to check the derivatives by differences) */
+static void loss_energy(const Prob *P, double v0, double dt0, double w0, double f0, double G, jet4 E[2], int order)
+{
+    DP54_TABLEAU
+    const double atol = g_le_atol, rtol = g_le_rtol;
+    const DynLoss *D = &P->dyn;
+    const jet4 dt = order ? j4_var(dt0, 1) : j4_const(dt0), w = order ? j4_var(w0, 2) : j4_const(w0);
+    jet4 y[3] = {order ? j4_var(v0, 0) : j4_const(v0), j4_const(0), j4_const(0)}, k[7][3], yn[3];
+    /* d(v, E_tr, E_rgb)/dsigma = dt (w - rr(v) - G, L_tr(f, v), L_rgb(f, v)) on the unit interval */
+#define ERHS(vj, out) do { const jet4 vj_ = (vj); \
+        const jet4 acc_ = j4_axpy(-P->sr1, vj_, j4_axpy(-P->sr2, j4_mul(vj_, vj_), j4_axpy(1.0, w, j4_const(-P->sr0 - G)))); \
+        (out)[0] = j4_mul(dt, acc_); \
+        const jet beta_ = spec_losses(D, 1, 0.0, vj_.v); \
+        for (int r_ = 0; r_ < 2; r_++) { double l_[6]; loss_split(D, r_, f0, vj_.v, &beta_, l_); \
+            if (!order) { l_[1] = l_[2] = l_[3] = l_[4] = l_[5] = 0; } \
+            (out)[1 + r_] = j4_mul(dt, j4_loss(l_, vj_)); } } while (0)
+    double sig = 0, h = 1.0;
+    ERHS(y[0], k[0]);
+    for (int step = 0; step < 100000 && sig < 1.0; step++) {
+        if (sig + h > 1.0) h = 1.0 - sig;
+        jet4 s;
+        s = j4_axpy(h*a21, k[0][0], y[0]); ERHS(s, k[1]);
+        s = j4_axpy(h*a32, k[1][0], j4_axpy(h*a31, k[0][0], y[0])); ERHS(s, k[2]);
+        s = j4_axpy(h*a43, k[2][0], j4_axpy(h*a42, k[1][0], j4_axpy(h*a41, k[0][0], y[0]))); ERHS(s, k[3]);
+        s = j4_axpy(h*a54, k[3][0], j4_axpy(h*a53, k[2][0], j4_axpy(h*a52, k[1][0], j4_axpy(h*a51, k[0][0], y[0])))); ERHS(s, k[4]);
+        s = j4_axpy(h*a65, k[4][0], j4_axpy(h*a64, k[3][0], j4_axpy(h*a63, k[2][0], j4_axpy(h*a62, k[1][0], j4_axpy(h*a61, k[0][0], y[0]))))); ERHS(s, k[5]);
+        for (int m = 0; m < 3; m++)
+            yn[m] = j4_axpy(h*b6, k[5][m], j4_axpy(h*b5, k[4][m], j4_axpy(h*b4, k[3][m], j4_axpy(h*b3, k[2][m], j4_axpy(h*b1, k[0][m], y[m])))));
+        const int finite = isfinite(yn[0].v) && isfinite(yn[1].v) && isfinite(yn[2].v) && yn[0].v > 0;
+        double err = 0;
+        if (finite) {
+            ERHS(yn[0], k[6]);
+            for (int m = 0; m < 3; m++) {
+                const double sc = atol + rtol*fmax(fabs(y[m].v), fabs(yn[m].v));
+                err = fmax(err, fabs(h*(e1*k[0][m].v + e3*k[2][m].v + e4*k[3][m].v + e5*k[4][m].v + e6*k[5][m].v + e7*k[6][m].v)/sc));
+            }
+        }
+        if (finite && err <= 1.0) {
+            sig += h;
+            for (int m = 0; m < 3; m++) { y[m] = yn[m]; k[0][m] = k[6][m]; }
+        }
+        const double fac = !finite ? 0.2 : (err > 0) ? 0.9*pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+        if (h < 1e-14) break;
+    }
+#undef ERHS
+    if (!(sig >= 1.0)) { y[1] = j4_const(NAN); y[2] = j4_const(NAN); }
+    E[0] = y[1]; E[1] = y[2];
+}
+
+/* test hook: E_tr, E_rgb and their derivatives wrt (v0, dt, w, f): out[k][15] = value, 4 first, 10 second (00 01 02 03 11 12 13 22 23 33);
+ * atol, rtol > 0: those tolerances instead of CVODES' */
+void oracle_loss_energy(const int *ip, const double *dp, double v0, double dt, double w, double f, double grad, double curv, double atol, double rtol, double *out30)
+{
+    Prob P; prob_init(&P, ip, dp, NULL, NULL, NULL, NULL);
+    jet4 E[2];
+    const double a0 = g_le_atol, r0 = g_le_rtol;
+    if (atol > 0 && rtol > 0) { g_le_atol = atol; g_le_rtol = rtol; }      /* (tests only, single-threaded) */
+    loss_energy(&P, v0, dt, w, f, track_resistance(&P, grad, curv), E, 2);
+    g_le_atol = a0; g_le_rtol = r0;
+    for (int r = 0; r < 2; r++) {
+        out30[15*r] = E[r].v;
+        for (int k = 0; k < 4; k++) out30[15*r + 1 + k] = E[r].g[k];
+        for (int k = 0; k < 10; k++) out30[15*r + 5 + k] = E[r].h[k];
+    }
+}
+
 /*
  * One shooting interval: tau = t+ - t and b+ as jets in (b, w), w = Fel + Fpb.
  * numApprox == 0: RK4 on (t, b) jointly (train.py:296-301, dt/ds = ds/sqrt(b) :255,258).
@@ -770,7 +889,13 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     e->d[RACC] = W->rs[RACC]*(f + p - (P->sr0 + P->sr1*sb + P->sr2*b) - W->G[i]);
     double lr[2][6];
     jet3 X = j3_const(0);
-    if (P->lossKind == 2) {
+    jet4 E4[2];
+    const int tabInt = P->lossKind == 2 && P->intLosses && P->energyOpt;      /* loss table integrated over the running time (loss_energy) */
+    if (tabInt) {
+        loss_energy(P, sb, x1[VT] - x[VT], f + p, f, W->G[i], E4, order ? 2 : 0);      /* ocp.py:233 */
+        e->d[RLTR] = W->rs[RLTR]*(s - E4[0].v);
+        e->d[RLRG] = W->rs[RLRG]*(s - E4[1].v);
+    } else if (P->lossKind == 2) {
         loss_rows(&P->dyn, f, 0.5*(sb + sb1), lr);
         e->d[RLTR] = W->rs[RLTR]*(s - lr[0][0]);
         e->d[RLRG] = W->rs[RLRG]*(s - lr[1][0]);
@@ -799,7 +924,7 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
     e->gr[RACC][LF] = 1; e->gr[RACC][LP] = P->withPn ? 1 : 0; e->gr[RACC][LB] = -(0.5*P->sr1/sb + P->sr2);
     e->hr[RACC][LB][LB] = 0.25*P->sr1/(b*sb);
     /* static loss rows (ocp.py:225-226 with train.py:203 / utils.py:197-220) */
-    if (P->lossKind == 2) {
+    if (P->lossKind == 2 && !tabInt) {
         /* rows s - g(f, vbar(b, b1)), vbar = (sqrt(b) + sqrt(b1))/2 */
         const double vb = 0.25/sb, vb1 = 0.25/sb1, vbb = -0.125/(b*sb), vb1b1 = -0.125/(x1[VB]*sb1);
         for (int k = 0; k < 2; k++) {
@@ -814,35 +939,53 @@ static void eval_interval(const Ws *W, const StageIt *it, int i, StageEv *e, int
             e->hr[r][LB][LB1] = e->hr[r][LB1][LB] = -gvv*vb*vb1;
         }
     } else if (P->intLosses && P->energyOpt) {
-        /* rows s + kappa f X(v(b), t1 - t, f + p): chain rule onto the local variables (b, f, p | t, t1) */
+        /* rows s + kappa_k phi_k(b, f, p, dt), dt = t1 - t.  Constant efficiencies: phi = f X(v(b), dt, f + p) for both rows, kappa = -ct, +cr.
+         * Loss table: phi_k = E_k(v(b), dt, f + p, f), kappa = -1.  Chain rule onto the local variables (b, f, p | t, t1) */
         const double vb = 0.5/sb, vbb = -0.25/(b*sb);
         enum { QB = 0, QF = 1, QP = 2, QD = 3 };      /* b, f, p, dt */
-        double X1[4], X2[4][4];
-        X1[QB] = X.g[0]*vb; X1[QF] = X.g[2]; X1[QP] = X.g[2]; X1[QD] = X.g[1];
-        X2[QB][QB] = X.h[0]*vb*vb + X.g[0]*vbb;
-        X2[QB][QF] = X2[QB][QP] = X.h[2]*vb; X2[QB][QD] = X.h[1]*vb;
-        X2[QF][QF] = X2[QF][QP] = X2[QP][QP] = X.h[5];
-        X2[QF][QD] = X2[QP][QD] = X.h[4];
-        X2[QD][QD] = X.h[3];
-        for (int a = 0; a < 4; a++) for (int c = 0; c < a; c++) X2[a][c] = X2[c][a];
-        double ph1[4], ph2[4][4];                         /* phi = f X */
-        for (int a = 0; a < 4; a++) {
-            ph1[a] = f*X1[a] + (a == QF ? X.v : 0.0);
-            for (int c = 0; c < 4; c++) ph2[a][c] = f*X2[a][c] + (a == QF ? X1[c] : 0.0) + (c == QF ? X1[a] : 0.0);
+        double ph1[2][4], ph2[2][4][4], kapv[2];
+        if (tabInt) {
+            for (int k = 0; k < 2; k++) {
+                const jet4 *E = &E4[k];
+                kapv[k] = -1.0;
+                ph1[k][QB] = E->g[0]*vb; ph1[k][QF] = E->g[2] + E->g[3]; ph1[k][QP] = E->g[2]; ph1[k][QD] = E->g[1];
+                ph2[k][QB][QB] = E->h[j4h(0, 0)]*vb*vb + E->g[0]*vbb;
+                ph2[k][QB][QF] = (E->h[j4h(0, 2)] + E->h[j4h(0, 3)])*vb; ph2[k][QB][QP] = E->h[j4h(0, 2)]*vb; ph2[k][QB][QD] = E->h[j4h(0, 1)]*vb;
+                ph2[k][QF][QF] = E->h[j4h(2, 2)] + 2*E->h[j4h(2, 3)] + E->h[j4h(3, 3)];
+                ph2[k][QF][QP] = E->h[j4h(2, 2)] + E->h[j4h(2, 3)]; ph2[k][QP][QP] = E->h[j4h(2, 2)];
+                ph2[k][QF][QD] = E->h[j4h(1, 2)] + E->h[j4h(1, 3)]; ph2[k][QP][QD] = E->h[j4h(1, 2)];
+                ph2[k][QD][QD] = E->h[j4h(1, 1)];
+                for (int a = 0; a < 4; a++) for (int c = 0; c < a; c++) ph2[k][a][c] = ph2[k][c][a];
+            }
+        } else {
+            double X1[4], X2[4][4];
+            X1[QB] = X.g[0]*vb; X1[QF] = X.g[2]; X1[QP] = X.g[2]; X1[QD] = X.g[1];
+            X2[QB][QB] = X.h[0]*vb*vb + X.g[0]*vbb;
+            X2[QB][QF] = X2[QB][QP] = X.h[2]*vb; X2[QB][QD] = X.h[1]*vb;
+            X2[QF][QF] = X2[QF][QP] = X2[QP][QP] = X.h[5];
+            X2[QF][QD] = X2[QP][QD] = X.h[4];
+            X2[QD][QD] = X.h[3];
+            for (int a = 0; a < 4; a++) for (int c = 0; c < a; c++) X2[a][c] = X2[c][a];
+            kapv[0] = -P->ct; kapv[1] = P->cr;
+            for (int k = 0; k < 2; k++)
+                for (int a = 0; a < 4; a++) {                         /* phi = f X */
+                    ph1[k][a] = f*X1[a] + (a == QF ? X.v : 0.0);
+                    for (int c = 0; c < 4; c++) ph2[k][a][c] = f*X2[a][c] + (a == QF ? X1[c] : 0.0) + (c == QF ? X1[a] : 0.0);
+                }
         }
         /* local columns of (b, f, p, dt): dt = t1 - t enters with +1 at LT1 and -1 at LT */
         const int col[4] = {LB, LF, LP, -1};
         for (int k = 0; k < 2; k++) {
             const int r = k == 0 ? RLTR : RLRG;
-            const double kap = k == 0 ? -P->ct : P->cr;
+            const double kap = kapv[k];
             e->gr[r][LS] = 1;
             for (int a = 0; a < 4; a++) {
                 if (a == QP && !P->withPn) continue;
-                if (col[a] >= 0) e->gr[r][col[a]] += kap*ph1[a];
-                else { e->gr[r][LT1] += kap*ph1[a]; e->gr[r][LT] -= kap*ph1[a]; }
+                if (col[a] >= 0) e->gr[r][col[a]] += kap*ph1[k][a];
+                else { e->gr[r][LT1] += kap*ph1[k][a]; e->gr[r][LT] -= kap*ph1[k][a]; }
                 for (int c = 0; c < 4; c++) {
                     if (c == QP && !P->withPn) continue;
-                    const double hv = kap*ph2[a][c];
+                    const double hv = kap*ph2[k][a][c];
                     const int na = col[a] >= 0 ? 1 : 2, nc = col[c] >= 0 ? 1 : 2;
                     const int ia[2] = {col[a] >= 0 ? col[a] : LT1, LT}, ic[2] = {col[c] >= 0 ? col[c] : LT1, LT};
                     const double sa[2] = {1, -1};
@@ -2497,7 +2640,7 @@ static void profile_guess(const Prob *P, double *z)
             if (P->hasPower) { const double vmx = fmax(v[i], v[i + 1]); fel = fmin(fmax(fel, -fabs(P->pwL)/vmx), fabs(P->pwU)/vmx); }
         }
         double sl;
-        if (P->lossKind == 2) { double lr[2][6]; loss_rows(&P->dyn, fel, 0.5*(v[i] + v[i + 1]), lr); sl = fmax(lr[0][0], lr[1][0]) + S0; }
+        if (P->lossKind == 2) { double lr[2][6]; loss_rows(&P->dyn, fel, 0.5*(v[i] + v[i + 1]), lr); sl = fmax(lr[0][0], lr[1][0])*(P->intLosses ? P->ds[i] : 1.0) + S0; }
         else sl = fmax(P->ct*fel, -P->cr*fel)*(P->intLosses ? P->ds[i] : 1.0) + S0;      /* integrateLosses: the slack is an energy per interval */
         q[0] = fel; if (P->withPn) q[1] = fpb;
         q[nu] = sl; q[nu + 1] = ti; q[nu + 2] = b[i];

@@ -77,3 +77,20 @@ def numpy_nlp(prob):
                          integrateLosses=bool(ip[IP['INTEGRATE_LOSSES']]))
 
 
+
+
+def gpops_profile_deviation(z, ds, stp=4):
+    """
+    A multiple-shooting solution of the figure-10 configuration against the GPOPS-II trajectory the reference holds (gpops/00_var_speed_limit_100_GPOPSII.csv,
+    278 rows of t, s, v; figure10.py:50-55,81-85 overlays it on the DMS solution): v(s) and t(s) of the solution interpolated at the GPOPS nodes
+    (b = v^2 linear in s between shooting nodes).  Returns max |dv|, rms dv, max |dt|.
+    """
+    import pandas as pd
+    from pathlib import Path
+    g = pd.read_csv(Path(__file__).resolve().parent / 'golden' / '00_var_speed_limit_100_GPOPSII.csv').drop_duplicates(subset='Position [m]')      # (figure10.py:52)
+    gs, gv, gt = g['Position [m]'].values, g['Velocity [m/s]'].values, g['Time [s]'].values
+    N = len(ds)
+    t, b = np.r_[z[stp - 2:stp*N:stp], z[-2]], np.r_[z[stp - 1:stp*N:stp], z[-1]]
+    pos = np.r_[0.0, np.cumsum(ds)]
+    dv, dt = np.abs(np.sqrt(np.interp(gs, pos, b)) - gv), np.abs(np.interp(gs, pos, t) - gt)
+    return float(dv.max()), float(np.sqrt((dv**2).mean())), float(dt.max())

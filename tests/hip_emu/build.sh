@@ -9,7 +9,7 @@ OUT=${OUT:-libmsd_emu.so}
 OBJ=${OBJDIR:-obj${SAN:+_san}}
 mkdir -p "$OBJ"
 pids=""
-for u in ${UNITS:-emu_driver emu_k_static emu_k_full emu_k_dynamic emu_k_general emu_k_intloss emu_k_stream}; do   # UNITS="emu_k_stream ...": only these (a quick look at one family; the other objects must be up to date)
+for u in ${UNITS:-emu_driver emu_k_static emu_k_full emu_k_dynamic emu_k_general emu_k_intloss emu_k_intloss_table emu_k_stream}; do   # UNITS="emu_k_stream ...": only these (a quick look at one family; the other objects must be up to date)
   g++ -std=c++17 $FLAGS -fPIC -pthread -ffp-contract=off -I. -c -o "$OBJ/$u.o" $u.cpp &
   pids="$pids $!"
 done

@@ -18,8 +18,20 @@
 
 #include "../../ms-eetc_amd/csrc/msd_kernel.hpp"
 
+/* MemorySanitizer build (tests/hip_emu/build_msan.sh, emu_msan_main.cpp): LDS and work area of an emulated workgroup start as uninitialised memory, so a
+ * read of shared memory before its first write is reported where it decides something -- with the origin of the value -- instead of showing as a NaN */
+#if defined(__has_feature)
+#if __has_feature(memory_sanitizer)
+#include <sanitizer/msan_interface.h>
+#define EMU_POISON_SHARED(p, n) __msan_poison((p), (n))
+#endif
+#endif
+#ifndef EMU_POISON_SHARED
+#define EMU_POISON_SHARED(p, n) ((void)0)
+#endif
 
-template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0>
+
+template <int NT, int SPT, int DYN, bool STREAM = false, bool GEN = false, int FULL = 0, int PART = 0, bool SLDS = false, bool SOCK = false>
 void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr, double *z, double *lam, double *stats, double *hist, int cap)
 {
     for (int b = 0; b < nscen; b++) {
@@ -27,20 +39,22 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
         std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, (FULL && DYN == 0 && !GEN) ? msd::XCH_FAST : msd::XCH_GENERAL,
-                                                                                                   (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
+                                                                                                   (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)) + (SLDS ? msd::STATIC_FIELDS*NT*SPT : 0));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
         /* EMU_POISON=1 (environment): LDS and work area start as NaN instead of zero -- a read of shared memory before its first write, which on the
          * device sees whatever the kernel before left there, then shows in the results */
         const char *poison = getenv("EMU_POISON");
         if (poison && *poison == '1') std::fill(lds.begin(), lds.end(), std::nan(""));
+        EMU_POISON_SHARED(lds.data(), 8*lds.size());
         blk.shfl = shfl.data(); blk.xch = xch.data(); blk.lds = lds.data();
         std::vector<double> work((STREAM ? msd::stream_doubles(P.N, NT*SPT, DYN != 0) : msd::work_doubles(NT*SPT))*(size_t)nscen);
         if (poison && *poison == '1') std::fill(work.begin(), work.end(), std::nan(""));
+        EMU_POISON_SHARED(work.data(), 8*work.size());
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++)
             th.emplace_back([&, t]() {
                 threadIdx = {(unsigned)t, 0, 0}; blockIdx = {(unsigned)b, 0, 0}; blockDim = {(unsigned)NT, 1, 1}; gridDim = {(unsigned)nscen, 1, 1};
                 emu_blk = &blk;
-                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL, PART>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
+                msd::solve_kernel<NT, SPT, 1, DYN, STREAM, GEN, FULL, PART, SLDS, SOCK>(P, nscen, scen, ovr, z, lam, stats, hist, cap, work.data());
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&blk.bar);
@@ -56,6 +70,7 @@ bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general(int NT, int SPT, const EmuArgs &a);
 bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general_intloss(int NT, int SPT, const EmuArgs &a);
+bool emu_run_intloss_table(int NT, int SPT, const EmuArgs &a);
 bool emu_run_stream(const EmuArgs &a);
 #define EMU_CALL(...) run_blocks<__VA_ARGS__>(a.P, a.nscen, a.scen, a.ovr, a.z, a.lam, a.stats, a.hist, a.cap)
 

@@ -29,7 +29,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
                                    double *z, double *lam, double *stats, double *hist, int cap)
 {
     msd::DevProb P;
-    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
+    P.guess = guess; P.guessStride = (4 + d->with_pn_brake)*d->num_intervals + 2; P.guessStatus = nullptr; P.warmMu = mu0; P.warmPush = push; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.socSeen = nullptr; P.dualOut = g_dual_out; P.dualIn = guess ? g_dual_in : nullptr; P.dualInStride = g_dual_stride; P.dualShift = 0;
     std::vector<double> pos(d->num_intervals + 1, 0.0);
     for (int i = 0; i < d->num_intervals; i++) pos[i + 1] = pos[i] + d->ds[i];
     P.pos = pos.data();
@@ -47,7 +47,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     const int nodes = P.N + 1;
     const EmuArgs a = {P, nscen, scen, ovr, z, lam, stats, hist, cap};
     if (d->integrate_losses) {      /* loss slacks from the integrated loss power (msd_lossint.hpp) */
-        if (dyn) return -3;
+        if (dyn) return (d->integrator == 0 && nodes <= 128 && emu_run_intloss_table(nodes <= 64 ? 64 : 128, 1, a)) ? 0 : -3;      /* the loss table integrated over the running time (msd_lossint_table.hpp) */
         if (d->integrator != 0) return (nodes <= 64 && emu_run_general_intloss(64, 1, a)) ? 0 : -3;      /* both options (msd_kernels_compose.hip) */
         return emu_run_intloss(64, nodes <= 64 ? 1 : 2, a) && nodes <= 128 ? 0 : -3;
     }

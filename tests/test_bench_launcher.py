@@ -96,6 +96,26 @@ def test_two_ranks_on_the_gpu_box():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('how', ['in_process', 'under_the_launcher'])
+def test_rccl_process_group_at_world_size_one(how):
+    """
+    The RCCL branch of bench.py -- `nccl` process group, the probing all-reduce, the barrier in front of and behind the timed region, the MAX and SUM
+    reductions -- on the one GPU of the box: `--process-group` forms the group at world size 1, directly and under the driver's launcher line
+    (torch.distributed.run --nproc-per-node 1), so that an 8-GPU run does not meet that code for the first time.  No scaling claim comes out of it.
+    """
+    env = _clean_env()
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    args = ['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-build', '--no-alt', '--no-cpu-baseline', '--process-group']
+    cmd = [sys.executable, str(ROOT / 'bench.py')] + args if how == 'in_process' else bench.rank_command(args, 1, bench.free_port())
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['config']['converged'] == 1024 and line['value'] > 1e5
+    assert line['config']['process_group_backend'] == 'nccl (RCCL)' and line['config']['world_size_seen'] == 1 and line['config']['device_of_rank'] == [0]
+    assert line['config']['by_rank']['ip_iterations_mean'][0] == pytest.approx(line['config']['ip_iterations_mean'])
+
+
+@pytest.mark.gpu
 def test_eight_ranks_config3_and_config4_on_the_gpu_box():
     """
     The launcher path of an 8-GPU run for BASELINE configs 3 and 4 at their full sizes, on the one device of the box (MSD_BENCH_SHARE_DEVICES=1:

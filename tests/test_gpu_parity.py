@@ -180,7 +180,28 @@ def test_figure10_configuration_and_gpops_limit():
         res = _compare(_solver(train, cases.track_00(), N), cases.oracle_problem(train, cases.track_00(), N), [1541.0])
         e[N] = res['cost'][0]
     g2 = pd.read_csv(Path(__file__).resolve().parent / 'golden' / '00_var_speed_limit_100_GPOPSII.csv')['Energy [kWh]'].iloc[0]
-    assert abs((9*e[300] - e[100])/8 - g2) < 0.02
+    assert abs((9*e[300] - e[100])/8 - g2) < 0.005      # (measured: 0.0016 kWh of 440.14)
+
+
+def test_figure10_solution_against_the_gpops_trajectory():
+    """
+    The only reference-held TRAJECTORIES of this OCP: the HIP solution of figure10.py's configuration at N = 1000 and N = 5000 (streamed
+    kernels) follows GPOPS-II's v(s) and t(s), closer with every refinement -- max |dv| 0.21 -> 0.08 m/s, rms 0.054 -> 0.018 m/s, max |dt| 2.3 -> 0.6 s of
+    1541 s (first order in 1/N: piecewise-constant forces against GPOPS's hp-collocation; N = 100 / 300: 2.1 / 0.64 m/s).  The energies: 440.377 / 440.181 kWh
+    against 440.1406.
+    """
+    train, track = cases.train_fig10(), cases.track_00()
+    dev = {}
+    for N in (1000, 5000):
+        s = _solver(train, track, N, start='profile', maxIterations=1000)
+        res = s.solveBatch([1541.0])
+        assert res['status'][0] == 0
+        dev[N] = cases.gpops_profile_deviation(res['z'][0], np.diff(s.points.index.values)) + (float(res['cost'][0]),)
+        s.close()
+    assert dev[1000][0] < 0.25 and dev[1000][1] < 0.065 and dev[1000][2] < 2.6, dev
+    assert dev[5000][0] < 0.10 and dev[5000][1] < 0.025 and dev[5000][2] < 0.8, dev
+    assert dev[5000][0] < 0.5*dev[1000][0] and dev[5000][2] < 0.4*dev[1000][2]
+    assert abs(dev[1000][3] - 440.3766) < 2e-3 and abs(dev[5000][3] - 440.1810) < 2e-3 and dev[5000][3] > 440.1406
 
 
 def test_minimum_time_constant_of_figure5():
@@ -1189,6 +1210,37 @@ def test_second_order_corrections_go_through_the_follow_up_kernel():
     assert np.max(np.abs(res['iterations'] - st[:, ST['ITERS']])) <= 2
     assert np.max(np.abs(res['cost'] - st[:, ST['OBJ']])/np.abs(st[:, ST['OBJ']])) <= 1e-7
     assert np.max(np.abs(res['z'] - z)/np.maximum(1.0, np.abs(z))) <= 1e-5
+    # Round 6: a handle whose launch has handed a correction over takes the first-pass kernel with the correction INSIDE the fused iteration from then on
+    # (msd_kernel.hpp: SOCK; msd_api.hip: launch) -- the same batch again: nothing is handed over for that reason, the corrections are counted by the fused
+    # iteration itself and agree with the oracle's, scenario for scenario
+    res2 = s.solveBatch(T)
+    t2, why2 = s.problem.follow_counts()
+    assert np.all(res2['status'] == 0)
+    assert why2[3] == why1[3], (why1, why2)
+    assert np.array_equal(res2['stats'][:, ST['N_SOC']], st[:, ST['N_SOC']])
+    assert np.max(np.abs(res2['iterations'] - st[:, ST['ITERS']])) <= 2
+    assert np.max(np.abs(res2['cost'] - st[:, ST['OBJ']])/np.abs(st[:, ST['OBJ']])) <= 1e-7
+    assert np.max(np.abs(res2['z'] - z)/np.maximum(1.0, np.abs(z))) <= 1e-5
+    s.close()
+    # ... on two nodes per lane as well (N = 100, config 1's geometry with the node constants in LDS): loose-ish schedules on the cropped track
+    track = cases.track_00(30000)
+    s = _solver(train, track, 70, start='profile')
+    prob = cases.oracle_problem(train, track, 70)
+    T = 1050.0*(1.0 + 0.4*np.random.default_rng(6).random(256))
+    T[0] = 1140.8291957305269*(70/60)
+    first = s.solveBatch(T)
+    w1 = s.problem.follow_counts()[1]
+    again = s.solveBatch(T)
+    w2 = s.problem.follow_counts()[1]
+    scen = np.stack([np.zeros_like(T), T, np.ones_like(T), np.ones_like(T)], axis=1)
+    z, st, nfail = oracle.solve_batch(prob, scen, nthreads=0, start='profile')
+    assert nfail == 0 and np.all(first['status'] == 0) and np.all(again['status'] == 0)
+    if st[:, ST['N_SOC']].sum() > 0:
+        assert w1[3] > 0 and w2[3] == w1[3]
+    for r in (first, again):
+        assert np.array_equal(r['stats'][:, ST['N_SOC']], st[:, ST['N_SOC']])
+        assert np.max(np.abs(r['iterations'] - st[:, ST['ITERS']])) <= 2
+        assert np.max(np.abs(r['cost'] - st[:, ST['OBJ']])/np.abs(st[:, ST['OBJ']])) <= 1e-7
     s.close()
 
 
@@ -1347,3 +1399,49 @@ def test_short_horizons_through_the_follow_up_kernel(variant):
                     assert abs(int(res['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2, (N, start, k, res['iterations'][k], ref['stats']['ITERS'])
                 assert abs(res['cost'][k] - ref['stats']['OBJ']) <= (1e-6 if through_resto else 1e-7)*max(1e-3, abs(ref['stats']['OBJ'])), (N, start, k)
             s.close()
+
+
+@pytest.mark.parametrize('case', ['seed105', 'seed125', 'short_rg', 'short_both', 'n100_rg'])
+def test_follow_up_kernels_are_deterministic_launch_to_launch(case, tmp_path):
+    """
+    The follow-up kernels (general iteration, restoration phase, second attempt) return the same bits from launch to launch -- what the reference's scripts
+    assert of repeated solves (figure6.py:191-193: identical iteration counts).  Round 5 shipped a register read before its first write (Solver::evs) that no
+    test could see: one-brake problems from the reference's starting point took 45 / 46 / 47 iterations in the follow-up kernel from one launch to the next
+    where the oracle takes 71 (random-sweep seeds 105 and 125).  Six launches of the same running times: identical status, iteration counts, z and
+    statistics; the scenarios went through the follow-up kernel; iteration counts equal the oracle's where no restoration phase is on the way.
+    """
+    from oracle import oracle
+    from mseetc._device import ST
+    if case.startswith('seed'):
+        train, track, N, rng = _random_problem(int(case[4:]), tmp_path)
+        v0, vN = float(rng.uniform(1, 15)), float(rng.uniform(1, 15))
+        po = cases.oracle_problem(train, track, N, energyOptimal=False, losses='none')
+        tmin = float(oracle.solve(po, po.scenario(3*track.length/train.velocityMax, 0.0, vN, v0), start='profile')['z'][-2])
+        T = tmin*np.array([1.05, 1.1, 1.2, 1.45, 2.0])
+    else:
+        train = cases.train_default() if case == 'short_both' else cases.train_fig10()
+        N, crop = (100, None) if case == 'n100_rg' else (50, 20000)
+        track = cases.track_00(crop) if crop else cases.track_00()
+        v0 = vN = 1.0
+        T = np.array([1541.0, 1700.0, 4000.0, 9000.0, 14000.0])*((crop or 48531)/48531.0)
+    s = _solver(train, track, N, start='reference', maxIterations=800)
+    before = s.problem.follow_counts()[0]
+    runs = [s.solveBatch(T, initialVelocity=v0, terminalVelocity=vN) for _ in range(6)]
+    handed = s.problem.follow_counts()[0] - before
+    s.close()
+    first = runs[0]
+    for r in runs[1:]:
+        assert np.array_equal(r['status'], first['status']) and np.array_equal(r['iterations'], first['iterations']), (case, [list(x['iterations']) for x in runs])
+        assert np.array_equal(r['z'], first['z'])
+        keep = [k for k in range(ST['COUNT']) if k not in (ST['CYC_TOTAL'], ST['CYC_KKT'])]      # (time stamps)
+        assert np.array_equal(r['stats'][:, keep], first['stats'][:, keep])
+    assert np.all(first['status'] >= 0), first['status']
+    if case != 'n100_rg':
+        assert handed >= 6      # (at least one scenario per launch took the follow-up kernel's path)
+    prob = cases.oracle_problem(train, track, N, maxIterations=800)
+    for k, t in enumerate(T):
+        ref = oracle.solve(prob, prob.scenario(float(t), 0.0, vN, v0), start='reference')
+        assert ref['stats']['STATUS'] >= 0
+        if first['stats'][k, ST['N_RESTO']] == 0 and ref['stats']['N_RESTO'] == 0:
+            assert abs(int(first['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2, (case, k, first['iterations'][k], ref['stats']['ITERS'])
+        assert abs(first['cost'][k] - ref['stats']['OBJ']) <= 1e-6*max(1e-3, abs(ref['stats']['OBJ'])), (case, k)

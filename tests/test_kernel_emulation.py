@@ -17,11 +17,96 @@ import cases
 EMU = Path(__file__).resolve().parent / 'hip_emu'
 
 
+class MsanProxy:
+    """
+    Stands in for the emulation library when MSD_EMU_MSAN names the MemorySanitizer build of the emulation (tests/hip_emu/build_msan.sh: an executable --
+    MSan needs an instrumented main program, the interpreter is not one).  Every emu_solve_batch* call is written to a case file, run by that program
+    (tests/hip_emu/emu_msan_main.cpp) and read back into the caller's arrays; a report of MemorySanitizer (exit code 77) fails the calling test with the
+    report as the message.  The emulation tests run unchanged (tests/hip_emu/run_msan.sh).
+    """
+
+    DUAL_STRIDE = 27      # MSD_DUAL_STRIDE
+
+    class _Fn:
+        def __init__(self, f):
+            self.f = f
+
+        def __call__(self, *a):
+            return self.f(*a)
+
+    def __init__(self, exe):
+        self.exe = str(exe)
+        self.dual_in = self.dual_out = None
+        self.dual_stride = 0
+        self.emu_solve_batch = self._Fn(lambda desc, nscen, scen, z, lam, st, hist, cap: self._run(desc, nscen, scen, None, None, 0.0, 0.0, z, lam, st, hist, cap))
+        self.emu_solve_batch_warm = self._Fn(self._run)
+        self.emu_set_duals = self._Fn(self._set_duals)
+
+    @staticmethod
+    def _addr(p):
+        return None if p is None else ctypes.cast(p, ctypes.c_void_p).value
+
+    @classmethod
+    def _view(cls, p, n):
+        a = cls._addr(p)
+        return None if not a else np.ctypeslib.as_array((ctypes.c_double*n).from_address(a))
+
+    def _set_duals(self, dual_in, stride, dual_out):
+        self.dual_in, self.dual_stride, self.dual_out = dual_in, int(stride), dual_out
+
+    def _run(self, desc, nscen, scen, ovr, guess, mu0, push, z, lam, st, hist, cap):
+        import os
+        import tempfile
+        d = desc._obj
+        N = d.num_intervals
+        nz = (4 + d.with_pn_brake)*N + 2
+        rpi = (2 if d.has_power_rows else 0) + 3 + (2 if d.energy_optimal else 0)
+        rec = (N + 1)*self.DUAL_STRIDE
+        loss = self._view(d.loss_table, d.loss_table_len) if d.loss_kind == 2 else None
+        coll = self._view(d.coll_tables, (d.coll_degree + 1)**2 + d.coll_degree + 1) if d.integrator == 2 else None
+        g = self._view(guess, nscen*nz)
+        o = self._view(ovr, nscen*10)
+        nrec_in = 0 if (self._addr(self.dual_in) is None or g is None) else (1 if self.dual_stride == 0 else nscen)
+        din = None
+        if nrec_in:
+            span = rec if nrec_in == 1 else (nscen - 1)*self.dual_stride + rec
+            raw = self._view(self.dual_in, span)
+            din = np.concatenate([raw[k*self.dual_stride:k*self.dual_stride + rec] for k in range(nrec_in)])
+        has_out = self._addr(self.dual_out) is not None
+        hdr = np.array([0x4d53414e, ctypes.sizeof(d), nscen, cap, o is not None, g is not None, nrec_in, has_out, 0 if nrec_in <= 1 else rec,
+                        0 if loss is None else loss.size, 0 if coll is None else coll.size, rec], dtype=np.int64)
+        with tempfile.TemporaryDirectory() as tmp:
+            case, res = os.path.join(tmp, 'case.bin'), os.path.join(tmp, 'result.bin')
+            with open(case, 'wb') as f:
+                f.write(hdr.tobytes()); f.write(np.array([mu0, push]).tobytes()); f.write(bytes(d))
+                for a in (self._view(d.ds, N), self._view(d.grad, N), self._view(d.curv, N), self._view(d.bmax, N + 1), loss, coll,
+                          self._view(scen, nscen*4), o, g, din):
+                    if a is not None:
+                        f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+            env = dict(os.environ, MSAN_OPTIONS='exit_code=77:halt_on_error=1')
+            r = subprocess.run([self.exe, case, res], capture_output=True, text=True, env=env, timeout=3600)
+            if r.returncode != 0:
+                raise AssertionError("MemorySanitizer build of the emulation, exit code {}:\n{}".format(r.returncode, r.stderr[-6000:]))
+            out = np.fromfile(res, dtype=np.float64)
+        rc = int(out[:1].view(np.int64)[0])
+        if rc != 0:
+            return rc
+        k = 1
+        for p, n in ((z, nscen*nz), (lam, nscen*rpi*N), (st, nscen*16), (hist, cap*8), (self.dual_out if has_out else None, nscen*rec if has_out else 0)):
+            v = self._view(p, n) if n else None
+            if v is not None:
+                v[:] = out[k:k + n]
+            k += n
+        return 0
+
+
 def load_emulation():
     "Build (when out of date) and load the host emulation of the kernels."
     src = sorted(EMU.glob('*.cpp')) + sorted(EMU.glob('*.h')) + [EMU / 'build.sh', EMU / 'hip' / 'hip_runtime.h'] \
         + sorted((EMU.parent.parent / 'ms-eetc_amd' / 'csrc').glob('*.hpp')) + [EMU.parent.parent / 'include' / 'mseetc_hip.h']
     import os
+    if os.environ.get('MSD_EMU_MSAN'):      # the MemorySanitizer build made by tests/hip_emu/run_msan.sh
+        return MsanProxy(os.environ['MSD_EMU_MSAN'])
     if os.environ.get('MSD_EMU_LIB'):      # a sanitizer build made by tests/hip_emu/run_sanitizers.sh
         so = Path(os.environ['MSD_EMU_LIB'])
         lib = ctypes.CDLL(str(so))
@@ -65,6 +150,35 @@ def test_emulated_kernel_matches_oracle(emu, N, crop, T, start):
     assert int(st[0, ST['N_SOC']]) == int(ref['stats']['N_SOC']) == (1 if T in (804.9041795334854, 1140.8291957305269) else 0)
     assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
     # the multipliers of a converged solve are determined to the solver tolerance (1e-8 on the scaled problem): relative bound
+    assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
+
+
+@pytest.mark.parametrize('N,crop,T', [(40, 16000, 804.9041795334854), (60, 30000, 1140.8291957305269), (100, None, 1541.0)])
+def test_emulated_second_order_correction_inside_the_fused_iteration(emu, N, crop, T, monkeypatch):
+    """
+    The first-pass kernels with the second-order correction (W&B section 2.4; IPOPT's default, ocp.py:290) inside the fused iteration (Solver: SOCK,
+    msd_kernels_full4.hip -- what the shrinking-horizon loop and a handle that has met corrections launch): the two solves of
+    test_emulated_kernel_matches_oracle that take a correction, one node per lane and two, run through the first pass ALONE (no follow-up kernel: EMU_NO_FOLLOW)
+    and follow the oracle -- iterations, number of corrections, point; the third case takes none and runs the 64 x 2 kernel with the node constants in LDS.
+    """
+    from mseetc.ocp import casadiSolver
+    from mseetc._device import ST
+    from oracle import oracle
+    monkeypatch.setenv('EMU_SOCK', '1')
+    monkeypatch.setenv('EMU_NO_FOLLOW', '1')
+    train, track = cases.train_default(), (cases.track_00(crop) if crop else cases.track_00())
+    solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=300, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+    scen = solver._scenarios(T, 0, 1, 1)
+    nz = (4 + int(solver.withPnBrake))*N + 2
+    z, lam, st, hist = np.zeros((1, nz)), np.zeros((1, 7*N)), np.full((1, ST['COUNT']), -77.0), np.zeros((8, 8))
+    d = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert emu.emu_solve_batch(ctypes.byref(solver._desc), 1, d(scen), d(z), d(lam), d(st), d(hist), 8) == 0
+    prob = cases.oracle_problem(train, track, N)
+    ref = oracle.solve(prob, prob.scenario(T), start='profile')
+    assert st[0, ST['STATUS']] == 0 and ref['stats']['STATUS'] == 0
+    assert int(st[0, ST['ITERS']]) == int(ref['stats']['ITERS'])
+    assert int(st[0, ST['N_SOC']]) == int(ref['stats']['N_SOC']) == (0 if N == 100 else 1)
+    assert np.max(np.abs(z[0] - ref['z'])/np.maximum(1, np.abs(ref['z']))) < 1e-8
     assert np.max(np.abs(lam[0] - ref['lam_g'])/np.maximum(1, np.abs(ref['lam_g']))) < 1e-7
 
 
@@ -296,3 +410,21 @@ def test_emulation_under_sanitizers():
     "ASan + UBSan over the emulated kernel (all emulation tests, every geometry they use): tests/hip_emu/run_sanitizers.sh must pass."
     r = subprocess.run([str(EMU / 'run_sanitizers.sh')], capture_output=True, text=True, timeout=3600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('RUN_SANITIZERS'), reason="opt-in (an hour of CPU): RUN_SANITIZERS=1")
+def test_emulation_under_memory_sanitizer():
+    """
+    MemorySanitizer (ROCm's clang) over the emulated kernels of every family -- fused first pass, follow-up kernels, restoration phase, watchdog procedure,
+    streamed kernel, the other shooting integrators and loss models: no local, LDS word or work-area word is read before it is written where the value
+    decides anything (round 5's Solver::evs was of that class and invisible to ASan, UBSan and the poisoned run).  tests/hip_emu/run_msan.sh must pass.
+    """
+    r = subprocess.run([str(EMU / 'run_msan.sh')], capture_output=True, text=True, timeout=4*3600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('RUN_SANITIZERS'), reason="opt-in (twenty minutes of CPU): RUN_SANITIZERS=1")
+def test_compilers_name_no_uninitialized_read_in_the_device_header():
+    "g++ -O2 -Werror=maybe-uninitialized and clang -Werror=sometimes/conditional-uninitialized over every emulation unit: tests/hip_emu/check_uninitialized.sh"
+    r = subprocess.run([str(EMU / 'check_uninitialized.sh')], capture_output=True, text=True, timeout=2*3600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])

@@ -233,15 +233,14 @@ def test_gpu_adaptive_integrator_shared_evaluation_equals_the_sequential_one(mon
     for v0 in (1.0, 20.0):
         out = {}
         for geometry in ('default', '64x2'):
-            if geometry == 'default':
-                monkeypatch.delenv('MSD_GEOMETRY2', raising=False)
-            else:
-                monkeypatch.setenv('MSD_GEOMETRY2', geometry)
+            from mseetc._device import lib
+            assert lib().msd_tuning(b'two_nodes_per_lane', int(geometry == '64x2')) == 0
             solver = casadiSolver(train, track, dict(numIntervals=100, maxIterations=400, integrationMethod='CVODES'), startingPoint='profile')
             scen = solver._scenarios(Ts, 0, 1, v0)
             out[geometry] = solver.problem.solve_batch(scen)
             assert tuple(solver.problem.geometry()) == ((128, 1) if geometry == 'default' else (64, 2))
             solver.close()
+            lib().msd_tuning(b'two_nodes_per_lane', 0)
         a, b = out['default'], out['64x2']
         assert np.all(a['stats'][:, 0] == 0) and np.all(b['stats'][:, 0] == 0)
         assert np.array_equal(a['stats'][:, 1], b['stats'][:, 1])                                     # iterations

@@ -8,6 +8,10 @@ sys.path[:0] = [R + '/ms-eetc_amd', R]
 import numpy as np
 from mseetc import workloads as wl
 from mseetc.ocp import casadiSolver
+from mseetc._device import lib
+# (the pickers' tuning switches go through the ABI -- msd_tuning of include/mseetc_aux.h; this script keeps its two environment knobs for A/B runs)
+lib().msd_tuning(b'two_nodes_per_lane', int(os.environ.get('MSD_GEOMETRY2') == '64x2'))
+lib().msd_tuning(b'no_full', int(os.environ.get('MSD_NO_FULL') == '1'))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 train, track, N = wl.config('c1')
 T = wl.c1_times(B, seed=20260612)
