@@ -707,6 +707,50 @@ def alt_workloads(args, device):
                                                         "that converge (the others end at the iteration limit on the device and on the CPU oracle alike)".format(Nd))
         sv.close()
 
+        if Nd == 100:
+            # ... and the same loss model integrated over the running time inside the NLP (integrateLosses=True: the switch of figure6.py:178; round 6, DYN = 3)
+            import copy
+            so = copy.deepcopy(wl.options(Nd)); so['integrateLosses'] = True
+            sv = _cs(tr, wl.track_00(8500), so, device=device)
+            sc = sv._scenarios(Td[:256], 0, 100/3.6, 1)
+            first = sv.problem.solve_batch(sc)
+            good = first['stats'][:, _ST['STATUS']] >= 0
+            e, ms, st = measure(sv, np.ascontiguousarray(sc[good]), None, 3, 1)
+            alt["dynamic_losses_integrated_N100"] = dict(summarize(int(good.sum()), Nd, 3, e, ms, st), kernel="msd::solve_kernel<{},{}> with the loss table integrated over the running time (DYN = 3)".format(*sv.problem.geometry()),
+                                                         running_times=256, running_times_not_converging=int((~good).sum()),
+                                                         workload="the figure-5 configuration with the dynamic loss model and integrateLosses=True (ocp.py:231-241 -> train.py:367-413; figure6.py:178), N = 100, 256 running times")
+            sv.close()
+
+    # one solve at a time -- how every script of the reference drives the API (table3.py:53-64: the minimum of five runs of casadiSolver.solve per horizon): wall time of
+    # solve() with the DataFrame and its post-processing, wall time of the batched entry for the one scenario, the kernels' own time, and the CPU oracle on one thread
+    # beside them.  figure-10 train (forceMinPn = 0, table3.py:18) on the full track, T = 1541 s.
+    from oracle import oracle as _orc                      # the checker, timed here as the CPU baseline of the row (kind: port)
+    import io, contextlib
+    single = {}
+    tr10 = wl.train_default()
+    tr10.forceMinPn = 0; tr10.forceMin = -tr10.forceMax; tr10.powerMax = 3129277; tr10.powerMin = -tr10.powerMax; tr10.etaTraction = tr10.etaRgBrake = 0.73
+    for Ns in (100, 300, 1000, 5000):
+        sv = _cs(tr10, wl.track_00(), dict(numIntervals=Ns, maxIterations=1000, integrationOptions=dict(numSteps=1, numApproxSteps=1)), device=device)
+        t_solve, t_batch, t_kernel = [], [], []
+        with contextlib.redirect_stdout(io.StringIO()):
+            sv.solve(1541.0)      # (first call: library and handle warm)
+            for _ in range(5):
+                t0 = time.perf_counter(); df, stt = sv.solve(1541.0); t_solve.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); r = sv.solveBatch([1541.0]); t_batch.append(time.perf_counter() - t0)
+                t_kernel.append(float(r['kernel_ms']))
+        from mseetc.track import computeDiscretizationPoints as _cdp
+        op = _orc.pack_problem(tr10, _cdp(wl.track_00(), Ns), dict(numIntervals=Ns, maxIterations=1000, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1), 1, 0.27/0.73, 0.27, wl.track_00().length)
+        t0 = time.perf_counter(); ro = _orc.solve(op, op.scenario(1541.0), start='profile'); t_cpu = time.perf_counter() - t0
+        single["N%d" % Ns] = {"solve_ms": 1e3*min(t_solve), "solve_batch_of_one_ms": 1e3*min(t_batch), "kernel_ms": min(t_kernel), "ip_iterations": int(r['iterations'][0]),
+                              "converged": bool(r['status'][0] >= 0 and df is not None), "cost_kWh": float(r['cost'][0]),
+                              "cpu_oracle_one_thread_ms": 1e3*t_cpu, "cpu_oracle_iterations": int(ro['stats']['ITERS'])}
+        sv.close()
+    single["workload"] = ("casadiSolver(train, track, opts).solve(1541) one scenario at a time, figure-10 train on 00_var_speed_limit_100, profile start; min of 5 like table3.py:53-64: "
+                          "solve_ms = wall time of solve() including the DataFrame and postProcessDataFrame (its CVODES re-simulation on the device), "
+                          "solve_batch_of_one_ms = the batched entry for one scenario (upload, kernels, download), kernel_ms = device time of the kernels; "
+                          "cpu_oracle_one_thread_ms = the C oracle on one host thread, same starting point.  The reference publishes 4.96 / 6.99 s for GPOPS on this problem (BASELINE.md)")
+    alt["single_solve"] = single
+
     # the host-buffer entry point (msd_solve_batch: scenarios from and results into host memory): the PCIe-inclusive rate of the same workload,
     # wall clock over ten calls -- upload of the scenario records, launch, download of z* and the statistics.  Never the headline value.
     hb = {}

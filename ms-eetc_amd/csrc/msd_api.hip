@@ -169,16 +169,10 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     pl.max_grid = per_cu*cus;
     pl.max_grid2 = 0;
     pl.NT2 = geo.NT; pl.SPT2 = geo.SPT; pl.lds_bytes2 = lds;
-#ifdef MSD_FOLLOW_64X1
-    if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST && full) {      /* (diagnostic build: the one-brake family keeps its 64 x 1 follow-up kernel) */
-#else
-    if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST) {
-#endif
-        /* horizons of up to 63 intervals: the first pass runs one node per lane, the follow-up kernel is the two-nodes-per-lane one (its second node
-         * slots stay idle).  The follow-up kernel restarts a scenario from its starting point, so nothing ties its geometry to the first pass's; and
-         * the 64 x 1 instantiation of the one-brake follow-up kernel faults on the device (round 4: `solve_kernel<64, 1, 1, 0, false, false, 2, 2>`
-         * with the phase fences -- the host emulation of the same code runs clean under the sanitizers, a build of that kernel without the fences
-         * takes another path than every other implementation: a code-generation problem of that one instantiation, tools/probe_follow_rg*.py) */
+    if (geo.fn2 && geo.NT == 64 && geo.SPT == 1 && geo.xch == msd::XCH_FAST && full) {
+        /* horizons of up to 63 intervals, both brakes: the first pass runs one node per lane, the follow-up kernel is the two-nodes-per-lane one (its second
+         * node slots stay idle; the follow-up kernel restarts a scenario from its starting point, so nothing ties its geometry to the first pass's -- and the
+         * family has no 64 x 1 follow-up instantiation).  The one-brake family has its 64 x 1 follow-up kernel back (round 6: msd_kernels_rg2.hip) */
         geo.fn2 = full ? msd::follow_kernel_full(64, 2) : msd::follow_kernel_full_rg(64, 2);
         pl.NT2 = 64; pl.SPT2 = 2;
         pl.lds_bytes2 = sizeof(double)*(size_t)msd::lds_doubles(N, 128, wide, geo.xch, geo.red);

