@@ -12,7 +12,10 @@ namespace msd {
  * inf, which every caller's finiteness / positivity test catches as before).  fsqrt2: v_rsq_f64 + one coupled Goldschmidt step + two residual
  * corrections -- the compiler's own refinement without its scaling -- returning the root and, from the same registers plus one Newton step, its
  * reciprocal (<= 1 ulp each: tests/test_gpu_parity.py::test_fast_reciprocal_and_square_root).
- * The general iteration (follow-up kernels, restoration, watchdog) keeps the IEEE operations: FM = false. */
+ * The general iteration (follow-up kernels, restoration, watchdog) keeps the IEEE operations in its own passes (FM = false).  Two shared pieces take
+ * frcp / fsqrt2 in every kernel: the 3 x 3 inverse of the scans' combines (msd_scan.hpp: inv3 -- one reciprocal of a determinant that the caller checks) and
+ * the right-hand side and step-size factor of the adaptive shooting integrator (msd_integ.hpp).  So a follow-up kernel agrees with the host emulation (IEEE
+ * throughout) to rounding, not bit for bit; frcp(0) is a NaN where 1/0 is an infinity -- either fails the callers' tests (fabs(det) > 0, isfinite). */
 #ifndef MSD_FAST_MATH
 #define MSD_FAST_MATH 1
 #endif

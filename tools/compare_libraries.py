@@ -1,9 +1,14 @@
 """
-Bit-for-bit comparison of two builds of the HIP library on a GPU box -- the device half of the hunt for reads before writes (task 1 iii):
-a diagnostic build with -ftrivial-auto-var-init=pattern (tools/build_variant.py pattern --flags "-ftrivial-auto-var-init=pattern": every local that the
-compiler cannot prove written starts as a NaN pattern instead of whatever the register held) must return exactly the bits of the product build.  A local
-read before its first write (round 5: Solver::evs) shows as a difference or as a failed solve; identical results say the pattern never reached a value
-that decides anything.
+Comparison of two builds of the HIP library on a GPU box -- the device half of the hunt for reads before writes (task 1 iii): a diagnostic
+build with -ftrivial-auto-var-init=pattern (tools/build_variant.py pattern --flags "-ftrivial-auto-var-init=pattern": every local that the compiler cannot
+prove written starts as a NaN pattern instead of whatever the register held) against the product build.  A local read before its first write (round 5:
+Solver::evs) that decides anything shows as a NaN, a failed solve or another path through the iteration.
+
+What "equal" can mean: the two builds are not bit-identical in their arithmetic -- the initialising stores that survive change the shape of the code and with it
+where the compiler contracts a*b + c into an FMA (HIP's default -ffp-contract=fast): measured on the fused benchmark path, 7e-12 in z.  So the rule is: same
+status for every solve; the objective to 1e-7 relative (1e-9 absolute); iteration counts within 2 for solves of at most 100 iterations (a loose schedule that
+crawls for hundreds of iterations or ends at the iteration limit follows rounding noise in either build: its status and objective are compared, not its path);
+every entry finite where the other build's is.  Bit-identical arrays are counted as well.
 
     python tools/compare_libraries.py <library A> <library B>        (each library runs in a process of its own: MSD_LIB)
 
@@ -105,19 +110,40 @@ def main():
                 return 2
             outs.append(dict(np.load(out)))
     ra, rb = outs
-    bad = 0
-    for key in sorted(ra):
-        same = ra[key].shape == rb[key].shape and np.array_equal(ra[key], rb[key], equal_nan=True)
-        if not same:
+    same_bits = sum(1 for k in ra if ra[k].shape == rb[k].shape and np.array_equal(ra[k], rb[k], equal_nan=True))
+    bad, worst_obj, worst_z, nsolve, nfail, nloose = 0, 0.0, 0.0, 0, 0, 0
+    for key in sorted(k for k in ra if k.endswith('/stats')):
+        A, B = ra[key], rb[key]
+        nsolve += len(A); nfail += int((A[:, 0] < 0).sum())
+        finds = []
+        if not np.array_equal(A[:, 0], B[:, 0]):
+            finds.append('status A %s B %s' % (A[:, 0].astype(int).tolist(), B[:, 0].astype(int).tolist()))
+        if not np.array_equal(np.isfinite(A), np.isfinite(B)):
+            finds.append('non-finite entries differ')
+        ok = (A[:, 0] >= 0) & (B[:, 0] >= 0)
+        dobj = np.abs(A[ok, 2] - B[ok, 2])/np.maximum(np.abs(A[ok, 2]), 1e-2)
+        worst_obj = max(worst_obj, float(dobj.max()) if dobj.size else 0.0)
+        if dobj.size and dobj.max() > 1e-7:
+            finds.append('objective differs by %.2e (scenarios %s)' % (dobj.max(), np.flatnonzero(ok)[dobj > 1e-7].tolist()))
+        short = ok & (A[:, 1] <= 100) & (B[:, 1] <= 100)
+        nloose += int((ok & ~short).sum())
+        dit = np.abs(A[short, 1] - B[short, 1])
+        if dit.size and dit.max() > 2:
+            finds.append('iterations A %s B %s' % (A[short, 1][dit > 2].astype(int).tolist(), B[short, 1][dit > 2].astype(int).tolist()))
+        zk = key[:-len('stats')] + 'z'
+        if zk in ra and short.any():
+            dz = np.abs(ra[zk][short] - rb[zk][short])/np.maximum(1.0, np.abs(ra[zk][short]))
+            worst_z = max(worst_z, float(np.nanmax(dz)))
+        if finds:
             bad += 1
-            d = np.abs(ra[key] - rb[key]) if ra[key].shape == rb[key].shape else None
-            print('DIFFERENT', key, 'max abs difference', None if d is None else float(np.nanmax(d)), 'entries', None if d is None else int((d > 0).sum()))
-            if key.endswith('/stats') and d is not None:
-                rows = np.flatnonzero((d > 0).any(axis=1))
-                print('    scenarios', rows[:10], 'status A', ra[key][rows[:10], 0], 'B', rb[key][rows[:10], 0], 'iterations A', ra[key][rows[:10], 1], 'B', rb[key][rows[:10], 1])
-    nsolve = sum(v.shape[0] for k, v in ra.items() if k.endswith('/stats'))
-    nfail = sum(int((v[:, 0] < 0).sum()) for k, v in ra.items() if k.endswith('/stats'))
-    print('%d result arrays, %d solves (%d failed in A): %d arrays differ between\n  A %s\n  B %s' % (len(ra), nsolve, nfail, bad, a, b))
+            print('FINDING', key[:-len('/stats')], '; '.join(finds))
+    for key in ('mpc/t0', 'mpc/cost'):
+        if key in ra and not np.allclose(ra[key], rb[key], rtol=1e-6, atol=1e-6, equal_nan=True):
+            bad += 1
+            print('FINDING', key, 'max difference', float(np.nanmax(np.abs(ra[key] - rb[key]))))
+    print('%d result arrays (%d bit-identical), %d solves (%d failed in A and B alike unless listed, %d long or crawling ones compared by status and objective only): %d findings; '
+          'largest objective difference %.1e relative, largest difference of a variable on the ordinary solves %.1e\n  A %s\n  B %s'
+          % (len(ra), same_bits, nsolve, nfail, nloose, bad, worst_obj, worst_z, a, b))
     return 1 if bad else 0
 
 
