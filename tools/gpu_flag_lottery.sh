@@ -1,32 +1,31 @@
 #!/bin/bash
 # Compiler-flag A/B of the benchmark kernel on a GPU box: msd_kernels_full.hip (the fused first-pass kernels; -DMSD_HOT_ONLY_64X2: the benchmark geometry alone) in a
 # handful of scheduling / allocation variants, compiled side by side, each timed on config 1 at 1024 and 8192 scenarios per launch.  A flag the compiler does not know
-# fails its build and is reported as such.   usage: tools/gpu_flag_lottery.sh <outdir-name>
+# fails its build and is reported as such.   usage: tools/gpu_flag_lottery.sh <outdir-name> [variants-file]
 name=${1:-lottery}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$name
 mkdir -p $O
 cd $R
 declare -A V
+if [ -n "$2" ]; then
+  # variants from a file: lines "tag|<build_hot.py arguments: -D switches and/or --flags "...">"
+  while IFS='|' read -r t f; do [ -n "$t" ] && V[$t]="$f"; done < "$2"
+else
 V[base]=""
-V[nomisched]="-mllvm -enable-misched=false"
-V[nopostmisched]="-mllvm -enable-post-misched=false"
-V[relaxocc]="-mllvm -amdgpu-schedule-relaxed-occupancy=true"
-V[o2]="-O2"
-V[os]="-Os"
-V[unroll]="__NOSOLVEFLAGS__"
-V[maxilp]="-mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1"
-V[noagprspill]="-mllvm -amdgpu-spill-vgpr-to-agpr=0"
-V[topdown]="-mllvm -misched-topdown"
-V[bottomup]="-mllvm -misched-bottomup"
-V[norewrite]="-mllvm -amdgpu-enable-rewrite-partial-reg-uses=0"
-V[splitall]="-mllvm -split-spill-mode=size"
-V[earlyinline]="-mllvm -amdgpu-early-inline-all=true"
+V[nomisched]="--flags \"-mllvm -enable-misched=false\""
+V[nopostmisched]="--flags \"-mllvm -enable-post-misched=false\""
+V[relaxocc]="--flags \"-mllvm -amdgpu-schedule-relaxed-occupancy=true\""
+V[o2]="--flags -O2"
+V[os]="--flags -Os"
+V[unroll]="--no-solve-flags"
+V[noagprspill]="--flags \"-mllvm -amdgpu-spill-vgpr-to-agpr=0\""
+V[norewrite]="--flags \"-mllvm -amdgpu-enable-rewrite-partial-reg-uses=0\""
+V[splitall]="--flags \"-mllvm -split-spill-mode=size\""
+V[earlyinline]="--flags \"-mllvm -amdgpu-early-inline-all=true\""
+fi
 for t in "${!V[@]}"; do
-  f="${V[$t]}"
-  if [ "$f" = "__NOSOLVEFLAGS__" ]; then ( python tools/build_hot.py lot_$t -DMSD_HOT_ONLY_64X2 --no-solve-flags > $O/build_$t.log 2>&1 ) &
-  elif [ -z "$f" ]; then ( python tools/build_hot.py lot_$t -DMSD_HOT_ONLY_64X2 > $O/build_$t.log 2>&1 ) &
-  else ( python tools/build_hot.py lot_$t -DMSD_HOT_ONLY_64X2 --flags "$f" > $O/build_$t.log 2>&1 ) & fi
+  ( eval python tools/build_hot.py lot_$t -DMSD_HOT_ONLY_64X2 ${V[$t]} > $O/build_$t.log 2>&1 ) &
 done
 wait
 for rep in 1 2; do
