@@ -756,20 +756,25 @@ def alt_workloads(args, device):
     hb = {}
     for B in (PER_GPU_BATCH['c1'], 8192):
         solver, scen, ov, text = build_workload('c1', B, 0, 0, 'profile', device, 'rk')
-        # warm-up like the timed loop, the previous call's results still held: the wrapper page-locks its two alternating result buffers here (hipHostMalloc of
-        # 34 MB costs more than a call; rounds 3-4 had two of them inside the ten timed calls: 10.2 ms per call of 8192 against 7.4 ms in steady state)
-        for _ in range(w + 2):
-            r = solver.problem.solve_batch(scen)
-        kk = 2*k
-        t0 = time.perf_counter()
-        for _ in range(kk):
-            r = solver.problem.solve_batch(scen)
-        dt = time.perf_counter() - t0
-        hb["batch_%d" % B] = {"solves_per_s": B*kk/dt, "ms_per_call": 1e3*dt/kk, "kernel_ms": float(r['kernel_ms']), "converged": int(np.sum(r['stats'][:, ST_STATUS] >= 0)),
-                              "bytes_to_device": int(scen.nbytes), "bytes_to_host": int(r['z'].nbytes + r['stats'].nbytes), "calls": kk}
+        for direct in (True, False):
+            solver.problem.direct_results(direct)
+            # warm-up like the timed loop, the previous call's results still held: the wrapper page-locks its two alternating result buffers here (hipHostMalloc of
+            # 34 MB costs more than a call; rounds 3-4 had two of them inside the ten timed calls: 10.2 ms per call of 8192 against 7.4 ms in steady state)
+            for _ in range(w + 2):
+                r = solver.problem.solve_batch(scen)
+            kk = 2*k
+            t0 = time.perf_counter()
+            for _ in range(kk):
+                r = solver.problem.solve_batch(scen)
+            dt = time.perf_counter() - t0
+            hb[("batch_%d" if direct else "batch_%d_copied") % B] = {
+                "solves_per_s": B*kk/dt, "ms_per_call": 1e3*dt/kk, "kernel_ms": float(r['kernel_ms']), "converged": int(np.sum(r['stats'][:, ST_STATUS] >= 0)),
+                "bytes_to_device": int(scen.nbytes), "bytes_to_host": int(r['z'].nbytes + r['stats'].nbytes), "calls": kk,
+                "results": "z* stored in the page-locked arrays by the kernels (msd_problem_direct_results)" if direct else "copied behind the launch"}
         solver.close()
     hb["workload"] = ("config 1 through msd_solve_batch: scenario records from a numpy array, results into the wrapper's page-locked arrays (two alternating buffers, allocated "
-                      "before the timed calls); wall time per call in steady state including both transfers")
+                      "before the timed calls); wall time per call in steady state including both transfers.  batch_N: the wrapper's default, the kernels store every "
+                      "scenario's z* in the host array when the scenario is done; batch_N_copied: one device-to-host copy behind the launch (the C entry point's default)")
     alt["host_buffers"] = hb
 
     # config 4: shrinking-horizon MPC, 512 scenarios per GPU (4096 over 8), 50 re-solves each: wall time of the whole loop

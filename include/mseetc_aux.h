@@ -27,6 +27,17 @@ int msd_host_alloc(unsigned long long bytes, void **ptr);
 int msd_host_free(void *ptr);
 
 /*
+ * With `on`, a host-buffer call (msd_solve_batch, _ex, _warm, _multi) whose z_out -- and lam_out, if given -- lie in page-locked memory the device can
+ * address (msd_host_alloc, hipHostMalloc, hipHostRegister) has the kernels store the results there themselves: every scenario's z* crosses the link when
+ * that scenario is done, spread over the launch, and no copy waits behind the last one (config 1 on MI355X: 0.99 x the device-resident rate instead of
+ * 0.89 x; same bits).  Arrays in pageable memory are served by copies as before.  The handle then keeps no device copy of such a solve:
+ * msd_solve_batch_shifted right after it fails with MSD_E_INVALID -- a loop of shifted re-solves leaves the switch off (mseetc/mpc.py does); a handle with
+ * msd_problem_keep_duals on is such a loop's and is served by copies whatever the switch says.  Default: off.
+ * (The reference hands back host arrays, ocp.py:359-380: this is the boundary's own cost)
+ */
+int msd_problem_direct_results(msd_handle h, int on);
+
+/*
  * Tuning switches of the kernel pickers for the problems created afterwards (process-wide; A/B measurements and one GPU test -- the library itself reads no
  * environment variable).  "no_full" != 0: the kernels without the structure of the NLP compiled in; "two_nodes_per_lane" != 0: the 64 x 2 geometry for
  * horizons of 64 ... 127 intervals of the shooting-integrator and integrateLosses families (default 128 x 1).  Unknown name: MSD_E_INVALID.

@@ -610,13 +610,24 @@ static int check_batch(msd_handle h, int nscen, const double *scen, const double
     return MSD_OK;
 }
 
-/* the copies of a batch's results into the caller's arrays, on the handle's stream */
+/* the address under which the device reaches a host array, or null: page-locked memory (msd_host_alloc, hipHostMalloc, hipHostRegister) has one */
+static double *device_address(const double *p)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }      /* (pageable memory: an error, cleared) */
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    return (double *)a.devicePointer;
+}
+
+/* the copies of a batch's results into the caller's arrays, on the handle's stream (last_direct: the kernels have written z* and the multipliers there) */
 static int enqueue_downloads(msd_handle h, int nscen, double *z_out, double *lam_out, double *stats)
 {
     HIP_TRY(hipSetDevice(h->device));
     const size_t nz = msd_problem_nz(h), nl = (size_t)msd_problem_rows_per_interval(h)*h->P.N;
-    HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));
-    if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
+    if (!h->last_direct) {
+        HIP_TRY(hipMemcpyAsync(z_out, h->d_z, sizeof(double)*nz*nscen, hipMemcpyDeviceToHost, h->stream));
+        if (lam_out) HIP_TRY(hipMemcpyAsync(lam_out, h->d_lam, sizeof(double)*nl*nscen, hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(hipMemcpyAsync(stats, h->d_stats, sizeof(double)*MSD_ST_COUNT*nscen, hipMemcpyDeviceToHost, h->stream));
     if (h->d_hist && h->h_hist && h->hist_cap > 0)
         HIP_TRY(hipMemcpyAsync(h->h_hist, h->d_hist, sizeof(double)*msd::HIST_COLS*h->hist_cap, hipMemcpyDeviceToHost, h->stream));
@@ -656,6 +667,8 @@ static int enqueue_batch(msd_handle h, int nscen, const double *scen, const doub
     if (shift >= 0) {
         /* guesses = the previous solutions of this handle, `shift` intervals down the horizon: a tail of each stored z */
         const int stp = 4 + h->P.withPn;
+        if (h->prev_nscen == 0 && h->last_direct)
+            return fail(MSD_E_INVALID, "the previous solve of this handle stored its results in host memory directly (msd_problem_direct_results): the device holds no copy a shifted warm start could begin from");
         if (h->prev_nscen != nscen || h->prev_stp != stp || h->prev_nz - stp*shift != (int)nz)
             return fail(MSD_E_INVALID, "no previous solve of this handle matches the shifted warm start (same batch, horizon longer by `shift` intervals)");
         ws.d_guess = h->d_z + (size_t)stp*shift; ws.stride = h->prev_nz; ws.d_status = h->d_stats; ws.mu = mu_init; ws.push = bound_push;
@@ -687,12 +700,21 @@ static int enqueue_batch(msd_handle h, int nscen, const double *scen, const doub
     }
     HIP_TRY(hipMemcpyAsync(h->d_scen, scen, sizeof(double)*MSD_SC_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
     if (overrides) HIP_TRY(hipMemcpyAsync(h->d_ovr, overrides, sizeof(double)*MSD_OV_COUNT*nscen, hipMemcpyHostToDevice, h->stream));
+    /* msd_problem_direct_results: result arrays the device can address are written by the kernels themselves -- every workgroup stores its z* when its
+     * scenario is done, spread over the launch, instead of one copy behind the last of them (config 1: 0.99 x the device-resident rate instead of 0.89 x,
+     * tools/zero_copy_probe.py).  The status records stay on the device (the follow-up kernel reads them) and are copied */
+    double *kz = h->d_z, *kl = lam_out ? h->d_lam : nullptr;
+    h->last_direct = false;
+    if (h->direct_results && shift < 0 && !h->keep_duals) {      /* (keep_duals: a shifted re-solve is to follow, the solutions stay with the multipliers) */
+        double *dz = device_address(z_out), *dl = lam_out ? device_address(lam_out) : nullptr;
+        if (dz && (!lam_out || dl)) { kz = dz; kl = dl; h->last_direct = true; }
+    }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, h->d_z, lam_out ? h->d_lam : nullptr, h->d_stats, d_hist, h->hist_cap, ws);
+    int rc = launch(h, nscen, h->d_scen, overrides ? h->d_ovr : nullptr, kz, kl, h->d_stats, d_hist, h->hist_cap, ws);
     if (rc != MSD_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     if (!d_hist && h->d_hist) { hipFree(h->d_hist); h->d_hist = nullptr; }      /* (enqueue_downloads copies a history only when this launch wrote one) */
-    h->prev_nscen = nscen; h->prev_nz = (int)nz; h->prev_stp = 4 + h->P.withPn;
+    h->prev_nscen = h->last_direct ? 0 : nscen; h->prev_nz = (int)nz; h->prev_stp = 4 + h->P.withPn;
     h->prev_dual_nodes = h->keep_duals ? h->P.N + 1 : 0;
     (void)nl;
     if (!defer_downloads) return enqueue_downloads(h, nscen, z_out, lam_out, stats);
@@ -715,6 +737,13 @@ int msd_solve_batch_warm(msd_handle h, int nscen, const double *scen, const doub
     rc = enqueue_batch(h, nscen, scen, overrides, z_guess, mu_init, bound_push, z_out, lam_out, stats);
     if (rc != MSD_OK) return rc;
     return finish_batch(h, kernel_ms);
+}
+
+int msd_problem_direct_results(msd_handle h, int on)
+{
+    if (!h) return fail(MSD_E_INVALID, "null handle");
+    h->direct_results = on != 0;
+    return MSD_OK;
 }
 
 int msd_problem_keep_duals(msd_handle h, int on)

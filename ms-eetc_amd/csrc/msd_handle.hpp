@@ -98,6 +98,8 @@ struct msd_problem {
     /* second result buffers: a solve that warm-starts from the previous solve of the handle reads one pair while it writes the other */
     double *d_z2 = nullptr, *d_stats2 = nullptr;
     int prev_nscen = 0, prev_nz = 0, prev_stp = 0;      /* what d_z / d_stats hold (prev_nscen = 0: nothing) */
+    /* msd_problem_direct_results: the kernels of a host-buffer call store z* (and the multipliers) in the caller's page-locked arrays themselves */
+    bool direct_results = false, last_direct = false;
     /* multipliers of the solves (msd_problem_keep_duals): written to d_dual, read from it by a shifted warm start that writes d_dual2 */
     bool keep_duals = false;
     double *d_dual = nullptr, *d_dual2 = nullptr;

@@ -100,6 +100,7 @@ def lib():
         L.msd_solve_batch_shifted.argtypes = [vp, ctypes.c_int, _dptr, _dptr, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dptr, _dptr, _dptr,
                                               ctypes.POINTER(ctypes.c_float)]
         L.msd_problem_keep_duals.argtypes = [vp, ctypes.c_int]
+        L.msd_problem_direct_results.argtypes = [vp, ctypes.c_int]
         L.msd_solve_batch_multi.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, _dptr, _dptr, _dptr, ctypes.c_double, ctypes.c_double, _dptr, _dptr,
                                             _dptr, ctypes.POINTER(ctypes.c_float)]
         L.msd_solve_batch_device.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
@@ -259,6 +260,7 @@ class DeviceProblem():
         self.rowsPerInterval = L.msd_problem_rows_per_interval(self._h)
         self.device = device
         self._results = _ResultArrays()
+        self.direct_results(True)      # (the result arrays below are page-locked: the kernels store z* there themselves)
 
     def reconfigure(self, desc):
         "Load another problem into this handle (stream and device buffers are kept): msd_problem_reconfigure."
@@ -378,6 +380,15 @@ class DeviceProblem():
 
     def solve_batch_device(self, B, d_scen, d_z, d_lam, d_stats, d_overrides=None):
         _check(lib().msd_solve_batch_device_ex(self._h, int(B), d_scen, d_overrides, d_z, d_lam, d_stats))
+
+    def direct_results(self, on=True):
+        """
+        Let the kernels store z* (and the multipliers) of solve_batch in the page-locked result arrays themselves instead of copying them behind
+        the launch (msd_problem_direct_results).  The handle then keeps no device copy: solve_batch(shift=...) right after such a solve fails.
+        """
+
+        _check(lib().msd_problem_direct_results(self._h, int(bool(on))))
+        return self
 
     def keep_duals(self, on=True):
         "Record the multipliers of every solve on the device; shifted warm starts then start from them too (msd_problem_keep_duals)."

@@ -239,6 +239,7 @@ def shrinkingHorizon(train, track, optsDict, terminalTime, numResolves, stride=2
                     twin.close()
                 if warmStart and solverFactory is None:
                     solver.problem.keep_duals(True)      # the multipliers of every solve stay on the device for the next re-solve
+                    solver.problem.direct_results(False)      # ... and so do the solutions: the shifted warm start reads them there
 
             common = dict(initialTime=t_now, terminalVelocity=terminalVelocity, initialVelocity=v_now)
 

@@ -784,6 +784,40 @@ def test_shifted_primal_dual_warm_start_vs_oracle():
     s2.close()
 
 
+def test_direct_results_are_the_copied_results():
+    """
+    msd_problem_direct_results (the Python wrapper's default): the kernels store z* and the multipliers in the page-locked result arrays themselves.
+    Same bits as the copies behind the launch, for a batch that goes through the follow-up kernel too; arrays in pageable memory are served by
+    copies; a shifted warm start cannot begin from such a solve and says so.
+    """
+    import ctypes
+    from mseetc._device import lib, DeviceError, ST, _d
+    train, track, N = cases.train_default(), cases.track_00(), 100
+    T = np.concatenate([cases.c1_times(96), [900.0, 11000.0, 15000.0]])      # an infeasible running time and two loose schedules among them
+    s = _solver(train, track, N, start='profile')
+    prob = s.problem
+    scen = s._scenarios(T, 0, 1, 1)
+    prob.solve_batch(scen)      # (the handle settles on its first-pass kernel: a launch that hands a second-order correction over switches to the instantiation that has it)
+    direct = prob.solve_batch(scen, want_multipliers=True)
+    zd, ld, sd = direct['z'].copy(), direct['lam_g'].copy(), direct['stats'].copy()
+    assert (sd[:, ST['STATUS']] >= 0).sum() >= 98
+    prob.direct_results(False)
+    copied = prob.solve_batch(scen, want_multipliers=True)
+    ok = copied['stats'][:, ST['STATUS']] >= 0
+    assert np.array_equal(zd[ok], copied['z'][ok]) and np.array_equal(ld[ok], copied['lam_g'][ok])
+    assert np.array_equal(sd[:, ST['STATUS']], copied['stats'][:, ST['STATUS']]) and np.array_equal(sd[:, ST['ITERS']], copied['stats'][:, ST['ITERS']])
+    # pageable arrays with the switch on: copies, same bits
+    prob.direct_results(True)
+    z = np.zeros_like(zd); st = np.zeros_like(sd); ms = ctypes.c_float(0)
+    assert lib().msd_solve_batch(prob._h, len(T), _d(np.ascontiguousarray(scen)), _d(z), None, _d(st), ctypes.byref(ms)) == 0
+    assert np.array_equal(z[ok], zd[ok])
+    # no device copy behind a direct solve: the shifted warm start refuses
+    prob.solve_batch(scen)
+    with pytest.raises(ValueError, match='host memory directly'):
+        prob.solve_batch(scen, shift=0)
+    s.close()
+
+
 def test_handle_reuse_across_problems():
     # msd_problem_reconfigure: one device handle carried through problems of different horizon, track and layout gives the
     # results of fresh handles (the receding-horizon loop reuses its stream and buffers this way)
