@@ -751,6 +751,28 @@ def alt_workloads(args, device):
                           "cpu_oracle_one_thread_ms = the C oracle on one host thread, same starting point.  The reference publishes 4.96 / 6.99 s for GPOPS on this problem (BASELINE.md)")
     alt["single_solve"] = single
 
+    # the streamed kernels (N >= 640: stage blocks in device memory) at the batch size of the other rows, the CPU oracle on all host cores beside them
+    # ("no CPU number stands beside the long-horizon rows")
+    from mseetc.track import computeDiscretizationPoints as _cdp2
+    streamed = {}
+    ncores = usable_cores()
+    for Ns in (700, 1000):
+        sv = _cs(wl.train_default(), wl.track_00(), dict(numIntervals=Ns, maxIterations=1000, integrationOptions=dict(numSteps=1, numApproxSteps=1)), device=device)
+        Ts = 1541*(1 + 0.15*np.random.default_rng(Ns).random(PER_GPU_BATCH['c1']))
+        sc = sv._scenarios(Ts, 0, 1, 1)
+        e, ms, st = measure(sv, sc, None, 2, 1)
+        trn = wl.train_default()
+        op = _orc.pack_problem(trn, _cdp2(wl.track_00(), Ns), dict(numIntervals=Ns, maxIterations=1000, energyOptimal=True, minimumVelocity=1, numSteps=1, numApproxSteps=1), 1,
+                               (1 - trn.etaTraction)/trn.etaTraction, 1 - trn.etaRgBrake, wl.track_00().length)
+        m = 4*ncores
+        t0 = time.perf_counter(); _, stc, nfail = _orc.solve_batch(op, sc[:m], nthreads=ncores, start='profile'); dtc = time.perf_counter() - t0
+        streamed["N%d" % Ns] = {"solves_per_s": len(Ts)/(ms*1e-3), "launch_ms": ms, "batch": len(Ts), "geometry": list(sv.problem.geometry()), "converged": int(np.sum(st[:, _ST['STATUS']] >= 0)),
+                                "ip_iterations_mean": float(np.mean(st[:, _ST['ITERS']])), "cpu_oracle_solves_per_s": m/dtc, "cpu_cores": ncores,
+                                "cpu_sample": "{} solves of the same batch, {:.1f} s, {} failed".format(m, dtc, int(nfail))}
+        sv.close()
+    streamed["workload"] = "config 1 problem (JSON-default train, full track) on 700 / 1000 intervals, 1024 running times per launch, profile start: the streamed kernels; CPU oracle (OpenMP over scenarios) beside them"
+    alt["streamed_horizons"] = streamed
+
     # the host-buffer entry point (msd_solve_batch: scenarios from and results into host memory): the PCIe-inclusive rate of the same workload,
     # wall clock over ten calls -- upload of the scenario records, launch, download of z* and the statistics.  Never the headline value.
     hb = {}

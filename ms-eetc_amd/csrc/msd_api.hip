@@ -153,7 +153,7 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol;
     P.guess = nullptr; P.guessStride = 0; P.guessStatus = nullptr; P.warmMu = 0; P.warmPush = 0; P.start = d->start_kind; P.lossMass = 0; P.queue = nullptr; P.follow = nullptr; P.list = nullptr; P.socSeen = nullptr; P.dualOut = nullptr; P.dualIn = nullptr; P.dualInStride = 0; P.dualShift = 0;
     P.ds = P.grad = P.curv = P.bmax = P.pos = nullptr;      /* (the owner of the profile buffer fills these) */
-    P.loss = nullptr;
+    P.loss = nullptr; P.lossCoef = nullptr;
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol;
     P.coll = nullptr;
     P.resto = d->no_restoration ? 0 : 1;

@@ -60,6 +60,10 @@ template <int DYN> inline Geometry pick_geometry_t(int N)
     return nodes <= 384 ? Geometry{192, 2, solve_kernel<192, 2, 1, DYN, false, false, 0, 1>} : Geometry{0, 0, nullptr};
 #endif
     if (nodes <= 64) return {64, 1, solve_kernel<64, 1, 1, DYN, false, false, 0, 1>};
+    /* the loss-table family on 65 ... 128 nodes: two waves with one node per lane and the whole register file of a SIMD each (round 6: 341 k against 289 k solves/s
+     * on the figure-5 batch at N = 100, 307 k against 219 k at N = 120 -- the jets through the table are the bulk of its iteration, like the shooting
+     * integrators' of msd_kernels_full2.hip; msd_tuning("two_nodes_per_lane", 1): the one-wave geometry) */
+    if (DYN == LOSS_TABLE && nodes > 64 && nodes <= 128 && !tuning().two_nodes_per_lane) return {128, 1, solve_kernel<128, 1, 1, DYN, false, false, 0, 1>};
     if (nodes <= 128) return {64, 2, solve_kernel<64, 2, 1, DYN, false, false, 0, 1>};     /* one wave per scenario, one wave per SIMD */
     if (nodes <= 256) return {128, 2, solve_kernel<128, 2, 1, DYN, false, false, 0, 1>};
 #ifdef MSD_MINIMAL_GEOMETRIES      /* tuning builds (tools/build_variant.py) */

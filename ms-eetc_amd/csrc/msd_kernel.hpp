@@ -78,8 +78,9 @@ struct DevProb {
     double sr0, sr1, sr2, g, rho, fmax, fmin, fminPn, pwU, pwL, accMin, accMax, ct, cr, vminSq, objDen, tol;
     const double *ds, *grad, *curv, *bmax;
     const double *loss;      /* parameter block of the dynamic loss model (lossKind == 2), see DynLoss */
+    const double *lossCoef;  /* null in the host's record.  The kernels keep the head of the block (scalars and breakpoints) in LDS where it fits: their LDS copy of this
+                              * record then has `loss` = that copy and `lossCoef` = the bicubic patches in device memory (solve_kernel) */
     const double *pos;       /* [N+1] node positions (cumulative ds), used by the profile start */
-    int start;               /* MSD_START_REFERENCE: cold start of ocp.py:325-339; MSD_START_PROFILE: profile start */
     /* primal warm start (set per launch by msd_solve_batch_warm, null = none) */
     const double *guess;
     long long guessStride;   /* doubles between the guesses of consecutive scenarios (nz, or the layout of the previous, longer horizon) */
@@ -101,6 +102,7 @@ struct DevProb {
     int resto;               /* feasibility restoration phase where the line search breaks down (IPOPT's behaviour; msd_resto.hpp) */
     int wdTrigger;           /* shortened iterations in a row that start the watchdog procedure (IPOPT: 10; <= 0: never) */
     int oneAttempt;          /* a solve that breaks down ends there: no second attempt from the other starting point (the re-solves of msd_mpc.hip) */
+    int start;               /* MSD_START_REFERENCE: cold start of ocp.py:325-339; MSD_START_PROFILE: profile start */
     /* split launches (solve_kernel's PART): the first-pass kernel appends the scenarios it does not finish to this list, the follow-up kernel drains it.
      * follow[0] entries written, [1] entries taken, [2] follow-up workgroups that found the list empty (the last one zeroes the three for the next
      * launch of the handle), [FOLLOW_HDR + 2k] scenario, [FOLLOW_HDR + 2k + 1] iterations already spent on it (>= 0: its first attempt broke down,
@@ -192,7 +194,11 @@ constexpr int COOP_REC = 9;
 __host__ __device__ __forceinline__ int coop_doubles(int NT, bool gen) { return (MSD_COOP_ADAPTIVE && gen && NT <= 128) ? (NT/64)*COOP_POOL + COOP_REC*NT : 0; }
 
 /* LDS of the streamed kernel: filter, reduction scratch, misc, uniform records */
-__host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96; }
+/* head of the loss table's parameter block (11 scalars, grid sizes, breakpoints of both axes) in LDS, between the uniform records and the node constants, in the
+ * kernels of the loss-table families: the cell search of table_eval reads the breakpoints -- a chain of dependent loads from device memory before round 6, the
+ * bulk of an evaluation (EVAL + MERIT 76 k of 175 k cycles per iteration of the figure-5 batch, profiles/r06).  A table with more breakpoints stays where it is */
+constexpr int LOSS_HEAD_CAP = 128;
+__host__ __device__ __forceinline__ int lds_doubles_stream() { return 2*64 + 4*16*8 + 32 + 96 + LOSS_HEAD_CAP; }
 
 /* exchange arrays over the node slots: neighbour t, b, Fel and three outgoing contributions; the fused iteration of the kernels with the
  * problem structure compiled in (Solver::FAST) publishes sqrt(b) too and sends seven contributions in one pass */
@@ -215,7 +221,7 @@ constexpr int STATIC_FIELDS = 5;
  * re-solves of msd_mpc.hip (WarmStart::use_soc) */
 __host__ __device__ __forceinline__ int lds_doubles(int N, int NS, bool dyn, int nxch = XCH_GENERAL, int red = RED_DOUBLES)
 {
-    return stage_stride(dyn)*(N + 1) + nxch*NS + 2*FILT_CAP + red + 32 + CONST_DOUBLES;
+    return stage_stride(dyn)*(N + 1) + nxch*NS + 2*FILT_CAP + red + 32 + CONST_DOUBLES + (dyn ? LOSS_HEAD_CAP : 0);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -349,20 +355,30 @@ struct DynLoss {
     double Fmax, Pmax, vTurn, vMin, vMax, aux, cgT, cgB, R, V, M;
     int nx, ny;
     const double *xb, *yb, *coef;
-    __device__ __forceinline__ DynLoss(const double *b, const double massOverride)
+    /* b: the parameter block, or its head alone (LDS copy) with the patches at `patches` (DevProb::loss / lossCoef) */
+    __device__ __forceinline__ DynLoss(const double *b, const double *patches, const double massOverride)
         : Fmax(b[0]), Pmax(b[1]), vTurn(b[2]), vMin(b[3]), vMax(b[4]), aux(b[5]), cgT(b[6]), cgB(b[7]), R(b[8]), V(b[9]), M(massOverride > 0 ? massOverride : b[10]),
-          nx((int)b[11]), ny((int)b[12]), xb(b + 13), yb(b + 13 + (int)b[11] + 1), coef(b + 13 + (int)b[11] + 1 + (int)b[12] + 1) {}
+          nx((int)b[11]), ny((int)b[12]), xb(b + 13), yb(b + 13 + (int)b[11] + 1), coef(patches ? patches : b + 13 + (int)b[11] + 1 + (int)b[12] + 1) {}
 };
 
-/* value and derivatives up to second order of the table at (x, y): t = {p, px, py, pxx, pxy, pyy}; zero outside the x range */
-__device__ __forceinline__ void table_eval(const DynLoss &D, double x, double y, double (&t)[6])
+/* index of the cell of an axis that holds x: the last interior breakpoint at or below x (0 below the first one and for a NaN) -- what a linear search over the
+ * ascending breakpoints finds, by bisection (round 6: the breakpoints in LDS, LOSS_HEAD_CAP) */
+__device__ __forceinline__ int table_cell(const double *bp, int n, double x)
+{
+    if (n < 2 || !(x >= bp[1])) return 0;      /* (the first cell: the evaluations at f = 0 and at the linear extension's +-tol) */
+    int lo = 1, hi = n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x >= bp[mid]) lo = mid; else hi = mid; }
+    return lo;
+}
+
+/* value and derivatives up to second order of the table at (x, y): t = {p, px, py, pxx, pxy, pyy}; zero outside the x range.  iy >= 0: the cell of y, already known
+ * (the three evaluations of loss_rows share their speed) */
+__device__ __forceinline__ void table_eval(const DynLoss &D, double x, double y, double (&t)[6], const int iy_known = -1)
 {
 #pragma unroll
     for (int k = 0; k < 6; k++) t[k] = 0;
     if (x < D.xb[0] || x > D.xb[D.nx]) return;
-    int ix = 0, iy = 0;
-    while (ix + 1 < D.nx && x >= D.xb[ix + 1]) ix++;
-    while (iy + 1 < D.ny && y >= D.yb[iy + 1]) iy++;
+    const int ix = table_cell(D.xb, D.nx, x), iy = iy_known >= 0 ? iy_known : table_cell(D.yb, D.ny, y);
     const double dx = x - 0.5*(D.xb[ix] + D.xb[ix + 1]), dy = y - 0.5*(D.yb[iy] + D.yb[iy + 1]);
     const double *c = D.coef + 16*(ix*D.ny + iy);
     const double X[4] = {1, dx, dx*dx, dx*dx*dx}, X1[4] = {0, 1, 2*dx, 3*dx*dx}, X2[4] = {0, 0, 2, 6*dx};
@@ -377,9 +393,12 @@ __device__ __forceinline__ void table_eval(const DynLoss &D, double x, double y,
         }
     }
 }
+/* the speed the table is read at (efficiency.py:40: constant continuation outside its range) and its cell */
+__device__ __forceinline__ double table_speed(const DynLoss &D, double v) { return (v >= D.vMin && v <= D.vMax) ? v : (v < D.vMin ? D.vMin : D.vMax); }
+__device__ __forceinline__ int table_speed_cell(const DynLoss &D, double v) { return table_cell(D.yb, D.ny, table_speed(D, v)); }
 
 /* specific total losses [W/kg] of the traction (f >= 0) or braking (f < 0) branch as a jet in (f, v) */
-__device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, double f, double v)
+__device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, double f, double v, const int iy = -1)      /* iy: table_speed_cell(D, v), or -1 */
 {
     const Jet F = Jet{f, 1, 0, 0, 0, 0}*D.M, vv = Jet{v, 0, 1, 0, 0, 0};
     const bool inside = (v >= D.vMin && v <= D.vMax);
@@ -390,7 +409,7 @@ __device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, doub
     const Jet absF = (traction || direct) ? F : F*(-1.0);
     const Jet load = direct ? absF : (vc.v <= D.vTurn) ? absF*(100/D.Fmax) : (absF*vc)*(100/D.Pmax);     /* efficiency.py:7-12 */
     double t[6];
-    table_eval(D, load.v, vc.v, t);
+    table_eval(D, load.v, vc.v, t, iy);
     if (!direct && !(t[0] > 0)) return Jet{0, 0, 0, 0, 0, 0};                                             /* efficiency.py:137 */
     Jet motor;
     motor.v = t[0];
@@ -417,27 +436,28 @@ __device__ __forceinline__ Jet spec_losses(const DynLoss &D, bool traction, doub
  */
 /* the split loss power itself (utils.py:197-220; specific, W/kg): l = {L, L_f, L_v, L_ff, L_fv, L_vv} of the traction part (row 0) or the regenerative-brake
  * part (row 1) at (f, v); beta = spec_losses(D, true, 0, v) */
-__device__ __forceinline__ void loss_split(const DynLoss &D, const int row, double f, double v, const Jet &beta, double (&l)[6])
+__device__ __forceinline__ void loss_split(const DynLoss &D, const int row, double f, double v, const Jet &beta, double (&l)[6], const int iy = -1)
 {
     const double tol = 1e-10;
     const bool traction = (row == 0);
     const bool truth = traction ? (f >= 0) : (f < 0);
     if (truth) {
-        const Jet s = spec_losses(D, traction, f, v);
+        const Jet s = spec_losses(D, traction, f, v, iy);
         l[0] = s.v; l[1] = s.g0; l[2] = s.g1; l[3] = s.h00; l[4] = s.h01; l[5] = s.h11;
     } else {
-        const Jet a = spec_losses(D, traction, traction ? tol : -tol, v);
+        const Jet a = spec_losses(D, traction, traction ? tol : -tol, v, iy);
         l[0] = a.g0*f + beta.v; l[1] = a.g0; l[2] = a.h01*f + beta.g1; l[3] = 0; l[4] = a.h01; l[5] = beta.h11;
     }
 }
 
 __device__ __forceinline__ void loss_rows(const DynLoss &D, double f, double v, double (&lr)[2][6])
 {
-    const Jet beta = spec_losses(D, true, 0.0, v);
+    const int iy = table_speed_cell(D, v);
+    const Jet beta = spec_losses(D, true, 0.0, v, iy);
 #pragma unroll
     for (int row = 0; row < 2; row++) {
         double l[6];
-        loss_split(D, row, f, v, beta, l);
+        loss_split(D, row, f, v, beta, l, iy);
         const double L = l[0], Lf = l[1], Lv = l[2], Lff = l[3], Lfv = l[4], Lvv = l[5];
         const double iv = 1/v;
         lr[row][0] = L*iv;
@@ -778,7 +798,7 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
     dv[RACC] = U.rs[RACC]*(f + p - (P.sr0 + P.sr1*sb + P.sr2*b) - nG);     /* ocp.py:199 */
     if (DYN == LOSS_INTEGRATED_TABLE) {
         /* ocp.py:233-240 with a loss table: s - E_tr, s - E_rgb, E_k = int L_k(f, v(t)) dt over t1 - t (msd_lossint_table.hpp) */
-        const DynLoss D(P.loss, P.lossMass);
+        const DynLoss D(P.loss, P.lossCoef, P.lossMass);
         if (DERIV) {
             Jet4 E[2];
             loss_energy<Jet4>(P, D, sb, t1 - x[VT], f + p, f, nG, E);
@@ -812,7 +832,7 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
             dv[RLRG] = U.rs[RLRG]*(s + P.cr*f*X);
         }
     } else if (DYN == LOSS_TABLE) {
-        const DynLoss D(P.loss, P.lossMass);
+        const DynLoss D(P.loss, P.lossCoef, P.lossMass);
         double lr[2][6];
         loss_rows(D, f, 0.5*(sb + sb1), lr);                                 /* ocp.py:221: mid-point speed of the interval */
         dv[RLTR] = U.rs[RLTR]*(s - lr[0][0]);
@@ -2854,7 +2874,7 @@ struct Solver {
                 if (hasPower()) { const double vmx = fmax(v0, v1); fel = fmin(fmax(fel, -fabs(P.pwL)/vmx), fabs(P.pwU)/vmx); }
             }
             double sl;
-            if (DYN == LOSS_TABLE || ITAB) { const DynLoss D(P.loss, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0])*(ITAB ? nd.ds : 1.0) + S0; }
+            if (DYN == LOSS_TABLE || ITAB) { const DynLoss D(P.loss, P.lossCoef, P.lossMass); double lr[2][6]; loss_rows(D, fel, 0.5*(v0 + v1), lr); sl = fmax(lr[0][0], lr[1][0])*(ITAB ? nd.ds : 1.0) + S0; }
             else sl = fmax(P.ct*fel, -P.cr*fel)*(INTEG ? nd.ds : 1.0) + S0;      /* integrated losses: the slack is an energy per interval */
             nd.x[VF] = fel; nd.x[VP] = fpb; nd.x[VS] = sl;
         }
@@ -4303,8 +4323,18 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
     c.red = c.filt + 2*FILT_CAP; c.misc = c.red + ((FASTK && NT == 64) ? 0 : RED_DOUBLES);      /* (a single wave reduces in registers) */
     /* the problem record and the scenario's uniform data live in LDS: phases read what they need (broadcast reads) instead of
      * carrying some eighty uniform values through the whole solve in registers */
-    c.st = c.misc + 32 + CONST_DOUBLES;
+    double *loss_lds = c.misc + 32 + CONST_DOUBLES;
+    c.st = loss_lds + (DYN != LOSS_STATIC ? LOSS_HEAD_CAP : 0);      /* (lds_doubles: every family with the wide stage blocks has the room) */
     c.pool = c.st;      /* (kernels of the shooting-integrator families have no node constants there) */
+    const double *loss_head = P.loss, *loss_coef = nullptr;
+    if ((DYN == LOSS_TABLE || DYN == LOSS_INTEGRATED_TABLE) && P.loss) {
+        const int len = 13 + ((int)P.loss[11] + 1) + ((int)P.loss[12] + 1);
+        loss_coef = P.loss + len;
+        if (len <= LOSS_HEAD_CAP) {
+            for (int k = threadIdx.x; k < len; k += NT) loss_lds[k] = P.loss[k];      /* (visible behind the barrier in front of the first scenario's record) */
+            loss_head = loss_lds;
+        }
+    }
     DevProb *Pl = reinterpret_cast<DevProb *>(c.misc + 32);
     Uni *Ul = reinterpret_cast<Uni *>(c.misc + 32 + UNI_OFF);
     static_assert(sizeof(DevProb) <= 8*UNI_OFF && sizeof(Uni) <= 8*(CONST_DOUBLES - UNI_OFF), "LDS room for the uniform records");
@@ -4336,6 +4366,7 @@ __global__ void __launch_bounds__(NT, WPS) solve_kernel(DevProb P, int nscen, co
         if (sidx >= nscen) break;
         /* per-scenario rolling stock (uniform over the workgroup) */
         DevProb Ps = P;
+        Ps.loss = loss_head; Ps.lossCoef = loss_coef;
         if (overrides) {
             const double *o = overrides + (size_t)MSD_OV_COUNT*sidx;
             Ps.sr0 = o[MSD_OV_SR0]; Ps.sr1 = o[MSD_OV_SR1]; Ps.sr2 = o[MSD_OV_SR2];

@@ -96,11 +96,12 @@ __device__ inline void loss_energy(const DevProb &P, const DynLoss &D, double v0
         const T acc = ((vj*(-P.sr1) + (vj*vj)*(-P.sr2)) + w) + (-P.sr0 - G);
         o[0] = dt*acc;
         const double vv = j4val(vj);
-        const Jet beta = spec_losses(D, true, 0.0, vv);
+        const int iy = table_speed_cell(D, vv);
+        const Jet beta = spec_losses(D, true, 0.0, vv, iy);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             double l[6];
-            loss_split(D, r, f0, vv, beta, l);
+            loss_split(D, r, f0, vv, beta, l, iy);
             o[1 + r] = dt*j4loss(l, vj);
         }
     };

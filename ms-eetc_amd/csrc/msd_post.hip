@@ -44,7 +44,7 @@ __device__ __forceinline__ void rhs(const PostTrain &T, const PostLoss &Ls, doub
         double ltr = 0, lrg = 0;
         if (Ls.kind == 1) { ltr = Ls.ct*f*v; lrg = -Ls.cr*f*v; }             /* train.py:203 through utils.py:197-220: linear in f */
         else if (Ls.kind == 2) {
-            const msd::DynLoss D(Ls.table, 0.0);
+            const msd::DynLoss D(Ls.table, nullptr, 0.0);
             double lr[2][6];
             msd::loss_rows(D, f, fmax(v, 1e-9), lr);                          /* rows are L/v */
             ltr = lr[0][0]*v; lrg = lr[1][0]*v;

@@ -37,7 +37,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     P.numSteps = d->num_steps; P.numApprox = d->num_approx_steps; P.lossKind = d->loss_kind; P.maxIter = d->max_iterations;
     P.sr0 = d->sr0; P.sr1 = d->sr1; P.sr2 = d->sr2; P.g = d->g; P.rho = d->rho; P.fmax = d->f_max; P.fmin = d->f_min; P.fminPn = d->f_min_pn;
     P.pwU = d->pw_upper; P.pwL = d->pw_lower; P.accMin = d->acc_min; P.accMax = d->acc_max; P.ct = d->loss_ct; P.cr = d->loss_cr;
-    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax; P.loss = d->loss_table;
+    P.vminSq = d->vmin_sq; P.objDen = d->obj_den; P.tol = d->tol; P.ds = d->ds; P.grad = d->grad; P.curv = d->curv; P.bmax = d->bmax; P.loss = d->loss_table; P.lossCoef = nullptr;
     P.integ = d->integrator; P.collD = d->coll_degree; P.newtonIters = d->newton_iterations; P.intAtol = d->int_abstol; P.intRtol = d->int_reltol; P.coll = d->coll_tables;
     P.resto = d->no_restoration ? 0 : 1;
     P.wdTrigger = d->watchdog_trigger == 0 ? 10 : d->watchdog_trigger;
@@ -63,7 +63,7 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     }
     if (force) sscanf(force, "%dx%d", &NT, &SPT);
     else if (nodes <= 64) { NT = 64; SPT = 1; }
-    else if (nodes <= 128) { NT = 64; SPT = 2; }
+    else if (nodes <= 128) { NT = dyn ? 128 : 64; SPT = dyn ? 1 : 2; }      /* (pick_geometry_t: the loss-table family takes one node per lane here) */
     else if (nodes <= 256) { NT = 128; SPT = 2; }
     else if (nodes <= 384) { NT = 192; SPT = 2; }
     else if (nodes <= 512) { NT = 256; SPT = 2; }

@@ -21,6 +21,7 @@ for name, extra, io in (("static", dict(), dict(numSteps=1, numApproxSteps=1)),
                         ("cvodes_tolerances", dict(integrationMethod='CVODES'), dict())):
     solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, integrationOptions=io, **extra), startingPoint='profile')
     scen = solver._scenarios(T, 0, 1, 1)
+    solver.problem.direct_results(False)      # (kernel time)
     solver.problem.solve_batch(scen)
     ms = []
     for _ in range(5):

@@ -11,6 +11,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 solver = casadiSolver(cases.train_default(), cases.track_00(), dict(numIntervals=N, maxIterations=500, integrationOptions=dict(numSteps=1, numApproxSteps=1)))
 scen = solver._scenarios(cases.c1_times(B), 0, 1, 1)
+solver.problem.direct_results(False)      # (kernel time: results copied behind the launch, not stored across the link by the kernels)
 ms = []
 for k in range(25):
     out = solver.problem.solve_batch(scen)

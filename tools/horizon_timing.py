@@ -11,14 +11,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 for variant in ('both', 'fig10'):
     train = cases.train_default() if variant == 'both' else cases.train_fig10()
     track = cases.track_00()
-    for N in (100, 200, 300, 383, 450, 511, 560, 700, 1000, 2000):
-        b = B if N <= 560 else max(1, B//16)
+    for N, b in ((100, B), (200, B), (300, B), (383, B), (450, B), (511, B), (560, B), (600, B), (639, B), (700, max(1, B//16)), (700, B), (1000, max(1, B//16)), (1000, B), (2000, max(1, B//16))):
         solver = casadiSolver(train, track, dict(numIntervals=N, maxIterations=1000, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+        solver.problem.direct_results(False)      # (kernel time)
         T = 1541*(1 + 0.15*np.random.default_rng(N).random(b))
         scen = solver._scenarios(T, 0, 1, 1)
         solver.problem.solve_batch(scen)
         ms = [solver.problem.solve_batch(scen)['kernel_ms'] for _ in range(3)]
         out = solver.problem.solve_batch(scen)
         st = out['stats']
-        print('%-6s N %4d geometry %-10s batch %5d  kernel %9.3f ms  %9.0f solves/s  iters %.1f  converged %d' % (variant, N, solver.problem.geometry(), b, np.mean(ms), b/np.mean(ms)*1e3, st[:, 1].mean(), (st[:, 0] >= 0).sum()))
+        print('%-6s N %4d geometry %-10s batch %5d  kernel %9.3f ms  %9.0f solves/s  iters %.1f  converged %d' % (variant, N, solver.problem.geometry(), b, np.mean(ms), b/np.mean(ms)*1e3, st[:, 1].mean(), (st[:, 0] >= 0).sum()), flush=True)
         solver.close()
