@@ -1075,27 +1075,19 @@ __device__ __noinline__ bool riccati_solve(const int N, const bool pn, double *S
  * the limit D_b -> 0.  Leaves (dt, db, df, dp, ds) and the new multipliers (lt, lb) of every interval in its block.
  * X: the integrated loss rows' share in the running time (fields W_RX of the work area, stride NS).
  * ---------------------------------------------------------------------------------------- */
-template <int DYN>
-__device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S, const double *Dtv, const double *Dbv, const double *X, const int NS)
+/* state of the backward sweep: value function and its gradient at the stage behind the one at work */
+struct RestoSweep { double P[3][3], pv[3]; bool ok, swapLast; };
+
+/* one stage of the backward sweep (w: stage i+1 in, stage i out); feedback, value function and gradient of stage i+1 into the stage's block */
+template <int DYN, bool last>
+__device__ __forceinline__ void resto_backward_stage(const int i, const bool pn, double *S, const double *Dtv, const double *Dbv, const double *X, const int NS, RestoSweep &w)
 {
     constexpr int S_STRIDE = stage_stride(DYN);
-    /* Round 3 kept every array of the sweeps in the work area (run-time indices): the stack of this cold function sized the scratch memory of
-     * every launch of the kernel it was compiled into.  Since round 4 it only lives in follow-up kernels (solve_kernel: PART = 2), so the
-     * arrays are locals with compile-time indices -- registers -- and the last interval is peeled off the stage loop */
-    double P[3][3], pv[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        pv[a] = 0;
-#pragma unroll
-        for (int b = 0; b < 3; b++) P[a][b] = 0;
-    }
-    P[0][0] = S[N*S_STRIDE + S_HTT]; pv[0] = S[N*S_STRIDE + S_HT];
-    bool ok = true, swapLast = false;
     /* cross terms of stage i: E[a][m], a over (t b q f p s), m over (t+, b+) */
-    auto cross = [&](const int i, const bool last, const double *s, double (&E)[6][2], double (&H)[6][6]) {
+    auto cross = [&](const int i, const bool last_, const double *s, double (&E)[6][2], double (&H)[6][6]) {
 #pragma unroll
         for (int a = 0; a < 6; a++) E[a][0] = E[a][1] = 0;
-        if (DYN == LOSS_TABLE && !last) { E[1][1] = s[S_EB]; E[5][1] = s[S_ES]; }
+        if (DYN == LOSS_TABLE && !last_) { E[1][1] = s[S_EB]; E[5][1] = s[S_ES]; }
         if (loss_integrated(DYN)) {
             const double Wdd = X[0*NS + i], Wbd = X[1*NS + i], Wfd = X[2*NS + i], Wpd = X[3*NS + i], Wsd = X[4*NS + i];
             /* d = t+ - t: entries at t are minus, at t+ plus the running time's (H_tt already carries W_dd, the next node's too: assemble) */
@@ -1103,232 +1095,253 @@ __device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S
             E[0][0] = -Wdd; E[1][0] = Wbd; E[3][0] = Wfd; E[4][0] = Wpd; E[5][0] = Wsd;
         }
     };
-    auto backward = [&](const int i, auto last_tag) {
-        constexpr bool last = decltype(last_tag)::value;
-        constexpr int nu = 3;      /* controls to eliminate: (f, p, s), in the last interval (v, k, s) with k the force that is kept */
-        double *s = S + i*S_STRIDE;
-        const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
-        const double Dt = Dtv[i], Db = Dbv[i];
-        double H[6][6], G[6][6], h[6], g[6], PF[3][6], Pr[3], F[3][6], r[3], L[3][3], K[3][4], E[6][2], Q[2][6];
+    constexpr int nu = 3;      /* controls to eliminate: (f, p, s), in the last interval (v, k, s) with k the force that is kept */
+    double *s = S + i*S_STRIDE;
+    const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+    const double Dt = Dtv[i], Db = Dbv[i];
+    double H[6][6], G[6][6], h[6], g[6], PF[3][6], Pr[3], F[3][6], r[3], L[3][3], K[3][4], E[6][2], Q[2][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        h[a] = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) H[a][b] = 0;
+    }
+    H[0][0] = s[S_HTT]; H[1][1] = s[S_HBB]; H[1][2] = H[2][1] = s[S_HBQ]; H[1][3] = H[3][1] = s[S_HBF]; H[1][4] = H[4][1] = s[S_HBP];
+    H[2][2] = s[S_HQQ]; H[2][3] = H[3][2] = s[S_HQF]; H[3][3] = s[S_HFF]; H[3][4] = H[4][3] = s[S_HFP]; H[4][4] = s[S_HPP];
+    h[0] = s[S_HT]; h[1] = s[S_HB]; h[2] = s[S_HQ]; h[3] = s[S_HF]; h[4] = s[S_HP];
+    H[3][5] = H[5][3] = s[S_GFS]; H[5][5] = 1.0/s[S_IS]; h[5] = s[S_GS];      /* the slack variable's row, unreduced (1/NaN when its pivot is not positive: the Cholesky below fails) */
+    if (DYN) { H[1][5] = H[5][1] = s[S_GBS]; H[4][5] = H[5][4] = s[S_GPS]; }
+    cross(i, last, s, E, H);
+    /* value function of stage i+1 as it is, for the forward sweep */
+    s[S_PN + 0] = w.P[0][0]; s[S_PN + 1] = w.P[0][1]; s[S_PN + 2] = w.P[0][2]; s[S_PN + 3] = w.P[1][1]; s[S_PN + 4] = w.P[1][2]; s[S_PN + 5] = w.P[2][2];
+    s[S_PV + 0] = w.pv[0]; s[S_PV + 1] = w.pv[1]; s[S_PV + 2] = w.pv[2];
+    /* through the relaxed rows */
+    double M00, M01, M11;
+    if (last) {
+        const double den = 1 + w.P[0][0]*Dt;
+        if (!(den > 0)) w.ok = false;
+        M00 = Dt/den; M01 = 0; M11 = 0;
+    } else {
+        const double st = sqrt(Dt), sb = sqrt(Db);
+        const double ma = 1 + st*w.P[0][0]*st, mb = st*w.P[0][1]*sb, mc = 1 + sb*w.P[1][1]*sb, det = ma*mc - mb*mb;
+        if (!(det > 0) || !(ma > 0)) w.ok = false;
+        M00 = st*(mc/det)*st; M01 = -st*(mb/det)*sb; M11 = sb*(ma/det)*sb;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) F[a][b] = 0;
+    F[0][0] = 1; F[0][1] = Tb; F[0][3] = Tw; F[0][4] = pn ? Tw : 0.0; F[1][1] = Bb; F[1][3] = Bw; F[1][4] = pn ? Bw : 0.0; F[2][3] = 1;
+    r[0] = rt; r[1] = last ? 0.0 : rb; r[2] = 0;
+    if (last) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) F[1][b] = 0;      /* db_N = 0: the b row is the equality handled below, not a transition */
+    }
+    /* G = H + F^T P F + E F2 + (E F2)^T, g = h + F^T (P r + p) + E r2 */
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) PF[a][b] = w.P[a][0]*F[0][b] + w.P[a][1]*F[1][b] + w.P[a][2]*F[2][b];
+        Pr[a] = w.pv[a] + w.P[a][0]*r[0] + w.P[a][1]*r[1] + w.P[a][2]*r[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b = 0; b < 6; b++)
+            G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b]
+                      + (DYN ? E[a][0]*F[0][b] + E[a][1]*F[1][b] + F[0][a]*E[b][0] + F[1][a]*E[b][1] : 0.0);
+        g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2] + (DYN ? E[a][0]*r[0] + E[a][1]*r[1] : 0.0);
+    }
+    /* - Q^T M Q on the relaxed rows */
+#pragma unroll
+    for (int b = 0; b < 6; b++) { Q[0][b] = PF[0][b] + (DYN ? E[b][0] : 0.0); Q[1][b] = PF[1][b] + (DYN ? E[b][1] : 0.0); }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double q0 = M00*Q[0][a] + M01*Q[1][a], q1 = M01*Q[0][a] + M11*Q[1][a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) G[a][b] -= q0*Q[0][b] + q1*Q[1][b];
+        g[a] -= q0*Pr[0] + q1*Pr[1];
+    }
+    if (!pn) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0;
+        G[4][4] = 1; g[4] = 0;
+    }
+    if (last) {
+        /* d(e) = eb db - d(k) + e0 - kap v: the force with the smaller curvature is eliminated (last_interval); when that is Fpb the two forces
+         * swap their slots here, and back in the forward sweep (every index a compile-time constant) */
+        w.swapLast = pn && G[4][4] < G[3][3];
+        if (w.swapLast) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) { const double v = G[3][a]; G[3][a] = G[4][a]; G[4][a] = v; }
+#pragma unroll
+            for (int a = 0; a < 6; a++) { const double v = G[a][3]; G[a][3] = G[a][4]; G[a][4] = v; }
+            const double v = g[3]; g[3] = g[4]; g[4] = v;
+        }
+        const double eb = -Bb/Bw, e0 = -rb/Bw, kap = sqrt(Db)/Bw;
+        double T[6][6], GT[6][6], G2[6][6], gy[6], g2[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) T[a][b] = a == b ? 1.0 : 0.0;
+        T[3][3] = -kap; T[3][1] = eb; T[3][4] = pn ? -1.0 : 0.0;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            h[a] = 0;
 #pragma unroll
-            for (int b = 0; b < 6; b++) H[a][b] = 0;
-        }
-        H[0][0] = s[S_HTT]; H[1][1] = s[S_HBB]; H[1][2] = H[2][1] = s[S_HBQ]; H[1][3] = H[3][1] = s[S_HBF]; H[1][4] = H[4][1] = s[S_HBP];
-        H[2][2] = s[S_HQQ]; H[2][3] = H[3][2] = s[S_HQF]; H[3][3] = s[S_HFF]; H[3][4] = H[4][3] = s[S_HFP]; H[4][4] = s[S_HPP];
-        h[0] = s[S_HT]; h[1] = s[S_HB]; h[2] = s[S_HQ]; h[3] = s[S_HF]; h[4] = s[S_HP];
-        H[3][5] = H[5][3] = s[S_GFS]; H[5][5] = 1.0/s[S_IS]; h[5] = s[S_GS];      /* the slack variable's row, unreduced (1/NaN when its pivot is not positive: the Cholesky below fails) */
-        if (DYN) { H[1][5] = H[5][1] = s[S_GBS]; H[4][5] = H[5][4] = s[S_GPS]; }
-        cross(i, last, s, E, H);
-        /* value function of stage i+1 as it is, for the forward sweep */
-        s[S_PN + 0] = P[0][0]; s[S_PN + 1] = P[0][1]; s[S_PN + 2] = P[0][2]; s[S_PN + 3] = P[1][1]; s[S_PN + 4] = P[1][2]; s[S_PN + 5] = P[2][2];
-        s[S_PV + 0] = pv[0]; s[S_PV + 1] = pv[1]; s[S_PV + 2] = pv[2];
-        /* through the relaxed rows */
-        double M00, M01, M11;
-        if (last) {
-            const double den = 1 + P[0][0]*Dt;
-            if (!(den > 0)) ok = false;
-            M00 = Dt/den; M01 = 0; M11 = 0;
-        } else {
-            const double st = sqrt(Dt), sb = sqrt(Db);
-            const double ma = 1 + st*P[0][0]*st, mb = st*P[0][1]*sb, mc = 1 + sb*P[1][1]*sb, det = ma*mc - mb*mb;
-            if (!(det > 0) || !(ma > 0)) ok = false;
-            M00 = st*(mc/det)*st; M01 = -st*(mb/det)*sb; M11 = sb*(ma/det)*sb;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 6; b++) F[a][b] = 0;
-        F[0][0] = 1; F[0][1] = Tb; F[0][3] = Tw; F[0][4] = pn ? Tw : 0.0; F[1][1] = Bb; F[1][3] = Bw; F[1][4] = pn ? Bw : 0.0; F[2][3] = 1;
-        r[0] = rt; r[1] = last ? 0.0 : rb; r[2] = 0;
-        if (last) {
-#pragma unroll
-            for (int b = 0; b < 6; b++) F[1][b] = 0;      /* db_N = 0: the b row is the equality handled below, not a transition */
-        }
-        /* G = H + F^T P F + E F2 + (E F2)^T, g = h + F^T (P r + p) + E r2 */
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-#pragma unroll
-            for (int b = 0; b < 6; b++) PF[a][b] = P[a][0]*F[0][b] + P[a][1]*F[1][b] + P[a][2]*F[2][b];
-            Pr[a] = pv[a] + P[a][0]*r[0] + P[a][1]*r[1] + P[a][2]*r[2];
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-                G[a][b] = H[a][b] + F[0][a]*PF[0][b] + F[1][a]*PF[1][b] + F[2][a]*PF[2][b]
-                          + (DYN ? E[a][0]*F[0][b] + E[a][1]*F[1][b] + F[0][a]*E[b][0] + F[1][a]*E[b][1] : 0.0);
-            g[a] = h[a] + F[0][a]*Pr[0] + F[1][a]*Pr[1] + F[2][a]*Pr[2] + (DYN ? E[a][0]*r[0] + E[a][1]*r[1] : 0.0);
-        }
-        /* - Q^T M Q on the relaxed rows */
-#pragma unroll
-        for (int b = 0; b < 6; b++) { Q[0][b] = PF[0][b] + (DYN ? E[b][0] : 0.0); Q[1][b] = PF[1][b] + (DYN ? E[b][1] : 0.0); }
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-            const double q0 = M00*Q[0][a] + M01*Q[1][a], q1 = M01*Q[0][a] + M11*Q[1][a];
-#pragma unroll
-            for (int b = 0; b < 6; b++) G[a][b] -= q0*Q[0][b] + q1*Q[1][b];
-            g[a] -= q0*Pr[0] + q1*Pr[1];
-        }
-        if (!pn) {
-#pragma unroll
-            for (int a = 0; a < 6; a++) G[4][a] = G[a][4] = 0;
-            G[4][4] = 1; g[4] = 0;
-        }
-        if (last) {
-            /* d(e) = eb db - d(k) + e0 - kap v: the force with the smaller curvature is eliminated (last_interval); when that is Fpb the two forces
-             * swap their slots here, and back in the forward sweep (every index a compile-time constant) */
-            swapLast = pn && G[4][4] < G[3][3];
-            if (swapLast) {
-#pragma unroll
-                for (int a = 0; a < 6; a++) { const double v = G[3][a]; G[3][a] = G[4][a]; G[4][a] = v; }
-#pragma unroll
-                for (int a = 0; a < 6; a++) { const double v = G[a][3]; G[a][3] = G[a][4]; G[a][4] = v; }
-                const double v = g[3]; g[3] = g[4]; g[4] = v;
-            }
-            const double eb = -Bb/Bw, e0 = -rb/Bw, kap = sqrt(Db)/Bw;
-            double T[6][6], GT[6][6], G2[6][6], gy[6], g2[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b < 6; b++) T[a][b] = a == b ? 1.0 : 0.0;
-            T[3][3] = -kap; T[3][1] = eb; T[3][4] = pn ? -1.0 : 0.0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-#pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    double v = 0;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) v += G[a][m]*T[m][b];
-                    GT[a][b] = v;
-                }
-                gy[a] = g[a] + G[a][3]*e0;
-            }
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-#pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    double v = 0;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) v += T[m][a]*GT[m][b];
-                    G2[a][b] = v;
-                }
+            for (int b = 0; b < 6; b++) {
                 double v = 0;
 #pragma unroll
-                for (int m = 0; m < 6; m++) v += T[m][a]*gy[m];
-                g2[a] = v;
+                for (int m = 0; m < 6; m++) v += G[a][m]*T[m][b];
+                GT[a][b] = v;
             }
-            G2[3][3] += 1.0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-#pragma unroll
-                for (int b = 0; b < 6; b++) G[a][b] = G2[a][b];
-                g[a] = g2[a];
-            }
-        }
-        /* eliminate the controls: Cholesky of the control block */
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) L[a][b] = 0;
-#pragma unroll
-        for (int j = 0; j < nu; j++) {
-            double d = G[3 + j][3 + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) d -= L[j][k]*L[j][k];
-            if (!(d > 0) || !isfinite(d)) { ok = false; d = 1.0; }
-            L[j][j] = sqrt(d);
-#pragma unroll
-            for (int a = j + 1; a < nu; a++) {
-                double v = G[3 + a][3 + j];
-#pragma unroll
-                for (int k = 0; k < j; k++) v -= L[a][k]*L[j][k];
-                L[a][j] = v/L[j][j];
-            }
+            gy[a] = g[a] + G[a][3]*e0;
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {      /* K: columns t, b, q and the constant */
-            double y[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+        for (int a = 0; a < 6; a++) {
 #pragma unroll
-            for (int a = 0; a < nu; a++) {
-                double v = -(c < 3 ? G[3 + a][c] : g[3 + a]);
+            for (int b = 0; b < 6; b++) {
+                double v = 0;
 #pragma unroll
-                for (int k = 0; k < a; k++) v -= L[a][k]*y[k];
-                y[a] = v/L[a][a];
+                for (int m = 0; m < 6; m++) v += T[m][a]*GT[m][b];
+                G2[a][b] = v;
             }
+            double v = 0;
 #pragma unroll
-            for (int a = nu - 1; a >= 0; a--) {
-                double v = y[a];
+            for (int m = 0; m < 6; m++) v += T[m][a]*gy[m];
+            g2[a] = v;
+        }
+        G2[3][3] += 1.0;
 #pragma unroll
-                for (int k = a + 1; k < nu; k++) v -= L[k][a]*x[k];
-                x[a] = v/L[a][a];
-            }
+        for (int a = 0; a < 6; a++) {
 #pragma unroll
-            for (int a = 0; a < 3; a++) K[a][c] = x[a];
+            for (int b = 0; b < 6; b++) G[a][b] = G2[a][b];
+            g[a] = g2[a];
+        }
+    }
+    /* eliminate the controls: Cholesky of the control block */
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) L[a][b] = 0;
+#pragma unroll
+    for (int j = 0; j < nu; j++) {
+        double d = G[3 + j][3 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k]*L[j][k];
+        if (!(d > 0) || !isfinite(d)) { w.ok = false; d = 1.0; }
+        L[j][j] = sqrt(d);
+#pragma unroll
+        for (int a = j + 1; a < nu; a++) {
+            double v = G[3 + a][3 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[a][k]*L[j][k];
+            L[a][j] = v/L[j][j];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {      /* K: columns t, b, q and the constant */
+        double y[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < nu; a++) {
+            double v = -(c < 3 ? G[3 + a][c] : g[3 + a]);
+#pragma unroll
+            for (int k = 0; k < a; k++) v -= L[a][k]*y[k];
+            y[a] = v/L[a][a];
         }
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
+        for (int a = nu - 1; a >= 0; a--) {
+            double v = y[a];
 #pragma unroll
-            for (int b = 0; b < 3; b++) {
-                double v = G[a][b];
-#pragma unroll
-                for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][b];
-                P[a][b] = v;
-            }
-            double v = g[a];
-#pragma unroll
-            for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][3];
-            pv[a] = v;
+            for (int k = a + 1; k < nu; k++) v -= L[k][a]*x[k];
+            x[a] = v/L[a][a];
         }
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int a = 0; a < 3; a++) K[a][c] = x[a];
+    }
 #pragma unroll
-            for (int b = a + 1; b < 3; b++) { const double m = 0.5*(P[a][b] + P[b][a]); P[a][b] = P[b][a] = m; }
-        if (!pn) { K[1][0] = K[1][1] = K[1][2] = K[1][3] = 0; }
-        s[S_K + 0] = K[0][0]; s[S_K + 1] = K[0][1]; s[S_K + 2] = K[0][2]; s[S_K + 3] = K[1][0]; s[S_K + 4] = K[1][1]; s[S_K + 5] = K[1][2];
-        s[S_KV + 0] = K[0][3]; s[S_KV + 1] = K[1][3];
-        s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3];      /* (over the slack row's inputs, which are used up) */
-    };
-    backward(N - 1, std::true_type());
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            double v = G[a][b];
+#pragma unroll
+            for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][b];
+            w.P[a][b] = v;
+        }
+        double v = g[a];
+#pragma unroll
+        for (int m = 0; m < nu; m++) v += G[a][3 + m]*K[m][3];
+        w.pv[a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = a + 1; b < 3; b++) { const double m = 0.5*(w.P[a][b] + w.P[b][a]); w.P[a][b] = w.P[b][a] = m; }
+    if (!pn) { K[1][0] = K[1][1] = K[1][2] = K[1][3] = 0; }
+    s[S_K + 0] = K[0][0]; s[S_K + 1] = K[0][1]; s[S_K + 2] = K[0][2]; s[S_K + 3] = K[1][0]; s[S_K + 4] = K[1][1]; s[S_K + 5] = K[1][2];
+    s[S_KV + 0] = K[0][3]; s[S_KV + 1] = K[1][3];
+    s[S_KS + 0] = K[2][0]; s[S_KS + 1] = K[2][1]; s[S_KS + 2] = K[2][2]; s[S_KS + 3] = K[2][3];      /* (over the slack row's inputs, which are used up) */
+}
+
+/* one stage of the forward sweep: (dt, db, dq) of stage i in, of stage i+1 out; steps and new multipliers into the stage's block */
+template <int DYN>
+__device__ __forceinline__ void resto_forward_stage(const int i, const bool last, const bool pn, double *S, const double *Dtv, const double *Dbv, const double *X, const int NS,
+                                                    const bool swapLast, double &x0, double &x1, double &x2)
+{
+    constexpr int S_STRIDE = stage_stride(DYN);
+    double *s = S + i*S_STRIDE;
+    const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
+    const double Dt = Dtv[i], Db = Dbv[i];
+    const double u0 = s[S_K + 0]*x0 + s[S_K + 1]*x1 + s[S_K + 2]*x2 + s[S_KV + 0];
+    const double u1 = pn ? s[S_K + 3]*x0 + s[S_K + 4]*x1 + s[S_K + 5]*x2 + s[S_KV + 1] : 0.0;
+    const double dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
+    double df = u0, dp = u1;
+    if (last) {
+        /* u0: v, u1: the force that was kept */
+        const double de = -Bb/Bw*x1 - u1 - rb/Bw - sqrt(Db)/Bw*u0;
+        df = swapLast ? u1 : de; dp = swapLast ? de : u1;
+    }
+    const double dw = df + dp;
+    const double at = x0 + Tb*x1 + Tw*dw + rt, ab = last ? 0.0 : Bb*x1 + Bw*dw + rb;
+    const double Ptt = s[S_PN + 0], Ptb = s[S_PN + 1], Ptq = s[S_PN + 2], Pbb = s[S_PN + 3], Pbq = s[S_PN + 4];
+    double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
+    /* + E^T y */
+    if (DYN == LOSS_TABLE && !last) g1 += s[S_EB]*x1 + s[S_ES]*dsl;
+    if (loss_integrated(DYN)) g0 += -X[0*NS + i]*x0 + X[1*NS + i]*x1 + X[2*NS + i]*df + X[3*NS + i]*dp + X[4*NS + i]*dsl;
+    double lt, lb, nt, nb;
+    if (last) { lt = -g0/(1 + Ptt*Dt); lb = u0/sqrt(Db); nt = at + Dt*lt; nb = 0; }
+    else {
+        const double a00 = 1 + Ptt*Dt, a01 = Ptb*Db, a10 = Ptb*Dt, a11 = 1 + Pbb*Db, det = a00*a11 - a01*a10;
+        lt = -(a11*g0 - a01*g1)/det; lb = -(a00*g1 - a10*g0)/det;
+        nt = at + Dt*lt; nb = ab + Db*lb;
+    }
+    s[S_DT] = x0; s[S_DB] = x1; s[S_DF] = df; s[S_DP] = dp; s[S_DS] = dsl; s[S_LT] = lt; s[S_LB] = lb;
+    x0 = nt; x1 = nb; x2 = df;
+}
+
+template <int DYN>
+__device__ __noinline__ bool riccati_resto(const int N, const bool pn, double *S, const double *Dtv, const double *Dbv, const double *X, const int NS)
+{
+    constexpr int S_STRIDE = stage_stride(DYN);
+    /* Round 3 kept every array of the sweeps in the work area (run-time indices): the stack of this cold function sized the scratch memory of
+     * every launch of the kernel it was compiled into.  Since round 4 it only lives in follow-up kernels (solve_kernel: PART = 2), so the
+     * arrays are locals with compile-time indices -- registers -- and the last interval is peeled off the stage loop */
+    RestoSweep w;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        w.pv[a] = 0;
+#pragma unroll
+        for (int b = 0; b < 3; b++) w.P[a][b] = 0;
+    }
+    w.P[0][0] = S[N*S_STRIDE + S_HTT]; w.pv[0] = S[N*S_STRIDE + S_HT];
+    w.ok = true; w.swapLast = false;
+    resto_backward_stage<DYN, true>(N - 1, pn, S, Dtv, Dbv, X, NS, w);
 #pragma unroll 1
-    for (int i = N - 2; i >= 0; i--) backward(i, std::false_type());
-    if (!ok) return false;
+    for (int i = N - 2; i >= 0; i--) resto_backward_stage<DYN, false>(i, pn, S, Dtv, Dbv, X, NS, w);
+    if (!w.ok) return false;
 
     double x0 = 0, x1 = 0, x2 = 0;      /* (dt, db, dq) of the stage; x_0 is a parameter */
 #pragma unroll 1
-    for (int i = 0; i < N; i++) {
-        double *s = S + i*S_STRIDE;
-        const bool last = i == N - 1;
-        const double Tb = s[S_TB], Tw = s[S_TW], Bb = s[S_BB], Bw = s[S_BW], rt = s[S_RT], rb = s[S_RB];
-        const double Dt = Dtv[i], Db = Dbv[i];
-        const double u0 = s[S_K + 0]*x0 + s[S_K + 1]*x1 + s[S_K + 2]*x2 + s[S_KV + 0];
-        const double u1 = pn ? s[S_K + 3]*x0 + s[S_K + 4]*x1 + s[S_K + 5]*x2 + s[S_KV + 1] : 0.0;
-        const double dsl = s[S_KS + 0]*x0 + s[S_KS + 1]*x1 + s[S_KS + 2]*x2 + s[S_KS + 3];
-        double df = u0, dp = u1;
-        if (last) {
-            /* u0: v, u1: the force that was kept */
-            const double de = -Bb/Bw*x1 - u1 - rb/Bw - sqrt(Db)/Bw*u0;
-            df = swapLast ? u1 : de; dp = swapLast ? de : u1;
-        }
-        const double dw = df + dp;
-        const double at = x0 + Tb*x1 + Tw*dw + rt, ab = last ? 0.0 : Bb*x1 + Bw*dw + rb;
-        const double Ptt = s[S_PN + 0], Ptb = s[S_PN + 1], Ptq = s[S_PN + 2], Pbb = s[S_PN + 3], Pbq = s[S_PN + 4];
-        double g0 = Ptt*at + Ptb*ab + Ptq*df + s[S_PV + 0], g1 = Ptb*at + Pbb*ab + Pbq*df + s[S_PV + 1];
-        /* + E^T y */
-        if (DYN == LOSS_TABLE && !last) g1 += s[S_EB]*x1 + s[S_ES]*dsl;
-        if (loss_integrated(DYN)) g0 += -X[0*NS + i]*x0 + X[1*NS + i]*x1 + X[2*NS + i]*df + X[3*NS + i]*dp + X[4*NS + i]*dsl;
-        double lt, lb, nt, nb;
-        if (last) { lt = -g0/(1 + Ptt*Dt); lb = u0/sqrt(Db); nt = at + Dt*lt; nb = 0; }
-        else {
-            const double a00 = 1 + Ptt*Dt, a01 = Ptb*Db, a10 = Ptb*Dt, a11 = 1 + Pbb*Db, det = a00*a11 - a01*a10;
-            lt = -(a11*g0 - a01*g1)/det; lb = -(a00*g1 - a10*g0)/det;
-            nt = at + Dt*lt; nb = ab + Db*lb;
-        }
-        s[S_DT] = x0; s[S_DB] = x1; s[S_DF] = df; s[S_DP] = dp; s[S_DS] = dsl; s[S_LT] = lt; s[S_LB] = lb;
-        x0 = nt; x1 = nb; x2 = df;
-    }
+    for (int i = 0; i < N; i++) resto_forward_stage<DYN>(i, i == N - 1, pn, S, Dtv, Dbv, X, NS, w.swapLast, x0, x1, x2);
     S[N*S_STRIDE + S_DT] = x0; S[N*S_STRIDE + S_DB] = 0.0; S[N*S_STRIDE + S_DF] = 0.0;
     return true;
 }
@@ -1744,6 +1757,11 @@ struct ParallelRiccati {
         return 1;
     }
 };
+
+#ifndef MSD_PARALLEL_RESTO
+#define MSD_PARALLEL_RESTO 1      /* 0: the restoration problem's Newton system on riccati_resto's serial sweeps alone (A/B builds) */
+#endif
+#include "msd_resto_scan.hpp"
 
 /* ------------------------------------------------------------------------------------------
  * the solver.  SPT = shooting nodes per thread: node j of thread `tid` is node tid + j*NT.

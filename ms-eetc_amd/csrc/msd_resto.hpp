@@ -185,10 +185,48 @@ __device__ __forceinline__ int restoration(const double *scen, double *hist, int
         bool ok;
         for (bool first = true;; first = false) {
             assemble(MODE_RESTO, mu, dw, eta);
-            if (c.tid == 0) c.misc[0] = riccati_resto<DYN>(N, withPn(), c.S, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS, work + (size_t)W_RX*NS, NS) ? 1.0 : 0.0;
-            __syncthreads();
-            ok = uni(c.misc[0]) != 0.0;
-            __syncthreads();
+            /* static loss rows: the sweeps on the stage-parallel scan (msd_resto_scan.hpp); -1: the scan broke down, or another loss model -- one lane sweeps */
+            int par = -1;
+#ifdef MSD_RESTO_CHECK      /* host emulation only: both solves of the same system side by side, the largest difference of their results printed */
+            double *chk_blocks = nullptr, *chk_out = nullptr;
+            if constexpr (DYN == LOSS_STATIC) {
+                if (c.tid == 0) { chk_blocks = (double *)malloc(sizeof(double)*S_STRIDE*(N + 1)); memcpy(chk_blocks, c.S, sizeof(double)*S_STRIDE*(N + 1)); }
+                __syncthreads();
+            }
+#endif
+            if constexpr (DYN == LOSS_STATIC && MSD_PARALLEL_RESTO && MSD_PARALLEL_RICCATI) par = ParallelResto<SPT>::solve(N, withPn(), c, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS);
+#ifdef MSD_RESTO_CHECK
+            if constexpr (DYN == LOSS_STATIC) {
+                __syncthreads();
+                if (c.tid == 0) {
+                    chk_out = (double *)malloc(sizeof(double)*S_STRIDE*(N + 1)); memcpy(chk_out, c.S, sizeof(double)*S_STRIDE*(N + 1));
+                    memcpy(c.S, chk_blocks, sizeof(double)*S_STRIDE*(N + 1));
+                    const bool sok = riccati_resto<DYN>(N, withPn(), c.S, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS, work + (size_t)W_RX*NS, NS);
+                    double worst = 0; int wi = -1, wk = -1;
+                    const int slots[7] = {S_DT, S_DB, S_DF, S_DP, S_DS, S_LT, S_LB};
+                    if (sok && par == 1)
+                        for (int k = 0; k < 7; k++) {      /* per kind of result: largest difference over the stages against the largest entry */
+                            double scale = 0;
+                            for (int i = 0; i < N; i++) scale = fmax(scale, fabs(c.S[i*S_STRIDE + slots[k]]));
+                            for (int i = 0; i <= (k == 0 ? N : N - 1); i++) {
+                                const double a = chk_out[i*S_STRIDE + slots[k]], b = c.S[i*S_STRIDE + slots[k]];
+                                const double d = fabs(a - b)/fmax(1e-300, scale);
+                                if (!(d <= worst)) { worst = d; wi = i; wk = k; }
+                            }
+                        }
+                    printf("RESTO_CHECK N %d par %d serial %d worst rel diff %.3e at stage %d slot %d\n", N, par, (int)sok, worst, wi, wk);
+                    if (par == 1) memcpy(c.S, chk_out, sizeof(double)*S_STRIDE*(N + 1));      /* go on with the parallel result */
+                    free(chk_blocks); free(chk_out);
+                }
+                __syncthreads();
+            }
+#endif
+            if (par < 0) {
+                if (c.tid == 0) c.misc[0] = riccati_resto<DYN>(N, withPn(), c.S, work + (size_t)W_RD*NS, work + (size_t)(W_RD + 1)*NS, work + (size_t)W_RX*NS, NS) ? 1.0 : 0.0;
+                __syncthreads();
+                ok = uni(c.misc[0]) != 0.0;
+                __syncthreads();
+            } else ok = par == 1;
             if (ok) break;
             if (first) dw = (delta_last == 0) ? DW_0 : fmax(DW_MIN, KW_MINUS*delta_last);
             else dw *= (delta_last == 0) ? KW_PLUS_BAR : KW_PLUS;
