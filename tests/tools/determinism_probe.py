@@ -2,7 +2,7 @@
 status, iterations and residuals of every launch (a library is deterministic when the six lines agree), multipliers of a failed solve.   usage: determinism_probe.py SEED 0"""
 import os, sys, tempfile
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in ('ms-eetc_amd', '', 'tests'):
     sys.path.insert(0, str(ROOT / p))
 import numpy as np

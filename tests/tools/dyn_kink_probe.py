@@ -2,7 +2,7 @@
 how far the mid-point speeds of the final iterate are from the kink of the loss model at the turning speed Pmax/Fmax (efficiency.py:7-12).  Restoration phase off:
 the plain iteration's stalling point.   usage: dyn_kink_probe.py"""
 import os, sys
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ('ms-eetc_amd','','tests'): sys.path.insert(0, os.path.join(ROOT,p))
 import numpy as np
 import cases
