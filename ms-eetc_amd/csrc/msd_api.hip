@@ -133,12 +133,12 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     const bool full_rg = d->with_pn_brake == 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                          && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
     msd::Geometry geo = itab ? msd::pick_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
-                        : dyn ? msd::pick_geometry_dynamic(N) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
+                        : dyn ? msd::pick_geometry_dynamic(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
     size_t lds = geo.fn ? sizeof(double)*(size_t)(msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) + msd::coop_doubles(geo.NT, gen) + geo.extra) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */
         geo = itab ? msd::pick_stream_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_stream_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_stream_geometry_general_intloss(N) : gen ? msd::pick_stream_geometry_general(N) : intloss ? msd::pick_stream_geometry_intloss(N)
-              : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N);
+              : dyn ? msd::pick_stream_geometry_dynamic(N) : msd::pick_stream_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
         lds = sizeof(double)*(size_t)msd::lds_doubles_stream();
         if (!geo.fn)
             return fail(MSD_E_UNSUPPORTED, (gen || intloss || dyn) ? "numIntervals = " + std::to_string(N) + " exceeds the 1023 intervals of the streamed kernels for the dynamic loss model, the collocation / adaptive shooting integrators and integrateLosses"

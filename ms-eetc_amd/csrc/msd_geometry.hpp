@@ -34,8 +34,12 @@ KernelFn follow_kernel_full(int NT, int SPT);       /* follow-up kernels of that
 KernelFn soc_kernel_full(int NT, int SPT, bool slds);      /* msd_kernels_full4.hip; nullptr: none for this geometry */
 Geometry pick_geometry_full_rg(int N);                /* the same with the regenerative brake alone (FULL_RG: msd_kernels_rg.hip, msd_kernels_rg2.hip) */
 KernelFn follow_kernel_full_rg(int NT, int SPT);
-Geometry pick_geometry_dynamic(int N);
-Geometry pick_stream_geometry_static(int N);
+Geometry pick_geometry_dynamic(int N, int full = 0);      /* full: FULL_BOTH / FULL_RG where the problem has that structure (msd_api.hip: make_plan) */
+Geometry pick_geometry_dynamic_full_rg(int N);      /* (msd_kernels_dynamic2.hip) */
+Geometry pick_geometry_dynamic_full_both(int N);    /* (msd_kernels_dynamic3.hip) */
+Geometry pick_stream_geometry_static(int N, int full = 0);      /* full: FULL_BOTH / FULL_RG -- that structure compiled into the first pass (the follow-up kernel stays general) */
+KernelFn stream_first_pass_full_rg(int SPT);       /* (msd_kernels_stream5.hip) */
+KernelFn stream_first_pass_full_both(int SPT);     /* (msd_kernels_stream6.hip) */
 Geometry pick_geometry_general_long(int N);      /* 257 ... 640 nodes of the same family (msd_kernels_general2.hip) */
 Geometry pick_geometry_general(int N, bool full = false);      /* collocation / adaptive shooting integrators (static loss models, LDS-resident) */
 Geometry pick_geometry_intloss(int N, bool full = false);      /* integrateLosses: loss slacks from the integrated loss power (static efficiencies, LDS-resident) */

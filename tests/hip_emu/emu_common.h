@@ -66,12 +66,12 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
 struct EmuArgs { msd::DevProb P; int nscen; const double *scen, *ovr; double *z, *lam, *stats, *hist; int cap; };
 bool emu_run_static(int NT, int SPT, const EmuArgs &a);
 bool emu_run_full(int NT, int SPT, const EmuArgs &a, int kind);      /* kind: msd::FULL_BOTH or msd::FULL_RG */
-bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a);
+bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a, int full = 0);
 bool emu_run_general(int NT, int SPT, const EmuArgs &a);
 bool emu_run_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_general_intloss(int NT, int SPT, const EmuArgs &a);
 bool emu_run_intloss_table(int NT, int SPT, const EmuArgs &a);
-bool emu_run_stream(const EmuArgs &a);
+bool emu_run_stream(const EmuArgs &a, int full = 0);
 #define EMU_CALL(...) run_blocks<__VA_ARGS__>(a.P, a.nscen, a.scen, a.ovr, a.z, a.lam, a.stats, a.hist, a.cap)
 
 /* a split solve of a family without LDS-resident follow-up kernels, like msd_api.hip: launch_plan does it: the first pass (PART = 1: the general iteration

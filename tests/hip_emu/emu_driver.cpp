@@ -59,7 +59,11 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     int NT = 0, SPT = 0;
     if (force && !strcmp(force, "stream")) {      /* the long-horizon kernel (stage blocks in memory) at a thread count the emulation can afford */
         if (dyn || nodes > 128*5) return -3;
-        return emu_run_stream(a) ? 0 : -3;
+        {   /* the first pass with the structure of the rolling stock compiled in where the problem has it, like msd_api.hip: make_plan */
+            const char *nf = getenv("EMU_NO_FULL");
+            const bool st = P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nf && *nf == '1');
+            return emu_run_stream(a, st ? (P.withPn ? msd::FULL_BOTH : msd::FULL_RG) : 0) ? 0 : -3;
+        }
     }
     if (force) sscanf(force, "%dx%d", &NT, &SPT);
     else if (nodes <= 64) { NT = 64; SPT = 1; }
@@ -74,5 +78,8 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     const char *nofull = getenv("EMU_NO_FULL");
     const bool full = !dyn && P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nofull && *nofull == '1');
     if (full && emu_run_full(NT, SPT, a, P.withPn ? msd::FULL_BOTH : msd::FULL_RG)) return 0;
+    /* the loss-table family with that structure compiled in, chosen like msd_api.hip does (first-pass kernels of msd_kernels_dynamic2.hip / 3.hip) */
+    const bool structured = P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nofull && *nofull == '1');
+    if (dyn && structured && emu_run_dynamic(NT, SPT, a, P.withPn ? msd::FULL_BOTH : msd::FULL_RG)) return 0;
     return (dyn ? emu_run_dynamic(NT, SPT, a) : emu_run_static(NT, SPT, a)) ? 0 : -3;
 }
