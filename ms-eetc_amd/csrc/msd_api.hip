@@ -132,8 +132,11 @@ int make_plan(int device, const msd_problem_desc *d, Plan *out)
     /* the same without the pneumatic brake (forceMinPn = 0: the reference's scripts); static loss rows + explicit Runge-Kutta shooting only */
     const bool full_rg = d->with_pn_brake == 0 && d->has_power_rows != 0 && d->energy_optimal != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max)
                          && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
+    /* the time-optimal problem on the same rolling stock (energyOptimal = False: minimumTime, the twins of msd_mpc.hip): power rows and acceleration row, no loss rows */
+    const bool full_time = d->energy_optimal == 0 && d->has_power_rows != 0 && std::isfinite(d->acc_min) && std::isfinite(d->acc_max) && std::isfinite(d->pw_upper) && std::isfinite(d->pw_lower);
+    const int structure = full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : full_time ? (d->with_pn_brake != 0 ? msd::FULL_TIME_BOTH : msd::FULL_TIME_RG) : 0;
     msd::Geometry geo = itab ? msd::pick_geometry_intloss_table(N) : (gen && dyn) ? msd::pick_geometry_general_dynamic(N) : (gen && intloss) ? msd::pick_geometry_general_intloss(N) : gen ? msd::pick_geometry_general(N, full) : intloss ? msd::pick_geometry_intloss(N, full)
-                        : dyn ? msd::pick_geometry_dynamic(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0) : msd::pick_geometry_static(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0);
+                        : dyn ? msd::pick_geometry_dynamic(N, full ? msd::FULL_BOTH : full_rg ? msd::FULL_RG : 0) : msd::pick_geometry_static(N, structure);
     size_t lds = geo.fn ? sizeof(double)*(size_t)(msd::lds_doubles(N, geo.NT*geo.SPT, wide, geo.xch, geo.red) + msd::coop_doubles(geo.NT, gen) + geo.extra) : 0;
     if (!geo.fn || lds > 160*1024) {
         /* the stage blocks do not fit the LDS of a compute unit: the streamed kernels keep them in device memory */

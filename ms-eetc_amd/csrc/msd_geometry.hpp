@@ -28,7 +28,9 @@ struct Geometry {
 struct Tuning { bool no_full = false, two_nodes_per_lane = false; };
 Tuning &tuning();      /* (msd_api.hip) */
 
-Geometry pick_geometry_static(int N, int full);     /* full: FULL_BOTH / FULL_RG -- the kernels with that structure compiled in (0: none) */
+Geometry pick_geometry_static(int N, int full);     /* full: FULL_BOTH / FULL_RG / FULL_TIME_* -- the kernels with that structure compiled in (0: none) */
+Geometry pick_geometry_time_rg(int N);              /* time-optimal problem, structure compiled in (FULL_TIME_RG: msd_kernels_time.hip; FULL_TIME_BOTH: msd_kernels_time2.hip) */
+Geometry pick_geometry_time_both(int N);
 Geometry pick_geometry_full(int N);                   /* static loss model, that structure compiled in (msd_kernels_full.hip); fn == nullptr: none for this horizon */
 KernelFn follow_kernel_full(int NT, int SPT);       /* follow-up kernels of that family (msd_kernels_full3.hip) */
 KernelFn soc_kernel_full(int NT, int SPT, bool slds);      /* msd_kernels_full4.hip; nullptr: none for this geometry */

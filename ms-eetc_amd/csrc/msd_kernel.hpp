@@ -149,6 +149,12 @@ __host__ __device__ constexpr bool loss_integrated(int dyn) { return dyn == LOSS
  * 2 the same with the regenerative brake alone (forceMinPn = 0: what every script of the reference sets -- figure5.py:88, figure6.py:108,
  * figure10.py:17, table3.py:18) */
 constexpr int FULL_BOTH = 1, FULL_RG = 2;
+/* 3, 4 (round 6): the time-optimal twins of 1 and 2 (ocp.py:150 -- minimum running time with 1e-4 (f^2 + p^2): power rows and acceleration row on and two-sided, no loss
+ * rows): the problems of OptionsCasadiSolver.energyOptimal = False on the reference's rolling stock, config 4's minimum-time certificates (msd_mpc.hip) */
+constexpr int FULL_TIME_BOTH = 3, FULL_TIME_RG = 4;
+__host__ __device__ constexpr bool full_energy(int full) { return full == FULL_BOTH || full == FULL_RG; }
+__host__ __device__ constexpr bool full_time(int full) { return full == FULL_TIME_BOTH || full == FULL_TIME_RG; }
+__host__ __device__ constexpr bool full_pn(int full) { return full == FULL_BOTH || full == FULL_TIME_BOTH; }
 constexpr int S_STRIDE_STATIC = 27, S_STRIDE_DYN = 31;
 __host__ __device__ constexpr int stage_stride(bool dyn) { return dyn ? S_STRIDE_DYN : S_STRIDE_STATIC; }
 constexpr int FILT_CAP = 64;
@@ -777,7 +783,7 @@ __device__ __forceinline__ void eval_interval(const DevProb &P, const Uni &U, co
                                               double (&cv)[2], double (&dv)[NR], Ev &e, const Jet *ptau = nullptr, const Jet *pbp = nullptr,
                                               const double *vtau = nullptr, const double *vbp = nullptr)
 {
-    const double b = x[VB], f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0, s = x[VS];
+    const double b = x[VB], f = x[VF], p = (full_pn(FULL) || (FULL == 0 && P.withPn)) ? x[VP] : 0.0, s = x[VS];
     if (DERIV) {
         Jet tau, bp;
         if (ptau) { tau = *ptau; bp = *pbp; }      /* (the interval map evaluated by the lanes of the wave together: Solver::coop_adaptive) */
@@ -855,12 +861,12 @@ __device__ __forceinline__ double objective_term(const DevProb &P, const NodeT &
 {
     double J = 0;
     if (n.ival()) {
-        const double f = x[VF], p = (FULL == FULL_BOTH || (FULL == 0 && P.withPn)) ? x[VP] : 0.0;
-        if (FULL || P.energyOpt) {
+        const double f = x[VF], p = (full_pn(FULL) || (FULL == 0 && P.withPn)) ? x[VP] : 0.0;
+        if (full_energy(FULL) || (FULL == 0 && P.energyOpt)) {
             J = LI ? n.ds*f + x[VS] : n.ds*(f + x[VS]);                       /* ocp.py:223 resp. :235 */
             if (n.i > 0) J += 1e-3*(f - q)*(f - q);                           /* ocp.py:245 */
         } else J = 1e-4*(f*f + p*p);                                          /* ocp.py:150 */
-    } else if (!FULL && n.i == P.N && !P.energyOpt) J = x[VT];
+    } else if (!full_energy(FULL) && n.i == P.N && (full_time(FULL) || !P.energyOpt)) J = x[VT];
     return sf*J/P.objDen;
 }
 
@@ -1798,11 +1804,11 @@ struct Solver {
     /* structure of the NLP.  FULL: traction + pneumatic brake, power rows, energy objective -- the rolling stock of the reference's JSON
      * files (BASELINE configs 1-4) -- known at compile time: no flag loads, no branches on them.  Rows then are: both power rows and the
      * acceleration row two-sided, the two loss rows bounded below (ocp.py:184-229) */
-    __device__ __forceinline__ bool rowOn(int r) const { return FULL ? true : U.rowOn[r]; }
-    __device__ __forceinline__ bool rL(int r) const { return FULL ? true : U.rL[r]; }
+    __device__ __forceinline__ bool rowOn(int r) const { return full_energy(FULL) ? true : full_time(FULL) ? (r <= RACC) : U.rowOn[r]; }      /* (time-optimal: no loss rows) */
+    __device__ __forceinline__ bool rL(int r) const { return full_energy(FULL) ? true : full_time(FULL) ? (r <= RACC) : U.rL[r]; }
     __device__ __forceinline__ bool rU(int r) const { return FULL ? (r <= RACC) : U.rU[r]; }
-    __device__ __forceinline__ bool withPn() const { return FULL == FULL_BOTH ? true : FULL == FULL_RG ? false : P.withPn != 0; }
-    __device__ __forceinline__ bool energyOpt() const { return FULL ? true : P.energyOpt != 0; }
+    __device__ __forceinline__ bool withPn() const { return FULL ? full_pn(FULL) : P.withPn != 0; }
+    __device__ __forceinline__ bool energyOpt() const { return FULL ? full_energy(FULL) : P.energyOpt != 0; }
     __device__ __forceinline__ bool hasPower() const { return FULL ? true : P.hasPower != 0; }
 
     __device__ __forceinline__ void store_ev(int j, const Ev &e)
@@ -2911,7 +2917,7 @@ struct Solver {
      * Anything rare -- wrong inertia, scan breakdown, a rejected first trial point (backtracking, second-order correction) --
      * repeats the iteration on the general path (run()).
      * ---------------------------------------------------------------------------------------- */
-    static constexpr bool FAST = FULL && DYN == LOSS_STATIC && !STREAM && !GEN && MSD_PARALLEL_RICCATI;
+    static constexpr bool FAST = full_energy(FULL) && DYN == LOSS_STATIC && !STREAM && !GEN && MSD_PARALLEL_RICCATI;
     static constexpr int HV = 6;      /* gradient side of a stage block: t, b, q, f, p and the slack row */
     double cnt_lam = 0, cnt_z = 0;    /* numbers of constraint and of bound multipliers (fused_pass) */
 

@@ -64,7 +64,7 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
 
 /* family dispatchers (emu_k_*.cpp): false when the family has no instantiation for (NT, SPT) */
 struct EmuArgs { msd::DevProb P; int nscen; const double *scen, *ovr; double *z, *lam, *stats, *hist; int cap; };
-bool emu_run_static(int NT, int SPT, const EmuArgs &a);
+bool emu_run_static(int NT, int SPT, const EmuArgs &a, int full = 0);
 bool emu_run_full(int NT, int SPT, const EmuArgs &a, int kind);      /* kind: msd::FULL_BOTH or msd::FULL_RG */
 bool emu_run_dynamic(int NT, int SPT, const EmuArgs &a, int full = 0);
 bool emu_run_general(int NT, int SPT, const EmuArgs &a);

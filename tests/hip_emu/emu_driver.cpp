@@ -81,5 +81,8 @@ extern "C" int emu_solve_batch_warm(const msd_problem_desc *d, int nscen, const 
     /* the loss-table family with that structure compiled in, chosen like msd_api.hip does (first-pass kernels of msd_kernels_dynamic2.hip / 3.hip) */
     const bool structured = P.hasPower && P.energyOpt && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nofull && *nofull == '1');
     if (dyn && structured && emu_run_dynamic(NT, SPT, a, P.withPn ? msd::FULL_BOTH : msd::FULL_RG)) return 0;
+    /* the time-optimal problem on the same rolling stock: first-pass kernels with that structure compiled in (msd_kernels_time.hip) */
+    const bool timed = !dyn && !P.energyOpt && P.hasPower && std::isfinite(P.accMin) && std::isfinite(P.accMax) && std::isfinite(P.pwU) && std::isfinite(P.pwL) && !(nofull && *nofull == '1');
+    if (timed && emu_run_static(NT, SPT, a, P.withPn ? msd::FULL_TIME_BOTH : msd::FULL_TIME_RG)) return 0;
     return (dyn ? emu_run_dynamic(NT, SPT, a) : emu_run_static(NT, SPT, a)) ? 0 : -3;
 }
