@@ -38,8 +38,8 @@ void run_blocks(msd::DevProb P, int nscen, const double *scen, const double *ovr
         emu_block blk;
         blk.nthreads = NT;
         pthread_barrier_init(&blk.bar, nullptr, NT);
-        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, (FULL && DYN == 0 && !GEN) ? msd::XCH_FAST : msd::XCH_GENERAL,
-                                                                                                   (FULL && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)) + (SLDS ? msd::STATIC_FIELDS*NT*SPT : 0));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
+        std::vector<double> shfl(NT), xch((size_t)NT*EMU_XCH), lds(STREAM ? msd::lds_doubles_stream() : msd::lds_doubles(P.N, NT*SPT, DYN != 0, (msd::full_energy(FULL) && DYN == 0 && !GEN) ? msd::XCH_FAST : msd::XCH_GENERAL,
+                                                                                                   (msd::full_energy(FULL) && DYN == 0 && !GEN && NT == 64) ? 0 : msd::RED_DOUBLES) + (STREAM ? 0 : msd::coop_doubles(NT, GEN)) + (SLDS ? msd::STATIC_FIELDS*NT*SPT : 0));      /* (exactly the LDS the launch code allocates: msd_geometry.hpp) */
         /* EMU_POISON=1 (environment): LDS and work area start as NaN instead of zero -- a read of shared memory before its first write, which on the
          * device sees whatever the kernel before left there, then shows in the results */
         const char *poison = getenv("EMU_POISON");
