@@ -11,4 +11,4 @@ export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export MSD_EMU_LIB="$out"
 cd "$here/../.."
-exec python3 -m pytest tests/test_kernel_emulation.py tests/test_shooting_integrators.py -q -x -k "emulated and not sanitizers"
+exec python3 -m pytest tests/test_kernel_emulation.py tests/test_shooting_integrators.py tests/test_restoration.py tests/test_watchdog.py tests/test_integrated_loss_table.py -q -x -k "emulated and not sanitizers"
