@@ -12,6 +12,10 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include <cstdio>
 #include <string>
 
@@ -142,29 +146,54 @@ extern "C" {
 
 const char *msd_post_last_error(void) { return g_post_err.c_str(); }
 
+/* Scratch of the two entry points, per device, grow-only, kept for the life of the process: a device buffer and a page-locked staging buffer of the same size.  A call
+ * packs its inputs into the staging buffer, copies them in one piece, launches, copies the results back in one piece -- eight synchronous copies, a hipMalloc and a
+ * hipFree per call were 0.45 of the 0.66 ms that casadiSolver.solve() spent in its re-simulation (round 6) */
+namespace {
+struct PostScratch { int device; double *d, *h; size_t cap; };
+std::mutex g_post_mu;
+std::vector<PostScratch> g_post;
+int post_scratch(int device, size_t doubles, double **d, double **h)
+{
+    for (PostScratch &p : g_post)
+        if (p.device == device) {
+            if (p.cap < doubles) {
+                hipFree(p.d); hipHostFree(p.h); p.d = p.h = nullptr; p.cap = 0;
+                if (hipMalloc((void **)&p.d, sizeof(double)*doubles) != hipSuccess || hipHostMalloc((void **)&p.h, sizeof(double)*doubles, hipHostMallocDefault) != hipSuccess) {
+                    hipFree(p.d); p.d = nullptr; (void)hipGetLastError();
+                    return post_fail(MSD_E_HIP, "no memory for the post-processing scratch");
+                }
+                p.cap = doubles;
+            }
+            *d = p.d; *h = p.h;
+            return MSD_OK;
+        }
+    g_post.push_back(PostScratch{device, nullptr, nullptr, 0});
+    return post_scratch(device, doubles, d, h);
+}
+}  // namespace
+
 int msd_resimulate(int device, int nscen, int N, const double *train5, const double *force, const double *dts, const double *grad, const double *curv,
                    const double *s0, const double *v0, double abstol, double reltol, double *pos_out, double *vel_out)
 {
     if (nscen < 1 || N < 1 || !train5 || !force || !dts || !grad || !curv || !s0 || !v0 || !pos_out || !vel_out) return post_fail(MSD_E_INVALID, "bad argument");
     if (hipSetDevice(device) != hipSuccess) return post_fail(MSD_E_NODEVICE, "no such device");
     const size_t nI = (size_t)nscen*N, nP = (size_t)nscen*(N + 1);
-    double *d = nullptr;
-    auto cleanup = [&]() { hipFree(d); };
-    const size_t total = 2*nI + 2*N + 2*nscen + 2*nP;
-    POST_TRY(hipMalloc((void **)&d, sizeof(double)*total));
+    const size_t nin = 2*nI + 2*N + 2*nscen, total = nin + 2*nP;
+    std::lock_guard<std::mutex> lock(g_post_mu);
+    double *d = nullptr, *h = nullptr;
+    int rc = post_scratch(device, total, &d, &h);
+    if (rc != MSD_OK) return rc;
+    auto cleanup = [&]() {};
     double *d_force = d, *d_dt = d_force + nI, *d_grad = d_dt + nI, *d_curv = d_grad + N, *d_s0 = d_curv + N, *d_v0 = d_s0 + nscen, *d_pos = d_v0 + nscen, *d_vel = d_pos + nP;
-    POST_TRY(hipMemcpy(d_force, force, sizeof(double)*nI, hipMemcpyHostToDevice));
-    POST_TRY(hipMemcpy(d_dt, dts, sizeof(double)*nI, hipMemcpyHostToDevice));
-    POST_TRY(hipMemcpy(d_grad, grad, sizeof(double)*N, hipMemcpyHostToDevice));
-    POST_TRY(hipMemcpy(d_curv, curv, sizeof(double)*N, hipMemcpyHostToDevice));
-    POST_TRY(hipMemcpy(d_s0, s0, sizeof(double)*nscen, hipMemcpyHostToDevice));
-    POST_TRY(hipMemcpy(d_v0, v0, sizeof(double)*nscen, hipMemcpyHostToDevice));
+    memcpy(h, force, sizeof(double)*nI); memcpy(h + nI, dts, sizeof(double)*nI); memcpy(h + 2*nI, grad, sizeof(double)*N); memcpy(h + 2*nI + N, curv, sizeof(double)*N);
+    memcpy(h + 2*nI + 2*N, s0, sizeof(double)*nscen); memcpy(h + 2*nI + 2*N + nscen, v0, sizeof(double)*nscen);
+    POST_TRY(hipMemcpy(d, h, sizeof(double)*nin, hipMemcpyHostToDevice));
     PostTrain T = {train5[0], train5[1], train5[2], train5[3], train5[4]};
     hipLaunchKernelGGL(resim_kernel, dim3((nscen + 63)/64), dim3(64), 0, 0, T, nscen, N, d_force, d_dt, d_grad, d_curv, d_s0, d_v0, abstol, reltol, d_pos, d_vel);
     POST_TRY(hipGetLastError());
-    POST_TRY(hipMemcpy(pos_out, d_pos, sizeof(double)*nP, hipMemcpyDeviceToHost));
-    POST_TRY(hipMemcpy(vel_out, d_vel, sizeof(double)*nP, hipMemcpyDeviceToHost));
-    cleanup();
+    POST_TRY(hipMemcpy(h + nin, d_pos, sizeof(double)*2*nP, hipMemcpyDeviceToHost));
+    memcpy(pos_out, h + nin, sizeof(double)*nP); memcpy(vel_out, h + nin + nP, sizeof(double)*nP);
     return MSD_OK;
 }
 

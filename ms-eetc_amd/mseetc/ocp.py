@@ -425,13 +425,9 @@ class casadiSolver():
         t = np.concatenate([body[:, 2 + pn], [z[stp*N]]])
         b = np.concatenate([body[:, 3 + pn], [z[stp*N + 1]]])
 
-        df = pd.DataFrame({'Time [s]': t, 'Position [m]': self.points.index.values}).set_index('Time [s]')
-        df['Velocity [m/s]'] = np.sqrt(b)
-        df['Force (el) [N]'] = Fel*self.totalMass
-        df['Force (pnb) [N]'] = Fpb*self.totalMass
-        df['Slacks'] = s*self.totalMass
-
-        return df
+        # (one construction: every column assigned to an existing frame costs a tenth of a millisecond)
+        return pd.DataFrame({'Position [m]': self.points.index.values, 'Velocity [m/s]': np.sqrt(b), 'Force (el) [N]': Fel*self.totalMass,
+                             'Force (pnb) [N]': Fpb*self.totalMass, 'Slacks': s*self.totalMass}, index=pd.Index(t, name='Time [s]'))
 
     def solve(self, terminalTime, initialTime=0, terminalVelocity=1, initialVelocity=1):
         "One scenario; returns (DataFrame or None, stats) like the reference (ocp.py:310-409)."
