@@ -818,6 +818,50 @@ def test_direct_results_are_the_copied_results():
     s.close()
 
 
+@pytest.mark.parametrize('family', ['loss_table_one_brake', 'loss_table_both_brakes', 'streamed', 'time_optimal'])
+def test_structure_compiled_in_matches_the_general_kernels(family):
+    """
+    Round 6 compiled the structure of the reference's rolling stock (rows on, row bounds, brakes, objective) into the first-pass kernels of three more families: the
+    loss table (msd_kernels_dynamic2/3.hip), the streamed static family (msd_kernels_stream5/6.hip) and the time-optimal problem (msd_kernels_time*.hip).  Same
+    iterates as the kernels that read that structure from the problem record (msd_tuning("no_full", 1)): status, iteration counts, objective, variables.
+    """
+    from mseetc._device import lib
+    from mseetc.ocp import casadiSolver
+    if family.startswith('loss_table'):
+        from mseetc.train import Train
+        from mseetc.efficiency import totalLossesFunction
+        train = Train(config={'id': 'NL_Intercity_VIRM6'})
+        if family.endswith('one_brake'):
+            train.forceMinPn = 0
+        train.powerLosses = totalLossesFunction(train, auxiliaries=27000, etaGear=0.96)
+        track, T, kw = cases.track_00(8500), 272.4726*np.array([1.08, 1.15, 1.25, 1.3]), dict(terminalVelocity=100/3.6)      # (not next to the kink bands of DESIGN.md section 8)
+        horizons, eo = (50, 100, 180), True
+    elif family == 'streamed':
+        train, track, T, kw, horizons, eo = cases.train_fig10(), cases.track_00(), np.array([1500.0, 1541.0, 1600.0]), {}, (700,), True
+    else:
+        train, track, T, kw, horizons, eo = cases.train_default(), cases.track_00(), np.array([1541.0, 1600.0]), {}, (50, 100, 200), True      # (through minimumTime: the twin is built there)
+    for N in horizons:
+        out = {}
+        for general in (0, 1):
+            assert lib().msd_tuning(b'no_full', general) == 0
+            try:
+                s = casadiSolver(train, track, dict(numIntervals=N, maxIterations=500, energyOptimal=eo, integrationOptions=dict(numSteps=1, numApproxSteps=1)), startingPoint='profile')
+                if family == 'time_optimal':
+                    tmin, ok = s.minimumTime(s._scenarios(T, 0, 1, 1))
+                    assert np.all(ok)
+                    out[general] = dict(status=np.zeros(len(T)), iterations=np.zeros(len(T)), cost=tmin, z=tmin[:, None])
+                else:
+                    out[general] = s.solveBatch(T, classifyFailures=False, **kw)
+                s.close()
+            finally:
+                lib().msd_tuning(b'no_full', 0)
+        a, b = out[0], out[1]
+        assert np.all(a['status'] == 0) and np.all(b['status'] == 0), (family, N, a['status'], b['status'])
+        assert np.max(np.abs(a['iterations'] - b['iterations'])) <= 1, (family, N, a['iterations'], b['iterations'])
+        assert np.max(np.abs(a['cost'] - b['cost'])/np.maximum(1.0, np.abs(b['cost']))) <= 1e-8, (family, N)      # (two builds of the same arithmetic: FMA contraction differs)
+        assert np.max(np.abs(a['z'] - b['z'])/np.maximum(1.0, np.abs(b['z']))) <= 1e-5, (family, N)
+
+
 def test_handle_reuse_across_problems():
     # msd_problem_reconfigure: one device handle carried through problems of different horizon, track and layout gives the
     # results of fresh handles (the receding-horizon loop reuses its stream and buffers this way)
